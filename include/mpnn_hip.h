@@ -1,0 +1,275 @@
+/*
+ * mpnn_hip.h -- C ABI of libmpnn_hip.so, the MI355X (gfx950) kernel library for
+ * the multipath-nn training hot path.
+ *
+ * The reference (MasonMcGill/multipath-nn) has no FFI: its boundary is the
+ * Python class protocol of scripts/lib/layer_types.py + scripts/lib/net_types.py
+ * whose arithmetic is delegated to TensorFlow ops.  Each entry point below
+ * replaces the TensorFlow op call sites it cites (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated; activations NHWC fp32,
+ *     filters HWIO fp32 (TensorFlow defaults, net_types.py:50-51);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *     allocates nothing, never synchronises and is hipGraph-capturable;
+ *   - return value: 0 = launched, >0 = hipError_t, <0 = MPNN_E_* (bad shape);
+ *     nothing throws across the ABI;
+ *   - "pre-activation" buffers hold the conv sums BEFORE BatchNorm; BatchNorm
+ *     (+ReLU) is applied by the consumer while loading (mpnn_act).
+ */
+#ifndef MPNN_HIP_H
+#define MPNN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPNN_E_SHAPE   (-1)   /* unsupported geometry / channel count      */
+#define MPNN_E_ARG     (-2)   /* inconsistent arguments                     */
+
+#define MPNN_ACT_IDENTITY 0   /* raw values (pyramid input, gradients)      */
+#define MPNN_ACT_BN_BATCH 1   /* relu(bn(x)) with batch statistics ('tr')   */
+#define MPNN_ACT_BN_MOVING 2  /* relu(bn(x)) with moving averages  ('ev')   */
+
+/* An activation as its consumer sees it: pre-activation values plus the
+ * BatchNorm + ReLU to apply on load.  Replaces BatchNorm.link / Rect.link /
+ * MultiscaleBatchNorm.link / MultiscaleRect.link (layer_types.py:219-249,
+ * 76-79, 196-199) and ToPyramid.link's strided pick (layer_types.py:118-125:
+ * `shift` = log2 of the subsampling factor). */
+typedef struct {
+    const float  *x;       /* [n, H<<shift, W<<shift, C]                      */
+    const double *sum;     /* [2*C]: sum, sum of squares over (n,H,W)         */
+    const float  *gamma, *beta, *m_avg, *v_avg;   /* [C] each                 */
+    float eps;             /* BatchNorm eps (layer_types.py:220)              */
+    int   cnt;             /* n*H*W: element count behind `sum`               */
+    int   C;
+    int   shift;
+    int   mode;            /* MPNN_ACT_*                                       */
+} mpnn_act;
+
+/* ---- weight packing ------------------------------------------------------
+ * HWIO [3][3][Cin][Cout] -> forward pack [9][ceil(Cin/16)][4][Cout][4]
+ * (k-interleaved so one 16-byte load feeds four v_mfma_f32_16x16x4_f32) and
+ * transposed+flipped pack for the input-gradient convolution.
+ * One launch packs `n_desc` tensors described by the device table `desc`
+ * (6 ints each: src_off, fwd_off, bwd_off, Cin, Cout, reserved; offsets in
+ * floats relative to `params` / `packs`). */
+int mpnn_pack_weights(const float *params, float *packs, const int *desc,
+                      int n_desc, void *stream);
+
+/* ---- multiscale conv block, forward --------------------------------------
+ * One scale of MultiscaleConvMax.link (layer_types.py:181-185):
+ *   out = bias + conv3x3_same(act(a)) [+ conv3x3_same(maxpool2x2(v))]
+ * and, fused, the per-channel sum / sum-of-squares that BatchNorm's
+ * tf.nn.moments needs (layer_types.py:232).  `v` is the PRE-BN output of the
+ * next finer scale, [n, 2H, 2W, Cv] (NULL for the first scale). */
+typedef struct {
+    mpnn_act a;
+    const float *v;  int Cv;
+    const float *wa_pack;  const float *wv_pack;   /* forward packs           */
+    const float *bias;                              /* [Cout]                  */
+    float  *out;                                    /* [n, H, W, Cout]         */
+    double *out_sum;                                /* [2*Cout], accumulated   */
+    int n, H, W, Cout;
+} mpnn_conv_fwd_args;
+int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
+
+/* ---- BatchNorm(+ReLU) backward pieces ------------------------------------
+ * Backward of `y = relu(gamma * (s - m) / sqrt(v + eps) + beta)` THROUGH the
+ * batch statistics (autodiff of layer_types.py:231-236):
+ *   dz   = dy * [y > 0]
+ *   red  = [sum dz, sum dz * xhat]                 (-> dbeta, dgamma)
+ *   g    = gamma*rstd * (dz - red0/cnt - xhat*red1/cnt)
+ * mpnn_bn_bwd_reduce computes dz and accumulates red; mpnn_bn_bwd_apply
+ * turns dz into g in place once red is complete. */
+typedef struct {
+    const float *s;        /* pre-BN values [n,H,W,C]                          */
+    mpnn_act bn;           /* the BatchNorm of s (x field unused)              */
+    const double *red;     /* [2*C] sum dz, sum dz*xhat (NULL: treat as zero)  */
+} mpnn_bn_ctx;
+int mpnn_bn_bwd_reduce(const float *dy, const mpnn_bn_ctx *ctx, float *dz,
+                       double *red_out, long n_pix, void *stream);
+int mpnn_bn_bwd_apply(float *dz_inout, const mpnn_bn_ctx *ctx, long n_pix,
+                      void *stream);
+
+/* ---- multiscale conv block, input gradients --------------------------------
+ * mpnn_msconv_dgrad_horz: dy = conv3x3_same^T(g, w_horz) [+ dy_extra], i.e. the
+ * gradient w.r.t. the block's (post-ReLU) input at this scale, fused with the
+ * producer's mpnn_bn_bwd_reduce (prev != NULL) or stored raw (prev == NULL).
+ * mpnn_msconv_dgrad_vert: dv = conv3x3_same^T(g, w_vert) at the coarse scale,
+ * routed through the 2x2 max-pool to the FIRST maximum of each window of the
+ * finer pre-BN map and added to that map's BatchNorm backward:
+ *   g_fine = bn_bwd_apply(dz_fine) + maxpool_bwd(dv)        (in place on dz_fine)
+ * Autodiff of layer_types.py:181-185. */
+typedef struct {
+    const float *g;  int Cg;            /* [n,H,W,Cg] gradient w.r.t. pre-BN sums */
+    const float *w_pack;                 /* backward pack                          */
+    const float *dy_extra;               /* [n,H,W,Cout] or NULL                   */
+    const mpnn_bn_ctx *prev;             /* producer BatchNorm context or NULL     */
+    float  *out;                         /* dz (prev != NULL) or dy                */
+    double *red_out;                     /* [2*Cout] accumulated (prev != NULL)    */
+    int n, H, W, Cout;
+} mpnn_dgrad_horz_args;
+int mpnn_msconv_dgrad_horz(const mpnn_dgrad_horz_args *args, void *stream);
+
+typedef struct {
+    const float *g;  int Cg;            /* coarse gradient [n,H,W,Cg]             */
+    const float *w_pack;                 /* backward pack of w_vert                */
+    const mpnn_bn_ctx *fine;             /* BatchNorm context of the finer scale   */
+    int fine_has_dz;                     /* 0: finer BN output has no consumer     */
+    float *dz_g_fine;                    /* [n,2H,2W,Cout]: dz in, g out           */
+    int n, H, W, Cout;                   /* H, W = COARSE size; Cout = fine chans  */
+} mpnn_dgrad_vert_args;
+int mpnn_msconv_dgrad_vert(const mpnn_dgrad_vert_args *args, void *stream);
+
+/* ---- multiscale conv block, weight gradients -------------------------------
+ * dW_horz = act(a)^T (*) g, dW_vert = maxpool2x2(v)^T (*) g, db = sum g,
+ * accumulated (fp32 atomics) into zeroed HWIO gradient tensors.  `n_split` =
+ * number of workgroups the pixel range is divided over. */
+typedef struct {
+    mpnn_act a;
+    const float *v;  int Cv;
+    const float *g;                      /* [n,H,W,Cout]                           */
+    float *dwa;  float *dwv;  float *db; /* HWIO grads, [Cout]                     */
+    int n, H, W, Cout;
+    int n_split;
+} mpnn_wgrad_args;
+int mpnn_msconv_wgrad(const mpnn_wgrad_args *args, void *stream);
+
+/* ---- exit head + router, first affine map ----------------------------------
+ * y_k = flatten(act(a)) @ w_k + b_k [+ alpha_cpt * k_cpt[n] * w_k[K]] for up to
+ * two weight sets sharing the input: the LogReg head's LinTrans and the
+ * router's first LinTrans (layer_types.py:39-53 after Select(-1),
+ * arch_and_hypers.py:45-49,66-70; the k_cpt column is net_types.py:149-160).
+ *
+ * The exit-path entry points are TABLE DRIVEN: `dev_table` is a DEVICE array
+ * of `count` argument records (uploaded once per plan); one launch serves every
+ * exit of the routing tree (the conv trunk does not depend on them). */
+typedef struct {
+    mpnn_act a;  int HW;                 /* input [n, HW, C] flattened to K=HW*C   */
+    const float *w[2];  const float *b[2];  float *y[2];  int M[2];   /* M <= 16   */
+    const float *k_cpt;  float alpha_cpt;  int extra_col[2];
+    int n;
+} mpnn_lin_fwd_args;
+int mpnn_lin_fwd(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void *stream);
+
+typedef struct {
+    mpnn_act a;  int HW;
+    const float *w[2];  const float *dy[2];  int M[2];
+    float *dw[2];  float *db[2];         /* written (not accumulated)              */
+    float *dx;                           /* [n, HW*C] written, or NULL             */
+    const float *k_cpt;  float alpha_cpt;  int extra_col[2];
+    int n;
+} mpnn_lin_bwd_args;
+int mpnn_lin_bwd(const mpnn_lin_bwd_args *dev_table, int count, int n_max, int k_max,
+                 void *stream);
+
+/* ---- exit tail: everything after the first affine map ----------------------
+ * Head: Softmax + CrossEntropyError (layer_types.py:81-84, 262-272).
+ * Router: BN -> ReLU -> LinTrans(R) -> BN -> ReLU -> LinTrans(n_sinks)
+ * (arch_and_hypers.py:47-49; BatchNorm over the batch, layer_types.py:219-239).
+ * One workgroup per exit owns the whole batch (batch statistics need every
+ * sample).  Limits: n_cls <= 32, R <= 16, n_sinks <= 8. */
+typedef struct {
+    /* head (z == NULL: no head at this exit) */
+    const float *z;  const float *y;  int n_cls;  float eps_ce;
+    float *c_err;  float *d_cor;                      /* [n] each               */
+    /* router (h1 == NULL: node has no router) */
+    const float *h1;  int R;  int n_sinks;            /* [n,R] pre-BN           */
+    const float *g1, *b1;  float *m1, *v1;            /* BN1 gamma/beta/avgs    */
+    const float *w2, *bias2;                          /* [R,R], [R]             */
+    const float *g2, *b2;  float *m2, *v2;
+    const float *w3, *bias3;                          /* [R,n_sinks], [n_sinks] */
+    float *h2;  float *r;  int r_stride;              /* [n,R] pre-BN2, [n,r_stride] */
+    float *bn_save;                                   /* [4*R] batch m1,rstd1,m2,rstd2 */
+    float bn_eps, bn_decay;
+    int mode;                                         /* MPNN_ACT_BN_BATCH / _MOVING */
+    int n;
+} mpnn_exit_tail_args;
+int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int count, void *stream);
+
+typedef struct {
+    mpnn_exit_tail_args f;
+    const float *w_cerr;                 /* [n] dL/dc_err                          */
+    const float *dr;                     /* [n,r_stride] dL/dr                     */
+    float *dz;                           /* [n,n_cls] dL/dz (head logits)          */
+    float *dh1;                          /* [n,R] dL/dh1                           */
+    float *dg1, *db1, *dw2, *dbias2, *dg2, *db2, *dw3, *dbias3;   /* written      */
+} mpnn_exit_tail_bwd_args;
+int mpnn_exit_tail_bwd(const mpnn_exit_tail_bwd_args *dev_table, int count, void *stream);
+
+/* ---- the router: routing probabilities, costs and their gradients ----------
+ * Replaces ActorNet._route/_route_sinks_dyn + cost assembly
+ * (net_types.py:108-131,165-177), CriticNet's (net_types.py:193-243,273-280)
+ * and SRNet's loss (net_types.py:93-95).  One thread per sample walks the
+ * routing tree given as a device table `nodes` (8 ints per node, DFS preorder:
+ * parent, sink_index, n_sinks, switch_id (-1: none), leaf_id (-1: none),
+ * n_leaves, reserved, reserved), `sw_children` [n_switches][max_sinks] node
+ * ids, and `node_ops` (n_ops + router.n_ops per node).
+ *   outputs: p_tr, p_ev [n_nodes][n]; w_cerr [n_leaves][n] = dL/dc_err;
+ *            dr [n_switches][n][max_sinks] = dL/dr; node_stat [n_nodes][2] =
+ *            sum p_tr, sum p_tr^2 (TALR, net_types.py:25-27), accumulated;
+ *            loss[4] accumulated sums: c_err, c_cpt, c_dec|c_cre, sample count.
+ * hyp = device floats indexed by MPNN_HYP_*. */
+#define MPNN_NET_SR     0
+#define MPNN_NET_ACTOR  1
+#define MPNN_NET_CRITIC 2
+#define MPNN_HYP_LR   0
+#define MPNN_HYP_MU   1
+#define MPNN_HYP_TAU  2
+#define MPNN_HYP_EPS  3
+#define MPNN_HYP_KCPT 4
+#define MPNN_HYP_KDEC 5
+#define MPNN_HYP_KCRE 6
+#define MPNN_HYP_ARTR 7
+#define MPNN_HYP_N    16
+#define MPNN_MAX_NODES 128
+#define MPNN_MAX_SINKS 4
+typedef struct {
+    int net_type;  int n_nodes, n_leaves, n_switches, max_sinks;
+    int optimistic, use_cls_err, want_grad;
+    const int *nodes;  const int *sw_children;  const float *node_ops;
+    const float *hyp;
+    const float *k_cpt_vec;              /* [n] per-sample k_cpt or NULL           */
+    const float *r;                      /* [n_switches][n][max_sinks]             */
+    const float *c_err;  const float *d_cor;          /* [n_leaves][n]             */
+    float *p_tr, *p_ev;                  /* [n_nodes][n]                           */
+    float *w_cerr;                       /* [n_leaves][n]                          */
+    float *dr;                           /* [n_switches][n][max_sinks]             */
+    float *node_stat;                    /* [n_nodes][2] accumulated               */
+    double *loss;                        /* [4] accumulated                        */
+    int n;  int n_total;                 /* n_total: samples the mean is over      */
+} mpnn_route_args;
+int mpnn_route(const mpnn_route_args *args, void *stream);
+
+/* On-device compaction of the 'ev' sub-batch that reaches a node: indices of
+ * samples with p_ev > 0, in order (wave64 ballot + prefix sum), and their
+ * count -- consumed by later launches without a host sync. */
+int mpnn_compact_by_branch(const float *p_ev, int n, int *idx_out, int *count_out,
+                           void *stream);
+
+/* ---- BatchNorm moving averages (layer_types.py:233-234) --------------------
+ * table: 6 ints per BN: sum_off (doubles), mavg_off, vavg_off (floats in
+ * `state`), C, pixels per image, reserved. */
+int mpnn_bn_finalize(const double *sums, float *state, const int *table, int n_bn,
+                     float decay, int n_img, void *stream);
+
+/* ---- TALR + L2 + momentum (net_types.py:24-37, tf.train.MomentumOptimizer) --
+ * For every trainable element: g = grad + 2*k_l2*pbar_node*(w - 0);
+ * g *= s_node (* alpha_rtr for router params), s_node = 1/sqrt(mean p_tr^2);
+ * accum = mu*accum + g; w -= lr*accum.  seg table: 6 ints per work item
+ * (offset, count, node, is_router, l2_bits (float as int), reserved).
+ * grad_scale multiplies the raw gradients (1/world_size after an all-reduce
+ * sum); inv_n = 1 / (samples behind node_stat). */
+int mpnn_talr_momentum_step(float *params, float *accum, const float *grads,
+                            const int *seg, int n_seg, const float *node_stat,
+                            const float *hyp, int talr, float inv_n, float grad_scale,
+                            void *stream);
+
+const char *mpnn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPNN_HIP_H */

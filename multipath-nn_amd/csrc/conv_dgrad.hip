@@ -1,0 +1,28 @@
+// Input-gradient convolutions of a MultiscaleConvMax scale (see conv_kernel.h).
+#include "conv_kernel.h"
+
+extern "C" int mpnn_msconv_dgrad_horz(const mpnn_dgrad_horz_args *a, void *stream) {
+    if (!a || !a->g || !a->w_pack || !a->out) return MPNN_E_ARG;
+    ConvP p = {};
+    p.a.x = a->g;  p.a.C = a->Cg;  p.a.mode = MPNN_ACT_IDENTITY;  p.a.shift = 0;
+    p.wa = a->w_pack;
+    p.n = a->n;  p.H = a->H;  p.W = a->W;  p.Cout = a->Cout;
+    p.extra = a->dy_extra;  p.out = a->out;
+    if (a->prev) {
+        if (!a->prev->s || !a->red_out) return MPNN_E_ARG;
+        p.sprev = a->prev->s;  p.pbn = a->prev->bn;  p.red_out = a->red_out;
+        return conv_launch<EPI_DGH_BN>(p, (hipStream_t)stream);
+    }
+    return conv_launch<EPI_DGH_RAW>(p, (hipStream_t)stream);
+}
+
+extern "C" int mpnn_msconv_dgrad_vert(const mpnn_dgrad_vert_args *a, void *stream) {
+    if (!a || !a->g || !a->w_pack || !a->fine || !a->fine->s || !a->dz_g_fine) return MPNN_E_ARG;
+    ConvP p = {};
+    p.a.x = a->g;  p.a.C = a->Cg;  p.a.mode = MPNN_ACT_IDENTITY;  p.a.shift = 0;
+    p.wa = a->w_pack;
+    p.n = a->n;  p.H = a->H;  p.W = a->W;  p.Cout = a->Cout;
+    p.out = a->dz_g_fine;  p.sprev = a->fine->s;  p.pbn = a->fine->bn;
+    p.red = a->fine_has_dz ? a->fine->red : nullptr;  p.has_dz = a->fine_has_dz;
+    return conv_launch<EPI_DGV>(p, (hipStream_t)stream);
+}

@@ -1,0 +1,235 @@
+// Small HBM-bound kernels around the conv path: weight packing, BatchNorm
+// backward pieces, moving averages, TALR+momentum update, branch compaction.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// mpnn_pack_weights
+// fwd pack [9][nchF][4][Cout][4]:  (tap, ch, gb, co, j) <- W[tap][ch*16+4gb+j][co]
+// bwd pack [9][nchB][4][Cin ][4]:  (tap, ch, gb, ci, j) <- W[8-tap][ci][ch*16+4gb+j]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_k(const float *__restrict__ params, float *__restrict__ packs,
+                                              const int *__restrict__ desc) {
+    const int *d = desc + blockIdx.x * 6;
+    const int src = d[0], fwd = d[1], bwd = d[2], Cin = d[3], Cout = d[4];
+    const int tap = blockIdx.y;
+    const float *W = params + src;
+    if (fwd >= 0) {
+        const int nch = (Cin + 15) >> 4, per_tap = nch * 16 * Cout;
+        float *dst = packs + fwd + (size_t)tap * per_tap;
+        for (int i = threadIdx.x; i < per_tap; i += 256) {
+            const int j = i & 3, co = (i >> 2) % Cout, rest = (i >> 2) / Cout;   // rest = ch*4 + gb
+            const int c = rest * 4 + j;
+            dst[i] = c < Cin ? W[((size_t)tap * Cin + c) * Cout + co] : 0.f;
+        }
+    }
+    if (bwd >= 0) {
+        const int nch = (Cout + 15) >> 4, per_tap = nch * 16 * Cin;
+        float *dst = packs + bwd + (size_t)tap * per_tap;
+        for (int i = threadIdx.x; i < per_tap; i += 256) {
+            const int j = i & 3, ci = (i >> 2) % Cin, rest = (i >> 2) / Cin;
+            const int co = rest * 4 + j;
+            dst[i] = co < Cout ? W[((size_t)(8 - tap) * Cin + ci) * Cout + co] : 0.f;
+        }
+    }
+}
+
+extern "C" int mpnn_pack_weights(const float *params, float *packs, const int *desc, int n_desc, void *stream) {
+    if (n_desc <= 0) return 0;
+    hipLaunchKernelGGL(pack_k, dim3(n_desc, 9), dim3(256), 0, (hipStream_t)stream, params, packs, desc);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// mpnn_bn_bwd_reduce / mpnn_bn_bwd_apply (elementwise forms; the conv
+// epilogues hold the fused forms).  C % 4 == 0 and (C/4) | 256.
+// ---------------------------------------------------------------------------
+struct BnBwdP { const float *dy; const float *s; mpnn_act bn; const double *red; float *dz; double *red_out; long n_pix; };
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_k(const BnBwdP p) {
+    const int C = p.bn.C, Q = C >> 2;             // channel quads
+    const int q = threadIdx.x % Q, lane_pix = threadIdx.x / Q, ppb = 256 / Q;
+    BnC k[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = bn_coef(p.bn, q * 4 + j);
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (long pix = (long)blockIdx.x * ppb + lane_pix; pix < p.n_pix; pix += (long)gridDim.x * ppb) {
+        const size_t idx = (size_t)pix * C + q * 4;
+        const f32x4 dy = *(const f32x4 *)(p.dy + idx), s = *(const f32x4 *)(p.s + idx);
+        f32x4 dz;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = s[j] - k[j].m;
+            const float yv = d * (k[j].gamma * k[j].rstd) + k[j].beta;
+            dz[j] = yv > 0.f ? dy[j] : 0.f;
+            s1[j] += dz[j]; s2[j] += dz[j] * (d * k[j].rstd);
+        }
+        *(f32x4 *)(p.dz + idx) = dz;
+    }
+    __shared__ double sh[256 * 8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[threadIdx.x * 8 + j] = s1[j]; sh[threadIdx.x * 8 + 4 + j] = s2[j]; }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x, cq = c >> 2, cj = c & 3;
+        double a1 = 0, a2 = 0;
+        for (int r = 0; r < ppb; ++r) { a1 += sh[(r * Q + cq) * 8 + cj]; a2 += sh[(r * Q + cq) * 8 + 4 + cj]; }
+        atomicAdd(p.red_out + c, a1);
+        atomicAdd(p.red_out + C + c, a2);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(const BnBwdP p) {
+    const int C = p.bn.C, Q = C >> 2;
+    const long total = p.n_pix * Q;
+    const double inv = 1.0 / (double)p.bn.cnt;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % Q);
+        const size_t idx = (size_t)i * 4;
+        const f32x4 dz = *(const f32x4 *)(p.dz + idx), s = *(const f32x4 *)(p.s + idx);
+        f32x4 g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = q * 4 + j;
+            const BnC k = bn_coef(p.bn, c);
+            const float r0 = p.red ? (float)(p.red[c] * inv) : 0.f, r1 = p.red ? (float)(p.red[C + c] * inv) : 0.f;
+            const float xh = (s[j] - k.m) * k.rstd;
+            g[j] = k.gamma * k.rstd * (dz[j] - r0 - xh * r1);
+        }
+        *(f32x4 *)(p.dz + idx) = g;
+    }
+}
+
+static int bn_shape_ok(int C) { return C > 0 && (C & 3) == 0 && C <= 1024 && (256 % (C >> 2)) == 0; }
+
+extern "C" int mpnn_bn_bwd_reduce(const float *dy, const mpnn_bn_ctx *ctx, float *dz, double *red_out,
+                                  long n_pix, void *stream) {
+    if (!dy || !ctx || !ctx->s || !dz || !red_out) return MPNN_E_ARG;
+    if (!bn_shape_ok(ctx->bn.C)) return MPNN_E_SHAPE;
+    if (n_pix <= 0) return 0;
+    BnBwdP p = {dy, ctx->s, ctx->bn, nullptr, dz, red_out, n_pix};
+    const int ppb = 256 / (ctx->bn.C >> 2);
+    long blocks = (n_pix + (long)ppb * 8 - 1) / ((long)ppb * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(bn_bwd_reduce_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mpnn_bn_bwd_apply(float *dz_inout, const mpnn_bn_ctx *ctx, long n_pix, void *stream) {
+    if (!dz_inout || !ctx || !ctx->s) return MPNN_E_ARG;
+    if (!bn_shape_ok(ctx->bn.C)) return MPNN_E_SHAPE;
+    if (n_pix <= 0) return 0;
+    BnBwdP p = {nullptr, ctx->s, ctx->bn, ctx->red, dz_inout, nullptr, n_pix};
+    long blocks = (n_pix * (ctx->bn.C >> 2) + 1023) / 1024;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(bn_bwd_apply_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// mpnn_bn_finalize: moving averages of every conv BatchNorm in one launch.
+// table: 6 ints per BN: sum_off (doubles), mavg_off, vavg_off, C, pix_per_img, -.
+// ---------------------------------------------------------------------------
+__global__ void bn_finalize_k(const double *__restrict__ sums, float *__restrict__ state,
+                              const int *__restrict__ table, float decay, int n_img) {
+    const int *t = table + blockIdx.x * 6;
+    const int C = t[3];
+    const double inv = 1.0 / ((double)t[4] * (double)n_img);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double mean = sums[t[0] + c] * inv;
+        double var = sums[t[0] + C + c] * inv - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        float *m = state + t[1] + c, *v = state + t[2] + c;
+        *m = decay * *m + (1.f - decay) * (float)mean;
+        *v = decay * *v + (1.f - decay) * (float)var;
+    }
+}
+
+extern "C" int mpnn_bn_finalize(const double *sums, float *state, const int *table, int n_bn, float decay,
+                                int n_img, void *stream) {
+    if (n_bn <= 0) return 0;
+    hipLaunchKernelGGL(bn_finalize_k, dim3(n_bn), dim3(128), 0, (hipStream_t)stream, sums, state, table, decay, n_img);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// mpnn_talr_momentum_step.  seg: 6 ints per work item
+// (offset, count, node, is_router, l2 as float bits, -).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void talr_momentum_k(float *__restrict__ params, float *__restrict__ accum,
+                                                       const float *__restrict__ grads, const int *__restrict__ seg,
+                                                       const float *__restrict__ node_stat,
+                                                       const float *__restrict__ hyp, int talr, float inv_n,
+                                                       float grad_scale) {
+    const int *s = seg + blockIdx.x * 6;
+    const int off = s[0], cnt = s[1], node = s[2], is_router = s[3];
+    const float l2 = __int_as_float(s[4]);
+    const float lr = hyp[MPNN_HYP_LR], mu = hyp[MPNN_HYP_MU];
+    const float pbar = node_stat[node * 2] * inv_n;                   // mean p_tr over the batch
+    float scale = 1.f;
+    if (talr) {
+        scale = 1.f / sqrtf(node_stat[node * 2 + 1] * inv_n);          // 1/sqrt(mean p_tr^2)
+        if (is_router) scale *= hyp[MPNN_HYP_ARTR];
+    }
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const float w = params[off + i];
+        float g = grads[off + i] * grad_scale;
+        if (l2 != 0.f) g += 2.f * l2 * pbar * w;
+        g *= scale;
+        const float a = mu * accum[off + i] + g;
+        accum[off + i] = a;
+        params[off + i] = w - lr * a;
+    }
+}
+
+extern "C" int mpnn_talr_momentum_step(float *params, float *accum, const float *grads, const int *seg, int n_seg,
+                                       const float *node_stat, const float *hyp, int talr, float inv_n,
+                                       float grad_scale, void *stream) {
+    if (n_seg <= 0) return 0;
+    hipLaunchKernelGGL(talr_momentum_k, dim3(n_seg), dim3(256), 0, (hipStream_t)stream, params, accum, grads, seg,
+                       node_stat, hyp, talr, inv_n, grad_scale);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// mpnn_compact_by_branch: ordered indices of samples with p_ev > 0 and their
+// count; wave64 ballot + popcount prefix, wave offsets through LDS.  One
+// workgroup of 1024 threads walks the batch in strides of 1024.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void compact_k(const float *__restrict__ p_ev, int n, int *__restrict__ idx_out,
+                                                  int *__restrict__ count_out) {
+    __shared__ int wave_cnt[16];
+    __shared__ int base_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    for (int start = 0; start < n; start += 1024) {
+        const int i = start + tid;
+        const bool on = i < n && p_ev[i] > 0.f;
+        const unsigned long long mask = __ballot(on);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wid] = __popcll(mask);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wave_cnt[w];
+        const int base = base_sh;
+        if (on) idx_out[base + woff + before] = i;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_cnt[w]; base_sh = base + t; }
+        __syncthreads();
+    }
+    if (tid == 0) *count_out = base_sh;
+}
+
+extern "C" int mpnn_compact_by_branch(const float *p_ev, int n, int *idx_out, int *count_out, void *stream) {
+    if (!p_ev || !idx_out || !count_out) return MPNN_E_ARG;
+    hipLaunchKernelGGL(compact_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, p_ev, n, idx_out, count_out);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" const char *mpnn_version(void) { return "mpnn_hip 0.1 (gfx950)"; }

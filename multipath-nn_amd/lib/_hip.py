@@ -1,0 +1,156 @@
+"""ctypes binding of libmpnn_hip.so (C ABI: include/mpnn_hip.h).
+
+The library is the product: if it is missing or fails to load, importing a
+net's execution engine raises -- there is no CPU or PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libmpnn_hip.so')
+
+ACT_IDENTITY, ACT_BN_BATCH, ACT_BN_MOVING = 0, 1, 2
+NET_SR, NET_ACTOR, NET_CRITIC = 0, 1, 2
+HYP_LR, HYP_MU, HYP_TAU, HYP_EPS, HYP_KCPT, HYP_KDEC, HYP_KCRE, HYP_ARTR, HYP_N = 0, 1, 2, 3, 4, 5, 6, 7, 16
+MAX_NODES, MAX_SINKS = 128, 4
+
+P = C.c_void_p
+
+
+class Act(C.Structure):
+    _fields_ = [('x', P), ('sum', P), ('gamma', P), ('beta', P), ('m_avg', P), ('v_avg', P),
+                ('eps', C.c_float), ('cnt', C.c_int), ('C', C.c_int), ('shift', C.c_int), ('mode', C.c_int)]
+
+
+class ConvFwdArgs(C.Structure):
+    _fields_ = [('a', Act), ('v', P), ('Cv', C.c_int), ('wa_pack', P), ('wv_pack', P), ('bias', P),
+                ('out', P), ('out_sum', P), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int)]
+
+
+class BnCtx(C.Structure):
+    _fields_ = [('s', P), ('bn', Act), ('red', P)]
+
+
+class DgradHorzArgs(C.Structure):
+    _fields_ = [('g', P), ('Cg', C.c_int), ('w_pack', P), ('dy_extra', P), ('prev', C.POINTER(BnCtx)),
+                ('out', P), ('red_out', P), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int)]
+
+
+class DgradVertArgs(C.Structure):
+    _fields_ = [('g', P), ('Cg', C.c_int), ('w_pack', P), ('fine', C.POINTER(BnCtx)), ('fine_has_dz', C.c_int),
+                ('dz_g_fine', P), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [('a', Act), ('v', P), ('Cv', C.c_int), ('g', P), ('dwa', P), ('dwv', P), ('db', P),
+                ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int), ('n_split', C.c_int)]
+
+
+class LinFwdArgs(C.Structure):
+    _fields_ = [('a', Act), ('HW', C.c_int), ('w', P * 2), ('b', P * 2), ('y', P * 2), ('M', C.c_int * 2),
+                ('k_cpt', P), ('alpha_cpt', C.c_float), ('extra_col', C.c_int * 2), ('n', C.c_int)]
+
+
+class LinBwdArgs(C.Structure):
+    _fields_ = [('a', Act), ('HW', C.c_int), ('w', P * 2), ('dy', P * 2), ('M', C.c_int * 2),
+                ('dw', P * 2), ('db', P * 2), ('dx', P), ('k_cpt', P), ('alpha_cpt', C.c_float),
+                ('extra_col', C.c_int * 2), ('n', C.c_int)]
+
+
+class ExitTailArgs(C.Structure):
+    _fields_ = [('z', P), ('y', P), ('n_cls', C.c_int), ('eps_ce', C.c_float), ('c_err', P), ('d_cor', P),
+                ('h1', P), ('R', C.c_int), ('n_sinks', C.c_int),
+                ('g1', P), ('b1', P), ('m1', P), ('v1', P), ('w2', P), ('bias2', P),
+                ('g2', P), ('b2', P), ('m2', P), ('v2', P), ('w3', P), ('bias3', P),
+                ('h2', P), ('r', P), ('r_stride', C.c_int), ('bn_save', P),
+                ('bn_eps', C.c_float), ('bn_decay', C.c_float), ('mode', C.c_int), ('n', C.c_int)]
+
+
+class ExitTailBwdArgs(C.Structure):
+    _fields_ = [('f', ExitTailArgs), ('w_cerr', P), ('dr', P), ('dz', P), ('dh1', P),
+                ('dg1', P), ('db1', P), ('dw2', P), ('dbias2', P), ('dg2', P), ('db2', P),
+                ('dw3', P), ('dbias3', P)]
+
+
+class RouteArgs(C.Structure):
+    _fields_ = [('net_type', C.c_int), ('n_nodes', C.c_int), ('n_leaves', C.c_int), ('n_switches', C.c_int),
+                ('max_sinks', C.c_int), ('optimistic', C.c_int), ('use_cls_err', C.c_int), ('want_grad', C.c_int),
+                ('nodes', P), ('sw_children', P), ('node_ops', P), ('hyp', P), ('k_cpt_vec', P), ('r', P),
+                ('c_err', P), ('d_cor', P), ('p_tr', P), ('p_ev', P), ('w_cerr', P), ('dr', P),
+                ('node_stat', P), ('loss', P), ('n', C.c_int), ('n_total', C.c_int)]
+
+
+_SIGS = {
+    'mpnn_pack_weights': [P, P, P, C.c_int, P],
+    'mpnn_msconv_fwd': [C.POINTER(ConvFwdArgs), P],
+    'mpnn_bn_bwd_reduce': [P, C.POINTER(BnCtx), P, P, C.c_long, P],
+    'mpnn_bn_bwd_apply': [P, C.POINTER(BnCtx), C.c_long, P],
+    'mpnn_msconv_dgrad_horz': [C.POINTER(DgradHorzArgs), P],
+    'mpnn_msconv_dgrad_vert': [C.POINTER(DgradVertArgs), P],
+    'mpnn_msconv_wgrad': [C.POINTER(WgradArgs), P],
+    'mpnn_lin_fwd': [P, C.c_int, C.c_int, P],
+    'mpnn_lin_bwd': [P, C.c_int, C.c_int, C.c_int, P],
+    'mpnn_exit_tail_fwd': [P, C.c_int, P],
+    'mpnn_exit_tail_bwd': [P, C.c_int, P],
+    'mpnn_route': [C.POINTER(RouteArgs), P],
+    'mpnn_compact_by_branch': [P, C.c_int, P, P, P],
+    'mpnn_bn_finalize': [P, P, P, C.c_int, C.c_float, C.c_int, P],
+    'mpnn_talr_momentum_step': [P, P, P, P, C.c_int, P, P, C.c_int, C.c_float, C.c_float, P],
+}
+
+EXPORTS = sorted(_SIGS) + ['mpnn_version']
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmpnn_hip.so or raise: the HIP path is the only path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError('%s not found -- build it with `make -C multipath-nn_amd/csrc` '
+                           '(or __graft_entry__.build()); there is no CPU fallback' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, sig in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = sig
+            fn.restype = C.c_int
+        lib.mpnn_version.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise HipError('%s failed with status %d (%s)' % (
+            what, code, {-1: 'unsupported shape', -2: 'bad argument'}.get(code, 'hipError_t')))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def act(x=None, C_=0, mode=ACT_IDENTITY, shift=0, bn=None, cnt=1):
+    """Build an mpnn_act.  bn = dict(sum=, gamma=, beta=, m_avg=, v_avg=, eps=) of tensors."""
+    a = Act()
+    a.x = ptr(x); a.C = int(C_); a.mode = int(mode); a.shift = int(shift); a.cnt = int(cnt)
+    if bn is not None:
+        a.sum = ptr(bn.get('sum')); a.gamma = ptr(bn['gamma']); a.beta = ptr(bn['beta'])
+        a.m_avg = ptr(bn['m_avg']); a.v_avg = ptr(bn['v_avg']); a.eps = float(bn['eps'])
+    return a
+
+
+def to_device_table(records, device):
+    """Upload an array of ctypes Structures as a device byte tensor."""
+    import torch
+    if not records:
+        return None
+    arr = (type(records[0]) * len(records))(*records)
+    raw = bytes(memoryview(arr))
+    host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    return host.to(device)
