@@ -249,11 +249,14 @@ int mpnn_route(const mpnn_route_args *args, void *stream);
 int mpnn_compact_by_branch(const float *p_ev, int n, int *idx_out, int *count_out,
                            void *stream);
 
-/* ---- BatchNorm moving averages (layer_types.py:233-234) --------------------
- * table: 6 ints per BN: sum_off (doubles), mavg_off, vavg_off (floats in
- * `state`), C, pixels per image, reserved. */
-int mpnn_bn_finalize(const double *sums, float *state, const int *table, int n_bn,
-                     float decay, int n_img, void *stream);
+/* ---- BatchNorm epilogue of a training step ----------------------------------
+ * Moving averages (layer_types.py:233-234) from the forward sums and
+ * dgamma / dbeta from the backward reductions, for every conv BatchNorm in one
+ * launch.  table: 8 ints per BN: sum_off (doubles; same offset in `reds`),
+ * mavg_off, vavg_off (floats in `state`), C, pixels per image, gamma_goff,
+ * beta_goff (floats in `grads`; -1: no gradient), reserved. */
+int mpnn_bn_finalize(const double *sums, const double *reds, float *state, float *grads,
+                     const int *table, int n_bn, float decay, int n_img, void *stream);
 
 /* ---- TALR + L2 + momentum (net_types.py:24-37, tf.train.MomentumOptimizer) --
  * For every trainable element: g = grad + 2*k_l2*pbar_node*(w - 0);

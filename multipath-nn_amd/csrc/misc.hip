@@ -129,12 +129,17 @@ extern "C" int mpnn_bn_bwd_apply(float *dz_inout, const mpnn_bn_ctx *ctx, long n
 }
 
 // ---------------------------------------------------------------------------
-// mpnn_bn_finalize: moving averages of every conv BatchNorm in one launch.
-// table: 6 ints per BN: sum_off (doubles), mavg_off, vavg_off, C, pix_per_img, -.
+// mpnn_bn_finalize: after a training step's backward, for every conv BatchNorm
+// in one launch: moving averages (layer_types.py:233-234) from the forward sums
+// and dgamma / dbeta from the backward reductions.
+// table: 8 ints per BN: sum_off (doubles, also the offset of the backward
+// reductions in `reds`), mavg_off, vavg_off (floats in `state`), C,
+// pixels per image, gamma_goff, beta_goff (floats in `grads`; -1: skip), -.
 // ---------------------------------------------------------------------------
-__global__ void bn_finalize_k(const double *__restrict__ sums, float *__restrict__ state,
+__global__ void bn_finalize_k(const double *__restrict__ sums, const double *__restrict__ reds,
+                              float *__restrict__ state, float *__restrict__ grads,
                               const int *__restrict__ table, float decay, int n_img) {
-    const int *t = table + blockIdx.x * 6;
+    const int *t = table + blockIdx.x * 8;
     const int C = t[3];
     const double inv = 1.0 / ((double)t[4] * (double)n_img);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -144,13 +149,18 @@ __global__ void bn_finalize_k(const double *__restrict__ sums, float *__restrict
         float *m = state + t[1] + c, *v = state + t[2] + c;
         *m = decay * *m + (1.f - decay) * (float)mean;
         *v = decay * *v + (1.f - decay) * (float)var;
+        if (reds && grads && t[5] >= 0) {
+            grads[t[6] + c] = (float)reds[t[0] + c];          // dbeta  = sum dz
+            grads[t[5] + c] = (float)reds[t[0] + C + c];      // dgamma = sum dz * xhat
+        }
     }
 }
 
-extern "C" int mpnn_bn_finalize(const double *sums, float *state, const int *table, int n_bn, float decay,
-                                int n_img, void *stream) {
+extern "C" int mpnn_bn_finalize(const double *sums, const double *reds, float *state, float *grads,
+                                const int *table, int n_bn, float decay, int n_img, void *stream) {
     if (n_bn <= 0) return 0;
-    hipLaunchKernelGGL(bn_finalize_k, dim3(n_bn), dim3(128), 0, (hipStream_t)stream, sums, state, table, decay, n_img);
+    hipLaunchKernelGGL(bn_finalize_k, dim3(n_bn), dim3(128), 0, (hipStream_t)stream, sums, reds, state, grads, table,
+                       decay, n_img);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

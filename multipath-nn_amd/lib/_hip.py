@@ -94,7 +94,7 @@ _SIGS = {
     'mpnn_exit_tail_bwd': [P, C.c_int, P],
     'mpnn_route': [C.POINTER(RouteArgs), P],
     'mpnn_compact_by_branch': [P, C.c_int, P, P, P],
-    'mpnn_bn_finalize': [P, P, P, C.c_int, C.c_float, C.c_int, P],
+    'mpnn_bn_finalize': [P, P, P, P, P, C.c_int, C.c_float, C.c_int, P],
     'mpnn_talr_momentum_step': [P, P, P, P, C.c_int, P, P, C.c_int, C.c_float, C.c_float, P],
 }
 

@@ -1,0 +1,700 @@
+"""Static execution plan of a net over pre-allocated HBM buffers.
+
+``Engine`` turns a linked ``Net`` (lib/net_types.py) into lists of launches of
+the HIP kernels behind the C ABI (include/mpnn_hip.h).  Everything a training
+step needs lives in a handful of flat device buffers:
+
+* ``P`` / ``A`` / ``G``: parameters, momentum accumulators, gradients (fp32, one
+  flat buffer each, same layout; ``G`` carries the per-node TALR statistics at
+  its tail so ONE all-reduce serves data-parallel training);
+* ``S``: BatchNorm moving averages (non-trainable state);
+* per block and scale: the pre-BatchNorm conv sums ``s`` (the only activation
+  that is materialised -- BatchNorm+ReLU are applied by consumers on load) and
+  one gradient buffer that holds dz, then g, in place;
+* fp64 arenas for BatchNorm statistics (forward sums, backward reductions).
+
+There is no CPU fallback: constructing an Engine loads libmpnn_hip.so and needs
+a GPU.  PyTorch provides device memory, streams and (optionally) graph capture.
+
+Reference semantics restated here (graph structure only; arithmetic is in the
+kernels): tree walk of Net.link (net_types.py:56-63), MultiscaleConvMax's
+negative indexing of the input pyramid (layer_types.py:163,181-185), the
+parameter -> tree-node map of minimize_expectation (net_types.py:28-34).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from lib import _hip
+from lib.layer_types import Chain
+from lib.net_types import n_leaves, params_list_rec
+
+ROUTER_COMPS = ['Select', 'LinTrans', 'BatchNorm', 'Rect', 'LinTrans', 'BatchNorm', 'Rect', 'LinTrans']
+BLOCK_COMPS = ['MultiscaleConvMax', 'MultiscaleBatchNorm', 'MultiscaleRect']
+HEAD_COMPS = ['Select', 'LinTrans', 'Softmax', 'CrossEntropyError']
+OPT_CHUNK = 2048
+
+
+def _kind(ℓ):
+    if isinstance(ℓ, Chain):
+        t = [type(c).__name__ for c in ℓ.comps]
+        if t == ['ToPyramid']:
+            return 'pyramid'
+        if t == BLOCK_COMPS:
+            return 'block'
+        if t == HEAD_COMPS:
+            return 'head'
+    raise NotImplementedError(
+        'layer %r (%s) is outside the MI355X hot path: supported tree nodes are the '
+        'ToPyramid, ReConvMax and LogReg chains of arch_and_hypers.py' % (ℓ.name, type(ℓ).__name__))
+
+
+class _Node:
+    pass
+
+
+class _Block:
+    pass
+
+
+class Engine:
+    def __init__(self, net, device=None, n_max=128):
+        self.net = net
+        self.lib = _hip.load()
+        if not torch.cuda.is_available():
+            raise _hip.HipError('no GPU visible: the multipath-nn hot path runs on MI355X only')
+        if device is None:
+            device = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', '0'))
+        self.dev = torch.device(device)
+        torch.cuda.set_device(self.dev)
+        self.n_max = 0
+        self.use_graph = bool(int(os.environ.get('MPNN_GRAPH', '0')))
+        self.world = 1
+        self.allreduce = None            # callable(G) installed by lib/_dp.py
+        self._keep = []
+        self._progs = {}
+        self._graphs = {}
+        self._classify()
+        self._alloc_params()
+        self.init_params(net.hypers.__dict__.get('seed'))
+        self._ensure_capacity(n_max)
+        self.last_n = 0
+        self.last_mode = 'ev'
+
+    # ------------------------------------------------------------------ structure
+    def _classify(self):
+        net = self.net
+        self.nodes = []
+        index = {}
+        for ℓ in net.layers:
+            nd = _Node()
+            nd.idx, nd.layer, nd.kind = len(self.nodes), ℓ, _kind(ℓ)
+            nd.parent, nd.sink_index = -1, 0
+            index[id(ℓ)] = nd
+            self.nodes.append(nd)
+        for nd in self.nodes:
+            for i, s in enumerate(nd.layer.sinks):
+                index[id(s)].parent, index[id(s)].sink_index = nd.idx, i
+        self.leaves = [nd for nd in self.nodes if len(nd.layer.sinks) == 0]
+        self.switches = [nd for nd in self.nodes if len(nd.layer.sinks) > 1]
+        for i, nd in enumerate(self.leaves):
+            nd.leaf_id = i
+        for i, nd in enumerate(self.switches):
+            nd.switch_id = i
+        self.max_sinks = max([len(nd.layer.sinks) for nd in self.switches] + [2])
+        if len(self.nodes) > _hip.MAX_NODES or self.max_sinks > _hip.MAX_SINKS:
+            raise NotImplementedError('routing tree too large for mpnn_route')
+        kind = self.net._net_kind
+        for nd in self.nodes:
+            r = nd.layer.router
+            if r is not None:
+                if kind == 'sr' or len(nd.layer.sinks) < 2:
+                    raise NotImplementedError('router on a node with < 2 sinks / in an SRNet')
+                if not isinstance(r, Chain) or [type(c).__name__ for c in r.comps] != ROUTER_COMPS:
+                    raise NotImplementedError('router chain outside the MI355X hot path')
+                if nd.kind != 'block':
+                    raise NotImplementedError('router on a %s node' % nd.kind)
+            elif len(nd.layer.sinks) > 1 and kind != 'sr':
+                raise NotImplementedError('switch without router')
+            if nd.kind == 'head' and nd.layer.sinks:
+                raise NotImplementedError('LogReg with sinks')
+        root = self.nodes[0]
+        if root.kind != 'pyramid':
+            raise NotImplementedError('root must be the ToPyramid chain')
+        self.x0_shape = tuple(self.net.hypers.x0_shape)
+        self.n_cls = int(self.net.hypers.y_shape[0])
+        # blocks
+        self.blocks = []
+        for nd in self.nodes:
+            if nd.kind != 'block':
+                continue
+            b = _Block()
+            b.node = nd
+            conv, mbn, _ = nd.layer.comps
+            b.conv, b.bns = conv, mbn.comps
+            b.L = len(conv.hypers.n_chan)
+            b.H = [s.shape[0] for s in conv.x]
+            b.W = [s.shape[1] for s in conv.x]
+            b.C = [s.shape[2] for s in conv.x]
+            for h, w in zip(b.H, b.W):
+                if h != w:
+                    raise NotImplementedError('non-square feature maps')
+            for i in range(b.L):
+                if tuple(getattr(conv.params, 'w_horz_%i' % i).shape[:2]) != (3, 3):
+                    raise NotImplementedError('only 3x3 filters are on the hot path')
+            par = self.nodes[nd.parent]
+            b.parent = getattr(par, 'block', None)
+            if par.kind == 'pyramid':
+                n_pyr = par.layer.comps[0].hypers.n_scales
+                b.in_shift = [n_pyr - b.L + i for i in range(b.L)]
+                b.in_map = None
+                b.Cin = [self.x0_shape[2]] * b.L
+            elif par.kind == 'block':
+                b.in_map = [b.parent.L - b.L + i for i in range(b.L)]
+                b.in_shift = [0] * b.L
+                b.Cin = [b.parent.C[j] for j in b.in_map]
+            else:
+                raise NotImplementedError('block below a %s node' % par.kind)
+            b.child = None
+            b.heads = [self.nodes[nd.idx].layer]  # placeholder, replaced below
+            nd.block = b
+            self.blocks.append(b)
+        for b in self.blocks:
+            kids = [self.nodes_by_layer(s) for s in b.node.layer.sinks]
+            cb = [k.block for k in kids if k.kind == 'block']
+            if len(cb) > 1:
+                raise NotImplementedError('tree-structured nets (more than one child block) are a later row')
+            b.child = cb[0] if cb else None
+            hs = [k for k in kids if k.kind == 'head']
+            if len(hs) > 1:
+                raise NotImplementedError('more than one LogReg under a block')
+            b.head = hs[0] if hs else None
+            b.router = b.node.layer.router
+            b.has_exit = b.head is not None or b.router is not None
+            # which scales' BN outputs are consumed (by the child block or the exit)
+            b.has_dz = [False] * b.L
+            if b.child is not None:
+                for j in b.child.in_map:
+                    b.has_dz[j] = True
+            if b.has_exit:
+                b.has_dz[b.L - 1] = True
+        for nd in self.nodes:
+            if nd.kind == 'head' and self.nodes[nd.parent].kind != 'block':
+                raise NotImplementedError('LogReg must hang off a ReConvMax block')
+
+    def nodes_by_layer(self, ℓ):
+        for nd in self.nodes:
+            if nd.layer is ℓ:
+                return nd
+        raise KeyError(ℓ)
+
+    # ------------------------------------------------------------------ parameters
+    def _alloc_params(self):
+        owner = {}
+        for nd in self.nodes:
+            for p in params_list_rec(nd.layer):
+                owner[id(p)] = (nd.idx, 0)
+            for p in params_list_rec(nd.layer.router):
+                owner[id(p)] = (nd.idx, 1)
+        self.trainable = [p for p in self.net._all_params if p.trainable]
+        self.state_params = [p for p in self.net._all_params if not p.trainable]
+        off = 0
+        for p in self.trainable:
+            p.offset, p.node, p.is_router = off, *owner[id(p)]
+            off += p.size
+        self.n_params = off
+        soff = 0
+        for p in self.state_params:
+            p.offset = soff
+            soff += p.size
+        n_stat = 2 * len(self.nodes)
+        dev = self.dev
+        self.P = torch.zeros(off, device=dev)
+        self.A = torch.zeros(off, device=dev)
+        self.G = torch.zeros(off + n_stat, device=dev)
+        self.S = torch.zeros(max(soff, 1), device=dev)
+        self.node_stat = self.G[off:]
+        for p in self.trainable:
+            p.data = self.P[p.offset:p.offset + p.size]
+            p.grad = self.G[p.offset:p.offset + p.size]
+            p.accum = self.A[p.offset:p.offset + p.size]
+        for p in self.state_params:
+            p.data = self.S[p.offset:p.offset + p.size]
+        # optimizer work items
+        seg = []
+        for p in self.trainable:
+            l2 = np.float32(p.l2).view(np.int32)
+            for s in range(0, p.size, OPT_CHUNK):
+                seg += [p.offset + s, min(OPT_CHUNK, p.size - s), p.node, p.is_router, int(l2), 0]
+            if p.l2 and p.eq is not None:
+                raise NotImplementedError('residual (w_eq) L2 terms are outside the hot path')
+        self.n_seg = len(seg) // 6
+        self.seg = torch.tensor(seg, dtype=torch.int32, device=dev)
+        # weight packs
+        desc, poff = [], 0
+        for b in self.blocks:
+            b.pack = {}
+            for i in range(b.L):
+                names = ['w_horz_%i' % i] + (['w_vert_%i' % (i - 1)] if i > 0 else [])
+                for name in names:
+                    p = getattr(b.conv.params, name)
+                    ci, co = p.shape[2], p.shape[3]
+                    fs = 9 * ((ci + 15) // 16) * 16 * co
+                    bs = 9 * ((co + 15) // 16) * 16 * ci if ci % 16 == 0 else 0
+                    desc += [p.offset, poff, poff + fs if bs else -1, ci, co, 0]
+                    b.pack[name] = (poff, poff + fs if bs else None)
+                    poff += fs + bs
+        self.n_pack = len(desc) // 6
+        self.packs = torch.zeros(max(poff, 1), device=dev)
+        self.pack_desc = torch.tensor(desc, dtype=torch.int32, device=dev)
+        # fp64 BatchNorm arenas + finalize table
+        doff, tab = 0, []
+        for b in self.blocks:
+            b.sum_off = []
+            for i in range(b.L):
+                bn = b.bns[i].params
+                b.sum_off.append(doff)
+                tab += [doff, bn.m_avg.offset, bn.v_avg.offset, b.C[i], b.H[i] * b.W[i],
+                        bn.γ.offset if b.has_dz[i] else -1, bn.β.offset, 0]
+                doff += 2 * b.C[i]
+        self.dsum = torch.zeros(max(doff, 1), dtype=torch.float64, device=dev)
+        self.dred = torch.zeros(max(doff, 1), dtype=torch.float64, device=dev)
+        self.n_bn = len(tab) // 8
+        self.bn_table = torch.tensor(tab, dtype=torch.int32, device=dev)
+        self.bn_decay = float(self.blocks[0].bns[0].hypers.d) if self.blocks else 0.9
+        # routing tables
+        nodes, ops = [], []
+        for nd in self.nodes:
+            ℓ = nd.layer
+            nodes += [nd.parent, nd.sink_index, len(ℓ.sinks), getattr(nd, 'switch_id', -1),
+                      getattr(nd, 'leaf_id', -1), n_leaves(ℓ), 0, 0]
+            ops.append(float(ℓ.n_ops + (ℓ.router.n_ops if ℓ.router is not None else 0)))
+        kids = []
+        for nd in self.switches:
+            row = [self.nodes_by_layer(s).idx for s in nd.layer.sinks]
+            kids += row + [0] * (self.max_sinks - len(row))
+        self.node_tab = torch.tensor(nodes, dtype=torch.int32, device=dev)
+        self.kid_tab = torch.tensor(kids if kids else [0], dtype=torch.int32, device=dev)
+        self.node_ops = torch.tensor(ops, dtype=torch.float32, device=dev)
+        self.node_ops_host = ops
+        self.hyp = torch.zeros(_hip.HYP_N, device=dev)
+        self.hyp_host = torch.zeros(_hip.HYP_N).pin_memory()
+        self.loss = torch.zeros(4, dtype=torch.float64, device=dev)
+
+    def init_params(self, seed=None):
+        """Draw every parameter from the reference's initialisation law
+        (layer_types.py:48-50, 64-71, 156-173, 227-230)."""
+        rng = np.random.default_rng(seed)
+        P = np.zeros(self.n_params, np.float32)
+        S = np.zeros(self.S.numel(), np.float32)
+        for p in self.net._all_params:
+            kind, scale = p.init
+            if kind == 'normal':
+                v = (scale * rng.standard_normal(p.size)).astype(np.float32)
+                if p.eq is not None:
+                    v = v + p.eq.reshape(-1)
+            elif kind == 'ones':
+                v = np.ones(p.size, np.float32)
+            else:
+                v = np.zeros(p.size, np.float32)
+            (P if p.trainable else S)[p.offset:p.offset + p.size] = v
+        self.P.copy_(torch.from_numpy(P))
+        self.S.copy_(torch.from_numpy(S))
+        self.A.zero_()
+
+    # ------------------------------------------------------------------ buffers
+    def _ensure_capacity(self, n):
+        if n <= self.n_max:
+            return
+        self.n_max = n
+        self._progs.clear()
+        self._graphs.clear()
+        dev = self.dev
+        z = lambda *shape: torch.zeros(shape, device=dev)
+        h, w, c0 = self.x0_shape
+        self.x0 = z(n, h, w, c0)
+        self.y = z(n, self.n_cls)
+        self.k_cpt = z(n)
+        for b in self.blocks:
+            b.s = [z(n, b.H[i], b.W[i], b.C[i]) for i in range(b.L)]
+            b.dzg = [z(n, b.H[i], b.W[i], b.C[i]) for i in range(b.L)]
+            if b.has_exit:
+                K = b.H[-1] * b.W[-1] * b.C[-1]
+                b.dx = z(n, K)
+                b.z = z(n, self.n_cls) if b.head is not None else None
+                b.dzh = z(n, self.n_cls) if b.head is not None else None
+                if b.router is not None:
+                    R = b.router.comps[1].hypers.n_chan
+                    b.R = R
+                    b.h1, b.h2, b.dh1 = z(n, R), z(n, R), z(n, R)
+                    b.bn_save = z(4 * R)
+        nn, nl, ns = len(self.nodes), len(self.leaves), max(len(self.switches), 1)
+        self.p_tr, self.p_ev = z(nn * n), z(nn * n)
+        self.c_err, self.d_cor, self.w_cerr = z(nl * n), z(nl * n), z(nl * n)
+        self.r, self.dr = z(ns * n * self.max_sinks), z(ns * n * self.max_sinks)
+
+    # ------------------------------------------------------------------ programs
+    def _bn(self, b, i, with_sum=True):
+        bn = b.bns[i].params
+        return dict(sum=self.dsum[b.sum_off[i]:] if with_sum else None, gamma=bn.γ.data, beta=bn.β.data,
+                    m_avg=bn.m_avg.data, v_avg=bn.v_avg.data, eps=float(b.bns[i].hypers.ϵ))
+
+    def _act_of_input(self, b, i, n, mode):
+        """mpnn_act of the block's input at scale i."""
+        if b.in_map is None:
+            return _hip.act(self.x0, self.x0_shape[2], _hip.ACT_IDENTITY, b.in_shift[i])
+        pb, j = b.parent, b.in_map[i]
+        return _hip.act(pb.s[j], pb.C[j], mode, 0, self._bn(pb, j), n * pb.H[j] * pb.W[j])
+
+    def _bn_ctx(self, b, i, n, with_red=True):
+        ctx = _hip.BnCtx()
+        ctx.s = b.s[i].data_ptr()
+        ctx.bn = _hip.act(None, b.C[i], _hip.ACT_BN_BATCH, 0, self._bn(b, i), n * b.H[i] * b.W[i])
+        ctx.red = self.dred[b.sum_off[i]:].data_ptr() if with_red else None
+        self._keep.append(ctx)
+        return ctx
+
+    def _wsplit(self, b, i, n):
+        """Workgroups the pixel range of a wgrad launch is divided over."""
+        H = b.H[i]
+        tiles = n * (H // 16) * (H // 4) if H >= 16 else (n if H == 8 else (n + 3) // 4)
+        nch = (b.Cin[i] + 15) // 16 + ((b.C[i - 1] + 15) // 16 if i > 0 else 0)
+        groups = max(1, b.C[i] // 64) if b.C[i] % 64 == 0 else (b.C[i] // 32 if b.C[i] % 32 == 0 else b.C[i] // 16)
+        want = max(1, 512 // (nch * groups))
+        return max(1, min(tiles, want))
+
+    def program(self, mode, n):
+        key = (mode, n)
+        if key in self._progs:
+            return self._progs[key]
+        self._ensure_capacity(n)
+        lib, keep = self.lib, self._keep
+        act_mode = _hip.ACT_BN_BATCH if mode == 'tr' else _hip.ACT_BN_MOVING
+        net, kind = self.net, self.net._net_kind
+        ϕ = net.hypers
+        fwd, bwd = [], []
+
+        def call(fn, what, *args):
+            def launch(st):
+                _hip.check(fn(*args, st), what)
+            return launch
+
+        # ---- forward convs ----
+        for b in self.blocks:
+            cp = b.conv.params
+            for i in range(b.L):
+                a = _hip.ConvFwdArgs()
+                a.a = self._act_of_input(b, i, n, act_mode)
+                if i > 0:
+                    a.v, a.Cv = b.s[i - 1].data_ptr(), b.C[i - 1]
+                    a.wv_pack = self.packs[b.pack['w_vert_%i' % (i - 1)][0]:].data_ptr()
+                a.wa_pack = self.packs[b.pack['w_horz_%i' % i][0]:].data_ptr()
+                a.bias = getattr(cp, 'b_%i' % i).data.data_ptr()
+                a.out = b.s[i].data_ptr()
+                a.out_sum = self.dsum[b.sum_off[i]:].data_ptr() if mode == 'tr' else None
+                a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
+                keep.append(a)
+                fwd.append(call(lib.mpnn_msconv_fwd, 'msconv_fwd', C.byref(a)))
+
+        # ---- exits ----
+        dyn = bool(getattr(ϕ, 'dyn_k_cpt', False))
+        lin_f, lin_b, tail_f, tail_b = [], [], [], []
+        MS = self.max_sinks
+        kmax = 0
+        for b in self.blocks:
+            if not b.has_exit:
+                continue
+            L1 = b.L - 1
+            K = b.H[L1] * b.W[L1] * b.C[L1]
+            kmax = max(kmax, K)
+            lf, lb = _hip.LinFwdArgs(), _hip.LinBwdArgs()
+            tf, tb = _hip.ExitTailArgs(), _hip.ExitTailBwdArgs()
+            a_in = _hip.act(b.s[L1], b.C[L1], act_mode, 0, self._bn(b, L1), n * b.H[L1] * b.W[L1])
+            lf.a, lb.a = a_in, a_in
+            lf.HW = lb.HW = b.H[L1] * b.W[L1]
+            lf.n = lb.n = tf.n = n
+            lf.k_cpt = lb.k_cpt = self.k_cpt.data_ptr()
+            lf.alpha_cpt = lb.alpha_cpt = float(getattr(ϕ, 'α_cpt', 0.0))
+            lb.dx = b.dx.data_ptr()
+            tf.mode = act_mode
+            if b.head is not None:
+                lt, ce = b.head.layer.comps[1], b.head.layer.comps[3]
+                lf.w[0], lf.b[0], lf.y[0], lf.M[0] = lt.params.w.data.data_ptr(), lt.params.b.data.data_ptr(), b.z.data_ptr(), self.n_cls
+                lb.w[0], lb.dy[0], lb.M[0] = lf.w[0], b.dzh.data_ptr(), self.n_cls
+                lb.dw[0], lb.db[0] = lt.params.w.grad.data_ptr(), lt.params.b.grad.data_ptr()
+                leaf = b.head.leaf_id
+                tf.z, tf.y, tf.n_cls, tf.eps_ce = b.z.data_ptr(), self.y.data_ptr(), self.n_cls, float(ce.hypers.ϵ)
+                tf.c_err = self.c_err[leaf * n:].data_ptr()
+                tf.d_cor = self.d_cor[leaf * n:].data_ptr()
+                tb.w_cerr = self.w_cerr[leaf * n:].data_ptr()
+                tb.dz = b.dzh.data_ptr()
+            if b.router is not None:
+                rc = b.router.comps
+                l1, bn1, l2, bn2, l3 = rc[1], rc[2], rc[4], rc[5], rc[7]
+                R, S = b.R, len(b.node.layer.sinks)
+                sw = b.node.switch_id
+                lf.w[1], lf.b[1], lf.y[1], lf.M[1] = l1.params.w.data.data_ptr(), l1.params.b.data.data_ptr(), b.h1.data_ptr(), R
+                lb.w[1], lb.dy[1], lb.M[1] = lf.w[1], b.dh1.data_ptr(), R
+                lb.dw[1], lb.db[1] = l1.params.w.grad.data_ptr(), l1.params.b.grad.data_ptr()
+                lf.extra_col[1] = lb.extra_col[1] = 1 if dyn else 0
+                tf.h1, tf.R, tf.n_sinks = b.h1.data_ptr(), R, S
+                tf.g1, tf.b1 = bn1.params.γ.data.data_ptr(), bn1.params.β.data.data_ptr()
+                tf.m1, tf.v1 = bn1.params.m_avg.data.data_ptr(), bn1.params.v_avg.data.data_ptr()
+                tf.w2, tf.bias2 = l2.params.w.data.data_ptr(), l2.params.b.data.data_ptr()
+                tf.g2, tf.b2 = bn2.params.γ.data.data_ptr(), bn2.params.β.data.data_ptr()
+                tf.m2, tf.v2 = bn2.params.m_avg.data.data_ptr(), bn2.params.v_avg.data.data_ptr()
+                tf.w3, tf.bias3 = l3.params.w.data.data_ptr(), l3.params.b.data.data_ptr()
+                tf.h2 = b.h2.data_ptr()
+                tf.r, tf.r_stride = self.r[sw * n * MS:].data_ptr(), MS
+                tf.bn_save = b.bn_save.data_ptr()
+                tf.bn_eps, tf.bn_decay = float(bn1.hypers.ϵ), float(bn1.hypers.d)
+                tb.dr = self.dr[sw * n * MS:].data_ptr()
+                tb.dh1 = b.dh1.data_ptr()
+                tb.dg1, tb.db1 = bn1.params.γ.grad.data_ptr(), bn1.params.β.grad.data_ptr()
+                tb.dw2, tb.dbias2 = l2.params.w.grad.data_ptr(), l2.params.b.grad.data_ptr()
+                tb.dg2, tb.db2 = bn2.params.γ.grad.data_ptr(), bn2.params.β.grad.data_ptr()
+                tb.dw3, tb.dbias3 = l3.params.w.grad.data_ptr(), l3.params.b.grad.data_ptr()
+            tb.f = tf
+            lin_f.append(lf); lin_b.append(lb); tail_f.append(tf); tail_b.append(tb)
+        n_exit = len(lin_f)
+        t_lf, t_lb = _hip.to_device_table(lin_f, self.dev), _hip.to_device_table(lin_b, self.dev)
+        t_tf, t_tb = _hip.to_device_table(tail_f, self.dev), _hip.to_device_table(tail_b, self.dev)
+        keep += [t_lf, t_lb, t_tf, t_tb]
+        if n_exit:
+            fwd.append(call(lib.mpnn_lin_fwd, 'lin_fwd', t_lf.data_ptr(), n_exit, n))
+            fwd.append(call(lib.mpnn_exit_tail_fwd, 'exit_tail_fwd', t_tf.data_ptr(), n_exit))
+
+        # ---- route ----
+        ra = _hip.RouteArgs()
+        ra.net_type = {'sr': _hip.NET_SR, 'actor': _hip.NET_ACTOR, 'critic': _hip.NET_CRITIC}[kind]
+        ra.n_nodes, ra.n_leaves, ra.n_switches, ra.max_sinks = len(self.nodes), len(self.leaves), len(self.switches), MS
+        ra.optimistic = int(bool(getattr(ϕ, 'optimistic', False)))
+        ra.use_cls_err = int(bool(getattr(ϕ, 'use_cls_err', False)))
+        ra.want_grad = 1 if mode == 'tr' else 0
+        ra.nodes, ra.sw_children, ra.node_ops = self.node_tab.data_ptr(), self.kid_tab.data_ptr(), self.node_ops.data_ptr()
+        ra.hyp = self.hyp.data_ptr()
+        ra.k_cpt_vec = self.k_cpt.data_ptr() if dyn else None
+        ra.r, ra.c_err, ra.d_cor = self.r.data_ptr(), self.c_err.data_ptr(), self.d_cor.data_ptr()
+        ra.p_tr, ra.p_ev, ra.w_cerr, ra.dr = self.p_tr.data_ptr(), self.p_ev.data_ptr(), self.w_cerr.data_ptr(), self.dr.data_ptr()
+        ra.node_stat = self.node_stat.data_ptr() if mode == 'tr' else None
+        ra.loss = self.loss.data_ptr()
+        ra.n, ra.n_total = n, n
+        keep.append(ra)
+        fwd.append(call(lib.mpnn_route, 'route', C.byref(ra)))
+
+        prog = dict(fwd=fwd, bwd=bwd, n=n, mode=mode)
+        self._progs[key] = prog
+        if mode != 'tr':
+            return prog
+
+        # ---- backward ----
+        if n_exit:
+            bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit))
+            bwd.append(call(lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
+        for b in reversed(self.blocks):
+            cp = b.conv.params
+            L1 = b.L - 1
+            # coarsest scale without a child block: its dy is the exit's dX alone
+            if b.child is None:
+                ctx = self._bn_ctx(b, L1, n, with_red=False)
+                bwd.append(call(lib.mpnn_bn_bwd_reduce, 'bn_bwd_reduce', b.dx.data_ptr(), C.byref(ctx),
+                                b.dzg[L1].data_ptr(), self.dred[b.sum_off[L1]:].data_ptr(),
+                                n * b.H[L1] * b.W[L1]))
+            ctx = self._bn_ctx(b, L1, n)
+            bwd.append(call(lib.mpnn_bn_bwd_apply, 'bn_bwd_apply', b.dzg[L1].data_ptr(), C.byref(ctx),
+                            n * b.H[L1] * b.W[L1]))
+            for i in range(L1, 0, -1):
+                a = _hip.DgradVertArgs()
+                fine = self._bn_ctx(b, i - 1, n)
+                a.g, a.Cg = b.dzg[i].data_ptr(), b.C[i]
+                a.w_pack = self.packs[b.pack['w_vert_%i' % (i - 1)][1]:].data_ptr()
+                a.fine = C.pointer(fine)
+                a.fine_has_dz = 1 if b.has_dz[i - 1] else 0
+                a.dz_g_fine = b.dzg[i - 1].data_ptr()
+                a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i - 1]
+                keep.append(a)
+                bwd.append(call(lib.mpnn_msconv_dgrad_vert, 'dgrad_vert', C.byref(a)))
+            for i in range(b.L):
+                a = _hip.WgradArgs()
+                a.a = self._act_of_input(b, i, n, act_mode)
+                if i > 0:
+                    a.v, a.Cv = b.s[i - 1].data_ptr(), b.C[i - 1]
+                    a.dwv = getattr(cp, 'w_vert_%i' % (i - 1)).grad.data_ptr()
+                a.g = b.dzg[i].data_ptr()
+                a.dwa = getattr(cp, 'w_horz_%i' % i).grad.data_ptr()
+                a.db = getattr(cp, 'b_%i' % i).grad.data_ptr()
+                a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
+                a.n_split = self._wsplit(b, i, n)
+                keep.append(a)
+                bwd.append(call(lib.mpnn_msconv_wgrad, 'wgrad', C.byref(a)))
+            if b.parent is not None:
+                pb = b.parent
+                for i in range(b.L):
+                    j = b.in_map[i]
+                    a = _hip.DgradHorzArgs()
+                    a.g, a.Cg = b.dzg[i].data_ptr(), b.C[i]
+                    a.w_pack = self.packs[b.pack['w_horz_%i' % i][1]:].data_ptr()
+                    a.dy_extra = pb.dx.data_ptr() if (pb.has_exit and j == pb.L - 1) else None
+                    prev = self._bn_ctx(pb, j, n, with_red=False)
+                    a.prev = C.pointer(prev)
+                    a.out = pb.dzg[j].data_ptr()
+                    a.red_out = self.dred[pb.sum_off[j]:].data_ptr()
+                    a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], pb.C[j]
+                    keep.append(a)
+                    bwd.append(call(lib.mpnn_msconv_dgrad_horz, 'dgrad_horz', C.byref(a)))
+        bwd.append(call(lib.mpnn_bn_finalize, 'bn_finalize', self.dsum.data_ptr(), self.dred.data_ptr(),
+                        self.S.data_ptr(), self.G.data_ptr(), self.bn_table.data_ptr(), self.n_bn,
+                        self.bn_decay, n))
+        return prog
+
+    # ------------------------------------------------------------------ running
+    def _stage(self, feed):
+        net = self.net
+        x0 = feed[net.x0]
+        n = int(x0.shape[0])
+        self._ensure_capacity(n)
+
+        def put(dst, src):
+            if isinstance(src, torch.Tensor):
+                if src.data_ptr() == dst.data_ptr():
+                    return
+                dst.copy_(src.reshape(dst.shape), non_blocking=True)
+            else:
+                dst.copy_(torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)).reshape(dst.shape),
+                          non_blocking=True)
+        put(self.x0[:n], x0)
+        put(self.y[:n], feed[net.y])
+        ϕ = net.hypers
+        get = lambda name, default: feed.get(getattr(net, name, None), getattr(ϕ, name, default))
+        h = self.hyp_host
+        h[_hip.HYP_LR] = float(get('λ_lrn', 0.0))
+        h[_hip.HYP_MU] = float(get('μ_lrn', 0.0))
+        h[_hip.HYP_TAU] = float(get('τ', 1.0))
+        h[_hip.HYP_EPS] = float(get('ϵ', 0.0))
+        h[_hip.HYP_KDEC] = float(getattr(ϕ, 'k_dec', 0.0))
+        h[_hip.HYP_KCRE] = float(getattr(ϕ, 'k_cre', 0.0))
+        h[_hip.HYP_ARTR] = float(getattr(ϕ, 'α_rtr', 1.0))
+        if getattr(ϕ, 'dyn_k_cpt', False):
+            k = feed[net.k_cpt]
+            k = np.broadcast_to(np.asarray(k, np.float32).reshape(-1), (n,)) if not isinstance(k, torch.Tensor) else k.expand(n)
+            put(self.k_cpt[:n], k)
+            h[_hip.HYP_KCPT] = 0.0
+        else:
+            h[_hip.HYP_KCPT] = float(getattr(ϕ, 'k_cpt', 0.0))
+        self.hyp.copy_(h, non_blocking=True)
+        return n, feed.get(net.mode, net.mode.default)
+
+    def _launch(self, ops):
+        st = torch.cuda.current_stream().cuda_stream
+        for op in ops:
+            op(st)
+
+    def _zero(self, train):
+        self.loss.zero_()
+        if train:
+            self.dsum.zero_()
+            self.dred.zero_()
+            self.G.zero_()
+
+    def _pack(self):
+        _hip.check(self.lib.mpnn_pack_weights(self.P.data_ptr(), self.packs.data_ptr(), self.pack_desc.data_ptr(),
+                                              self.n_pack, torch.cuda.current_stream().cuda_stream), 'pack_weights')
+
+    def _opt(self, n):
+        talr = 1 if (self.net._net_kind != 'sr' and getattr(self.net.hypers, 'talr', False)) else 0
+        _hip.check(self.lib.mpnn_talr_momentum_step(
+            self.P.data_ptr(), self.A.data_ptr(), self.G.data_ptr(), self.seg.data_ptr(), self.n_seg,
+            self.node_stat.data_ptr(), self.hyp.data_ptr(), talr, 1.0 / (n * self.world), 1.0 / self.world,
+            torch.cuda.current_stream().cuda_stream), 'talr_momentum_step')
+
+    def _phase_a(self, prog, train):
+        self._zero(train)
+        self._pack()
+        self._launch(prog['fwd'])
+        if train:
+            self._launch(prog['bwd'])
+
+    def run(self, feed, train):
+        n, mode = self._stage(feed)
+        if train and mode != 'tr':
+            raise ValueError("net.train.run needs net.mode: 'tr' in the feed")
+        prog = self.program(mode, n)
+        do_bwd = train
+        if not self.use_graph:
+            self._phase_a(prog, do_bwd)
+            if do_bwd:
+                if self.allreduce is not None:
+                    self.allreduce(self.G)
+                self._opt(n)
+        else:
+            self._run_graphed(prog, do_bwd, n)
+        self.last_n, self.last_mode = n, mode
+        self._bind_views(n)
+
+    def _run_graphed(self, prog, train, n):
+        """First call runs eagerly (loads code objects); the second captures
+        hipGraphs (phase A = forward+backward, phase B = optimizer, split so a
+        data-parallel all-reduce can sit between them); later calls replay."""
+        key = (prog['mode'], n, train)
+        g = self._graphs.get(key)
+        if g is None:
+            self._phase_a(prog, train)
+            if train:
+                if self.allreduce is not None:
+                    self.allreduce(self.G)
+                self._opt(n)
+            self._graphs[key] = 'warm'
+            return
+        if g == 'warm':
+            torch.cuda.synchronize()
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._phase_a(prog, train)
+            gb = None
+            if train:
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb):
+                    self._opt(n)
+            g = self._graphs[key] = (ga, gb)
+        ga, gb = g
+        ga.replay()
+        if train:
+            if self.allreduce is not None:
+                self.allreduce(self.G)
+            gb.replay()
+
+    # ------------------------------------------------------------------ results
+    def _bind_views(self, n):
+        nn, nl, MS = len(self.nodes), len(self.leaves), self.max_sinks
+        ptr, pev = self.p_tr[:nn * n].view(nn, n), self.p_ev[:nn * n].view(nn, n)
+        cerr, dcor = self.c_err[:nl * n].view(nl, n), self.d_cor[:nl * n].view(nl, n)
+        for nd in self.nodes:
+            ℓ = nd.layer
+            ℓ.p_tr, ℓ.p_ev = ptr[nd.idx], pev[nd.idx]
+            if hasattr(nd, 'leaf_id') and nd.kind == 'head':
+                ℓ.c_err, ℓ.δ_cor = cerr[nd.leaf_id], dcor[nd.leaf_id]
+            if hasattr(nd, 'switch_id'):
+                sw = nd.switch_id
+                ℓ.router.x = self.r[sw * n * MS:(sw + 1) * n * MS].view(n, MS)[:, :len(ℓ.sinks)]
+
+    def state(self):
+        """Per-sample statistics of the last run (scripts/train-nets:117-130)."""
+        net, n = self.net, self.last_n
+        y = self.y[:n]
+        out = {}
+        leaves = [nd.layer for nd in self.leaves]
+        out[(net, 'acc')] = sum(ℓ.p_ev * ℓ.δ_cor for ℓ in leaves)
+        out[(net, 'moc')] = sum(nd.layer.p_ev * self.node_ops_host[nd.idx] for nd in self.nodes)
+        for ℓ in leaves:
+            out[(ℓ, 'p_cor')] = ℓ.p_ev * ℓ.δ_cor
+            out[(ℓ, 'p_inc')] = ℓ.p_ev * (1 - ℓ.δ_cor)
+            out[(ℓ, 'p_cor_by_cls')] = (ℓ.p_ev * ℓ.δ_cor)[:, None] * y
+            out[(ℓ, 'p_inc_by_cls')] = (ℓ.p_ev * (1 - ℓ.δ_cor))[:, None] * y
+            if net._net_kind != 'sr':
+                out[(ℓ, 'p_tr')] = ℓ.p_tr
+            out[(ℓ, 'c_err')] = ℓ.c_err
+        for nd in self.switches:
+            out[(nd.layer, 'x_rte')] = nd.layer.router.x.abs().mean(1)
+        return out

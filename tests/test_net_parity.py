@@ -1,0 +1,164 @@
+"""GPU parity of whole training / evaluation steps: product nets (HIP kernels through the
+C ABI) vs. oracle/ref_net.py (float64 torch-CPU restatement of the reference graph) from
+identical injected weights and identical batches.
+
+Tolerances (fp32 kernels vs. a float64 oracle; north_star: routing statistics within 1e-3):
+  per-sample costs / probabilities : 2e-4 absolute-or-relative
+  gradients                         : 2e-3 * max|grad| per tensor (long fp32 sums, atomics)
+  parameters after 3 steps          : 2e-3 * max|param| per tensor
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def batch(n, c0=3, n_cls=10, seed=0):
+    rng = np.random.default_rng(seed)
+    x0 = rng.random((n, 32, 32, c0)).astype(np.float32)
+    y = np.eye(n_cls, dtype=np.float32)[rng.integers(0, n_cls, n)]
+    return x0, y
+
+
+def perturb_routers(net, seed=5):
+    """The last router map starts at exactly zero (arch_and_hypers.py:49); give it weight so
+    routing is non-trivial."""
+    rng = np.random.default_rng(seed)
+    for ℓ in net.layers:
+        if ℓ.router is not None:
+            w = ℓ.router.comps[-1].params.w
+            w.assign(rng.standard_normal(w.shape) * 0.5)
+            b = ℓ.router.comps[-1].params.b
+            b.assign(rng.standard_normal(b.shape) * 0.2)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (1e-12 + np.abs(b).max())
+
+
+def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3):
+    from oracle.ref_net import RefNet
+    net = make_net((32, 32, c0), (10,))
+    eng = net.engine()
+    if net._net_kind != 'sr':
+        perturb_routers(net)
+    ref = RefNet(net)
+    ref.load_params()
+    for t in range(steps):
+        x0, y = batch(n, c0, seed=t)
+        feed = {net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.05, **feeds(net, t)}
+        kw = {}
+        if net._net_kind != 'sr':
+            kw['τ'] = feed[net.τ]
+        if k_cpt_vec is not None:
+            kv = k_cpt_vec(t, n)
+            feed[net.k_cpt] = kv
+            kw['k_cpt'] = kv
+        # snapshot gradients: the engine keeps them in G until the next step
+        net.train.run(feed)
+        torch.cuda.synchronize()
+        res = ref.train_step(x0, y, 0.05, **kw)
+        R = lambda ℓ: res['out'][id(ℓ)]
+        for ℓ in net.layers:
+            assert np.abs(ℓ.p_tr.cpu().numpy() - R(ℓ)['p_tr'].detach().numpy()).max() < 2e-4, ('p_tr', ℓ.name, t)
+            assert np.abs(ℓ.p_ev.cpu().numpy() - R(ℓ)['p_ev'].detach().numpy()).max() == 0, ('p_ev', ℓ.name, t)
+        for ℓ in net.leaves:
+            ce = R(ℓ)['c_err'].detach().numpy()
+            assert np.abs(ℓ.c_err.cpu().numpy() - ce).max() < 2e-4 * (1 + np.abs(ce).max()), ('c_err', t)
+            assert np.array_equal(ℓ.δ_cor.cpu().numpy(), R(ℓ)['δ_cor'].numpy()), ('δ_cor', t)
+        for ℓ in net.switches:
+            rx = R(ℓ.router)['x'].detach().numpy()
+            assert np.abs(ℓ.router.x.cpu().numpy() - rx).max() < 2e-4 * (1 + np.abs(rx).max()), ('router.x', t)
+        bad = []
+        for p in net._all_params:
+            if not p.trainable:
+                continue
+            g_ref = res['grads'][id(p)].numpy().reshape(-1)
+            g = p.grad.cpu().numpy()
+            scale = np.abs(g_ref).max()
+            if np.abs(g - g_ref).max() > 2e-3 * scale + 1e-9:
+                bad.append((p.owner.name, p.name, float(np.abs(g - g_ref).max()), float(scale)))
+        assert not bad, ('grads', t, bad[:8])
+    bad = []
+    for p in net._all_params:
+        v_ref = ref.V(p).detach().numpy().reshape(-1)
+        v = p.data.cpu().numpy()
+        if np.abs(v - v_ref).max() > 2e-3 * np.abs(v_ref).max() + 1e-7:
+            bad.append((p.owner.name, p.name, float(np.abs(v - v_ref).max()), float(np.abs(v_ref).max())))
+    assert not bad, ('params', bad[:8])
+    # evaluation pass: moving-average BatchNorm, hard routing, statistics
+    x0, y = batch(n, c0, seed=99)
+    feed = {net.x0: x0, net.y: y, **{k: v for k, v in feeds(net, 0).items()}}
+    kw = {}
+    if k_cpt_vec is not None:
+        feed[net.k_cpt] = k_cpt_vec(0, n)
+        kw['k_cpt'] = k_cpt_vec(0, n)
+    net.eval(feed)
+    st = net.state()
+    res = ref.forward(x0, y, 'ev', τ=feed.get(getattr(net, 'τ', None)), **kw)
+    rs = ref.stats(res)
+    assert np.abs(st[(net, 'acc')].cpu().numpy() - rs['acc']).mean() <= 1e-3
+    assert rel(st[(net, 'moc')].cpu().numpy().mean(), rs['moc'].mean()) <= 1e-3
+    hist = np.stack([ℓ.p_ev.cpu().numpy() for ℓ in net.leaves]).mean(1)
+    assert np.abs(hist - rs['p_leaf'].mean(1)).max() <= 1e-3
+
+
+def test_sr_chain_3():
+    import arch_and_hypers as A
+    run_case(A.sr_chain(3), 8, lambda net, t: {})
+
+
+def test_sr_chain_8():
+    import arch_and_hypers as A
+    run_case(A.sr_chain(8), 8, lambda net, t: {}, steps=2)
+
+
+def test_ac_chain():
+    import arch_and_hypers as A
+    run_case(A.ac_chain(k_cpt=1.6e-8), 16, lambda net, t: {net.τ: A.τ_ds(t * 5000)})
+
+
+def test_cr_chain():
+    import arch_and_hypers as A
+    run_case(A.cr_chain(k_cpt=8e-9), 16, lambda net, t: {net.τ: A.τ_cr(t * 5000)})
+
+
+def test_cr_chain_optimistic_clserr():
+    import arch_and_hypers as A
+    run_case(A.cr_chain(k_cpt=8e-9, optimistic=True, use_cls_err=True), 12, lambda net, t: {net.τ: 0.05}, steps=2)
+
+
+def test_ac_chain_notalr_nokdec():
+    import arch_and_hypers as A
+    run_case(A.ac_chain(k_cpt=4e-9, talr=False, k_dec=0), 12, lambda net, t: {net.τ: 0.7}, steps=2)
+
+
+def test_ac_chain_dyn_k_cpt():
+    import arch_and_hypers as A
+    kv = lambda t, n: np.random.default_rng(t).choice(A.k_cpts, n).astype(np.float32)
+    run_case(A.ac_chain(dyn_k_cpt=True), 12, lambda net, t: {net.τ: 0.8}, steps=2, k_cpt_vec=kv)
+
+
+def test_mnist_sr():
+    import arch_and_hypers as A
+    run_case(A.sr_chain(2), 8, lambda net, t: {}, steps=2, c0=1)
+
+
+def test_known_answers_at_init():
+    """KA3/KA4: at initialisation every router output is exactly 0, so the test-time
+    routing histogram is [1,0,...,0], moc = 1 368 608, leaf p_tr ~ 2^-(j+1)."""
+    import arch_and_hypers as A
+    net = A.ac_chain(k_cpt=0.0)((32, 32, 3), (10,))
+    x0, y = batch(16)
+    net.eval({net.x0: x0, net.y: y})
+    st = net.state()
+    leaves = list(net.leaves)
+    hist = [float(ℓ.p_ev.mean()) for ℓ in leaves]
+    assert hist == [1.0] + [0.0] * 7
+    assert float(st[(net, 'moc')].mean()) == 1361664 + 4384 + 2560
+    ptr = [float(ℓ.p_tr.mean()) for ℓ in leaves]
+    assert abs(sum(ptr) - 1) < 1e-6
+    for j, p in enumerate(ptr):
+        assert abs(p - 2.0 ** -(min(j, 6) + 1)) < 1e-5
