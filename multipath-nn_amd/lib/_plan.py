@@ -23,6 +23,7 @@ parameter -> tree-node map of minimize_expectation (net_types.py:28-34).
 """
 import ctypes as C
 import os
+import unicodedata
 
 import numpy as np
 import torch
@@ -35,6 +36,16 @@ ROUTER_COMPS = ['Select', 'LinTrans', 'BatchNorm', 'Rect', 'LinTrans', 'BatchNor
 BLOCK_COMPS = ['MultiscaleConvMax', 'MultiscaleBatchNorm', 'MultiscaleRect']
 HEAD_COMPS = ['Select', 'LinTrans', 'Softmax', 'CrossEntropyError']
 OPT_CHUNK = 2048
+
+
+def _nf(name):
+    """Python NFKC-normalises identifiers (the keyword ``ϵ=`` U+03F5 is stored as U+03B5) but not
+    string literals: every string-keyed attribute lookup must go through the same normalisation."""
+    return unicodedata.normalize('NFKC', name)
+
+
+def _attr(obj, name, default=None):
+    return getattr(obj, _nf(name), default)
 
 
 def _kind(ℓ):
@@ -416,7 +427,7 @@ class Engine:
             lf.HW = lb.HW = b.H[L1] * b.W[L1]
             lf.n = lb.n = tf.n = n
             lf.k_cpt = lb.k_cpt = self.k_cpt.data_ptr()
-            lf.alpha_cpt = lb.alpha_cpt = float(getattr(ϕ, 'α_cpt', 0.0))
+            lf.alpha_cpt = lb.alpha_cpt = float(_attr(ϕ, 'α_cpt', 0.0))
             lb.dx = b.dx.data_ptr()
             tf.mode = act_mode
             if b.head is not None:
@@ -567,15 +578,15 @@ class Engine:
         put(self.x0[:n], x0)
         put(self.y[:n], feed[net.y])
         ϕ = net.hypers
-        get = lambda name, default: feed.get(getattr(net, name, None), getattr(ϕ, name, default))
+        get = lambda name, default: feed.get(_attr(net, name), _attr(ϕ, name, default))
         h = self.hyp_host
         h[_hip.HYP_LR] = float(get('λ_lrn', 0.0))
         h[_hip.HYP_MU] = float(get('μ_lrn', 0.0))
         h[_hip.HYP_TAU] = float(get('τ', 1.0))
         h[_hip.HYP_EPS] = float(get('ϵ', 0.0))
-        h[_hip.HYP_KDEC] = float(getattr(ϕ, 'k_dec', 0.0))
-        h[_hip.HYP_KCRE] = float(getattr(ϕ, 'k_cre', 0.0))
-        h[_hip.HYP_ARTR] = float(getattr(ϕ, 'α_rtr', 1.0))
+        h[_hip.HYP_KDEC] = float(_attr(ϕ, 'k_dec', 0.0))
+        h[_hip.HYP_KCRE] = float(_attr(ϕ, 'k_cre', 0.0))
+        h[_hip.HYP_ARTR] = float(_attr(ϕ, 'α_rtr', 1.0))
         if getattr(ϕ, 'dyn_k_cpt', False):
             k = feed[net.k_cpt]
             k = np.broadcast_to(np.asarray(k, np.float32).reshape(-1), (n,)) if not isinstance(k, torch.Tensor) else k.expand(n)

@@ -247,7 +247,7 @@ class RefNet:
             for p in params_list_rec(ℓ):
                 scale[id(p)] = s
             for p in params_list_rec(ℓ.router):
-                scale[id(p)] = (getattr(ϕ, 'α_rtr', 1.0) if talr else 1.0) * s
+                scale[id(p)] = (ϕ.α_rtr if talr else 1.0) * s
         res['grads'] = {}
         with torch.no_grad():
             for p in net._all_params:
