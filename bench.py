@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of full training steps (forward + backward +
+gradient all-reduce + TALR/momentum update) of the CIFAR-10 actor-routed chain
+net (BASELINE.json: cifar10-ac), batch 128 per GPU, synthetic 32x32x3 inputs
+resident in HBM, fp32 (the reference's arithmetic type).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract: see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'multipath-nn_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+MAC_FWD = 20699872                    # ac/cr chain forward MAC per image
+F_TRAIN = 6 * MAC_FWD - 2 * 587520    # no dgrad w.r.t. the image: 123.024 MFLOP
+PEAK_F32_MFMA = 157.3                 # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+
+
+def synthetic(n, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.rand((n, 32, 32, 3), generator=g)
+    y = torch.nn.functional.one_hot(torch.randint(0, 10, (n,), generator=g), 10).float()
+    return x0.to(device), y.to(device)
+
+
+def cpu_baseline(batch, seconds=15.0):
+    """The oracle (oracle/ref_net.py, torch-CPU fp32, all host cores) on the same step."""
+    import arch_and_hypers as A
+    from oracle.ref_net import RefNet
+    net = A.ac_chain(k_cpt=0.0)((32, 32, 3), (10,))
+    rng = np.random.default_rng(1234)
+    vals = {}
+    for p in net._all_params:
+        kind, scale = p.init
+        vals[id(p)] = ((scale * rng.standard_normal(p.size)) if kind == 'normal' else
+                       (np.ones(p.size) if kind == 'ones' else np.zeros(p.size))).reshape(p.shape)
+    ref = RefNet(net, torch.float32)
+    ref.load_params(vals)
+    x0, y = synthetic(batch, 0, 'cpu')
+    x0, y = x0.numpy(), y.numpy()
+    times = []
+    t_end = time.time() + seconds
+    for i in range(1000):
+        t0 = time.time()
+        ref.train_step(x0, y, 0.1, τ=1.0)
+        if i >= 2:
+            times.append(time.time() - t0)
+        if time.time() > t_end and len(times) >= 3:
+            break
+    med = float(np.median(times))
+    return dict(value=batch / med, unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d timed steps of batch %d (median %.1f ms/step), oracle/ref_net.py torch-CPU fp32'
+                       % (len(times), batch, med * 1e3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=128, help='per-GPU batch (arch_and_hypers.py:35)')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import arch_and_hypers as A
+    from lib import _dp
+    rank, world = _dp.init()
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dev = 'cuda:%d' % local
+    torch.cuda.set_device(local)
+
+    net = A.ac_chain(k_cpt=0.0, seed=1234)((32, 32, 3), (10,))
+    net.to(dev)
+    eng = net.engine()
+    eng.use_graph = not args.no_graph
+    _dp.attach(net)
+    n = args.batch
+    x0, y = synthetic(n, rank, dev)
+    eng.x0[:n].copy_(x0)
+    eng.y[:n].copy_(y)
+    feed = {net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr',
+            net.λ_lrn: A.λ_lrn(0), net.τ: A.τ_ds(0)}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 3)):      # >= 3: eager, capture, first replay
+        net.train.run(feed)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.train.run(feed)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = n * world / (dt / args.steps)
+
+    out = None
+    if rank == 0:
+        # routed FLOPs/s = images/s x 2 x moc (scripts/train-nets:120), moc from an 'ev' pass
+        net.eval({net.x0: eng.x0[:n], net.y: eng.y[:n]})
+        moc = float(net.state()[(net, 'moc')].mean())
+        # dominant kernel: per-launch HIP-event timing on the launch stream
+        ops = eng.time_ops('tr', n, reps=20)
+        conv = [o for o in ops if o[2] > 0]
+        dom = max(conv, key=lambda o: o[3])
+        ach = dom[2] / (dom[3] * 1e-3) / 1e12
+        total_ms = sum(o[3] for o in ops)
+        conv_fl, conv_ms = sum(o[2] for o in conv), sum(o[3] for o in conv)
+        out = {
+            'metric': 'images/sec training CIFAR-10 actor-net', 'value': value, 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'cifar10-ac: ac_chain(k_cpt=0) 8-block actor-routed chain, 32x32x3, 10 classes',
+                       'global_batch': n * world, 'per_gpu_batch': n, 'parallelism': 'dp%d' % world,
+                       'hip_graph': bool(eng.use_graph)},
+            'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
+                         'frac': ach / PEAK_F32_MFMA, 'traffic': None,
+                         'kernel': '%s [%s]' % (dom[0], dom[1]), 'kernel_ms': dom[3],
+                         'kernel_flops': dom[2]},
+            'step_frac_of_mfma_roofline': value / world * F_TRAIN / 1e12 / PEAK_F32_MFMA,
+            'conv_kernels': {'tflops': conv_fl / (conv_ms * 1e-3) / 1e12, 'sum_ms': conv_ms,
+                             'all_launches_sum_ms': total_ms, 'n_launches': len(ops)},
+            'routed_flops_per_s': value * 2 * moc, 'moc': moc,
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(n)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

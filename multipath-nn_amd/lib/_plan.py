@@ -387,9 +387,10 @@ class Engine:
         ϕ = net.hypers
         fwd, bwd = [], []
 
-        def call(fn, what, *args):
+        def call(fn, what, *args, flops=0.0, tag=''):
             def launch(st):
                 _hip.check(fn(*args, st), what)
+            launch.what, launch.flops, launch.tag = what, float(flops), tag
             return launch
 
         # ---- forward convs ----
@@ -407,7 +408,9 @@ class Engine:
                 a.out_sum = self.dsum[b.sum_off[i]:].data_ptr() if mode == 'tr' else None
                 a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
                 keep.append(a)
-                fwd.append(call(lib.mpnn_msconv_fwd, 'msconv_fwd', C.byref(a)))
+                fl = 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
+                fwd.append(call(lib.mpnn_msconv_fwd, 'msconv_fwd', C.byref(a), flops=fl,
+                                tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])))
 
         # ---- exits ----
         dyn = bool(getattr(ϕ, 'dyn_k_cpt', False))
@@ -526,7 +529,9 @@ class Engine:
                 a.dz_g_fine = b.dzg[i - 1].data_ptr()
                 a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i - 1]
                 keep.append(a)
-                bwd.append(call(lib.mpnn_msconv_dgrad_vert, 'dgrad_vert', C.byref(a)))
+                bwd.append(call(lib.mpnn_msconv_dgrad_vert, 'dgrad_vert', C.byref(a),
+                                flops=2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * b.C[i - 1],
+                                tag='h%d %d->%d' % (b.H[i], b.C[i], b.C[i - 1])))
             for i in range(b.L):
                 a = _hip.WgradArgs()
                 a.a = self._act_of_input(b, i, n, act_mode)
@@ -539,7 +544,9 @@ class Engine:
                 a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
                 a.n_split = self._wsplit(b, i, n)
                 keep.append(a)
-                bwd.append(call(lib.mpnn_msconv_wgrad, 'wgrad', C.byref(a)))
+                fl = 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
+                bwd.append(call(lib.mpnn_msconv_wgrad, 'wgrad', C.byref(a), flops=fl,
+                                tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])))
             if b.parent is not None:
                 pb = b.parent
                 for i in range(b.L):
@@ -554,7 +561,9 @@ class Engine:
                     a.red_out = self.dred[pb.sum_off[j]:].data_ptr()
                     a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], pb.C[j]
                     keep.append(a)
-                    bwd.append(call(lib.mpnn_msconv_dgrad_horz, 'dgrad_horz', C.byref(a)))
+                    bwd.append(call(lib.mpnn_msconv_dgrad_horz, 'dgrad_horz', C.byref(a),
+                                    flops=2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * pb.C[j],
+                                    tag='h%d %d->%d' % (b.H[i], b.C[i], pb.C[j])))
         bwd.append(call(lib.mpnn_bn_finalize, 'bn_finalize', self.dsum.data_ptr(), self.dred.data_ptr(),
                         self.S.data_ptr(), self.G.data_ptr(), self.bn_table.data_ptr(), self.n_bn,
                         self.bn_decay, n))
@@ -675,6 +684,29 @@ class Engine:
             if self.allreduce is not None:
                 self.allreduce(self.G)
             gb.replay()
+
+    def time_ops(self, mode, n, reps=20):
+        """Per-launch timing with HIP events on the launch stream (torch's current
+        stream is the stream every kernel of the plan is launched on).  Returns
+        [(what, tag, flops, mean_ms)] for one (mode, n) program, forward then backward."""
+        prog = self.program(mode, n)
+        ops = list(prog['fwd']) + (list(prog['bwd']) if mode == 'tr' else [])
+        st = torch.cuda.current_stream()
+        out = []
+        self._zero(mode == 'tr')
+        self._pack()
+        for op in ops:                        # state made valid by running the whole step once
+            op(st.cuda_stream)
+        for op in ops:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            op(st.cuda_stream)
+            e0.record(st)
+            for _ in range(reps):
+                op(st.cuda_stream)
+            e1.record(st)
+            e1.synchronize()
+            out.append((op.what, op.tag, op.flops, e0.elapsed_time(e1) / reps))
+        return out
 
     # ------------------------------------------------------------------ results
     def _bind_views(self, n):
