@@ -28,6 +28,12 @@ extern "C" {
 #define MPNN_E_SHAPE   (-1)   /* unsupported geometry / channel count      */
 #define MPNN_E_ARG     (-2)   /* inconsistent arguments                     */
 
+/* BatchNorm statistics are accumulated with fp64 atomics into MPNN_BN_SLOTS
+ * replicated slots (a workgroup adds to slot blockIdx % MPNN_BN_SLOTS) so that
+ * thousands of workgroups do not serialise on one address; readers add the
+ * slots.  A statistics buffer is therefore [MPNN_BN_SLOTS][2*C] doubles. */
+#define MPNN_BN_SLOTS 16
+
 #define MPNN_ACT_IDENTITY 0   /* raw values (pyramid input, gradients)      */
 #define MPNN_ACT_BN_BATCH 1   /* relu(bn(x)) with batch statistics ('tr')   */
 #define MPNN_ACT_BN_MOVING 2  /* relu(bn(x)) with moving averages  ('ev')   */
@@ -39,7 +45,7 @@ extern "C" {
  * `shift` = log2 of the subsampling factor). */
 typedef struct {
     const float  *x;       /* [n, H<<shift, W<<shift, C]                      */
-    const double *sum;     /* [2*C]: sum, sum of squares over (n,H,W)         */
+    const double *sum;     /* [SLOTS][2*C]: sum, sum of squares over (n,H,W)  */
     const float  *gamma, *beta, *m_avg, *v_avg;   /* [C] each                 */
     float eps;             /* BatchNorm eps (layer_types.py:220)              */
     int   cnt;             /* n*H*W: element count behind `sum`               */
@@ -70,7 +76,7 @@ typedef struct {
     const float *wa_pack;  const float *wv_pack;   /* forward packs           */
     const float *bias;                              /* [Cout]                  */
     float  *out;                                    /* [n, H, W, Cout]         */
-    double *out_sum;                                /* [2*Cout], accumulated   */
+    double *out_sum;                                /* [SLOTS][2*Cout], accumulated */
     int n, H, W, Cout;
 } mpnn_conv_fwd_args;
 int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
@@ -86,7 +92,7 @@ int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
 typedef struct {
     const float *s;        /* pre-BN values [n,H,W,C]                          */
     mpnn_act bn;           /* the BatchNorm of s (x field unused)              */
-    const double *red;     /* [2*C] sum dz, sum dz*xhat (NULL: treat as zero)  */
+    const double *red;     /* [SLOTS][2*C] sum dz, sum dz*xhat (NULL: zero)    */
 } mpnn_bn_ctx;
 int mpnn_bn_bwd_reduce(const float *dy, const mpnn_bn_ctx *ctx, float *dz,
                        double *red_out, long n_pix, void *stream);
@@ -108,7 +114,7 @@ typedef struct {
     const float *dy_extra;               /* [n,H,W,Cout] or NULL                   */
     const mpnn_bn_ctx *prev;             /* producer BatchNorm context or NULL     */
     float  *out;                         /* dz (prev != NULL) or dy                */
-    double *red_out;                     /* [2*Cout] accumulated (prev != NULL)    */
+    double *red_out;                     /* [SLOTS][2*Cout] accumulated (prev != NULL) */
     int n, H, W, Cout;
 } mpnn_dgrad_horz_args;
 int mpnn_msconv_dgrad_horz(const mpnn_dgrad_horz_args *args, void *stream);
@@ -124,18 +130,30 @@ typedef struct {
 int mpnn_msconv_dgrad_vert(const mpnn_dgrad_vert_args *args, void *stream);
 
 /* ---- multiscale conv block, weight gradients -------------------------------
- * dW_horz = act(a)^T (*) g, dW_vert = maxpool2x2(v)^T (*) g, db = sum g,
- * accumulated (fp32 atomics) into zeroed HWIO gradient tensors.  `n_split` =
- * number of workgroups the pixel range is divided over. */
+ * dW_horz = act(a)^T (*) g, dW_vert = maxpool2x2(v)^T (*) g, db = sum g.
+ * The pixel range is divided over `n_split` workgroup rows; split s WRITES its
+ * partial sums (plain stores, every element exactly once) to dwa/dwv/db +
+ * s*split_stride.  With n_split == 1 those may be the gradient tensors
+ * themselves; otherwise they point into a scratch slab and mpnn_slab_reduce
+ * adds the splits in a fixed order (bitwise-reproducible gradients; fp32
+ * atomics from hundreds of workgroups onto a few-KB tensor serialise). */
 typedef struct {
     mpnn_act a;
     const float *v;  int Cv;
     const float *g;                      /* [n,H,W,Cout]                           */
-    float *dwa;  float *dwv;  float *db; /* HWIO grads, [Cout]                     */
+    float *dwa;  float *dwv;  float *db; /* HWIO partial sums of split 0, [Cout]   */
+    long split_stride;                   /* floats between consecutive splits      */
     int n, H, W, Cout;
     int n_split;
 } mpnn_wgrad_args;
 int mpnn_msconv_wgrad(const mpnn_wgrad_args *args, void *stream);
+/* Number of 64-pixel tiles (upper bound of n_split) for a map, or MPNN_E_SHAPE. */
+int mpnn_wgrad_tiles(int n, int H, int W);
+/* dst[i] = sum_{s<n_split} src[s*stride + i].  table: 6 ints per work item:
+ * src_off (floats in `slabs`), dst_off (floats in `grads`), count (<= 1024),
+ * n_split, stride, reserved. */
+int mpnn_slab_reduce(const float *slabs, float *grads, const int *table, int n_items,
+                     void *stream);
 
 /* ---- exit head + router, first affine map ----------------------------------
  * y_k = flatten(act(a)) @ w_k + b_k [+ alpha_cpt * k_cpt[n] * w_k[K]] for up to
@@ -252,7 +270,8 @@ int mpnn_compact_by_branch(const float *p_ev, int n, int *idx_out, int *count_ou
 /* ---- BatchNorm epilogue of a training step ----------------------------------
  * Moving averages (layer_types.py:233-234) from the forward sums and
  * dgamma / dbeta from the backward reductions, for every conv BatchNorm in one
- * launch.  table: 8 ints per BN: sum_off (doubles; same offset in `reds`),
+ * launch.  table: 8 ints per BN: sum_off (doubles; same offset in `reds`; each
+ * a [SLOTS][2*C] block),
  * mavg_off, vavg_off (floats in `state`), C, pixels per image, gamma_goff,
  * beta_goff (floats in `grads`; -1: no gradient), reserved. */
 int mpnn_bn_finalize(const double *sums, const double *reds, float *state, float *grads,

@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
             if (EPI == EPI_DGH_BN) { e[3] = k.beta; e[4] = 0.f; }
             else {
                 const double inv = 1.0 / (double)p.pbn.cnt;
-                e[3] = p.red ? (float)(p.red[co0 + c] * inv) : 0.f;               // dbeta / cnt
-                e[4] = p.red ? (float)(p.red[p.pbn.C + co0 + c] * inv) : 0.f;     // dgamma / cnt
+                e[3] = p.red ? (float)(slot_sum(p.red, 2 * p.pbn.C, co0 + c) * inv) : 0.f;             // dbeta / cnt
+                e[4] = p.red ? (float)(slot_sum(p.red, 2 * p.pbn.C, p.pbn.C + co0 + c) * inv) : 0.f;   // dgamma / cnt
             }
         }
     }
@@ -309,8 +309,9 @@ __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
                 double a1 = 0.0, a2 = 0.0;
 #pragma unroll
                 for (int w = 0; w < WM; ++w) { a1 += redbuf[(w * CT + tid) * 2]; a2 += redbuf[(w * CT + tid) * 2 + 1]; }
-                atomicAdd(dst + co0 + tid, a1);
-                atomicAdd(dst + p.Cout + co0 + tid, a2);
+                double *slot = dst + (size_t)(blockIdx.x % MPNN_BN_SLOTS) * 2 * p.Cout;
+                atomicAdd(slot + co0 + tid, a1);
+                atomicAdd(slot + p.Cout + co0 + tid, a2);
             }
         }
     }

@@ -46,12 +46,26 @@ extern "C" int mpnn_pack_weights(const float *params, float *packs, const int *d
 // ---------------------------------------------------------------------------
 struct BnBwdP { const float *dy; const float *s; mpnn_act bn; const double *red; float *dz; double *red_out; long n_pix; };
 
+// Per-workgroup coefficient table in LDS: [C][6] = m, rstd, gamma*rstd, beta, red0/cnt, red1/cnt.
+__device__ __forceinline__ void bn_table(const BnBwdP &p, float *tab) {
+    const int C = p.bn.C;
+    const double inv = 1.0 / (double)p.bn.cnt;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const BnC k = bn_coef(p.bn, c);
+        float *e = tab + c * 6;
+        e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd; e[3] = k.beta;
+        e[4] = p.red ? (float)(slot_sum(p.red, 2 * C, c) * inv) : 0.f;
+        e[5] = p.red ? (float)(slot_sum(p.red, 2 * C, C + c) * inv) : 0.f;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const BnBwdP p) {
+    __shared__ float tab[1024 * 6 / 4];           // C <= 256 here (host checks)
+    __shared__ double sh[256 * 8];
+    bn_table(p, tab);
     const int C = p.bn.C, Q = C >> 2;             // channel quads
     const int q = threadIdx.x % Q, lane_pix = threadIdx.x / Q, ppb = 256 / Q;
-    BnC k[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) k[j] = bn_coef(p.bn, q * 4 + j);
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     for (long pix = (long)blockIdx.x * ppb + lane_pix; pix < p.n_pix; pix += (long)gridDim.x * ppb) {
         const size_t idx = (size_t)pix * C + q * 4;
@@ -59,14 +73,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const BnBwdP p) {
         f32x4 dz;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float d = s[j] - k[j].m;
-            const float yv = d * (k[j].gamma * k[j].rstd) + k[j].beta;
+            const float *e = tab + (q * 4 + j) * 6;
+            const float d = s[j] - e[0];
+            const float yv = d * e[2] + e[3];
             dz[j] = yv > 0.f ? dy[j] : 0.f;
-            s1[j] += dz[j]; s2[j] += dz[j] * (d * k[j].rstd);
+            s1[j] += dz[j]; s2[j] += dz[j] * (d * e[1]);
         }
         *(f32x4 *)(p.dz + idx) = dz;
     }
-    __shared__ double sh[256 * 8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { sh[threadIdx.x * 8 + j] = s1[j]; sh[threadIdx.x * 8 + 4 + j] = s2[j]; }
     __syncthreads();
@@ -74,33 +88,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const BnBwdP p) {
         const int c = threadIdx.x, cq = c >> 2, cj = c & 3;
         double a1 = 0, a2 = 0;
         for (int r = 0; r < ppb; ++r) { a1 += sh[(r * Q + cq) * 8 + cj]; a2 += sh[(r * Q + cq) * 8 + 4 + cj]; }
-        atomicAdd(p.red_out + c, a1);
-        atomicAdd(p.red_out + C + c, a2);
+        double *slot = p.red_out + (size_t)(blockIdx.x % MPNN_BN_SLOTS) * 2 * C;
+        atomicAdd(slot + c, a1);
+        atomicAdd(slot + C + c, a2);
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(const BnBwdP p) {
+    __shared__ float tab[1024 * 6 / 4];
+    bn_table(p, tab);
     const int C = p.bn.C, Q = C >> 2;
     const long total = p.n_pix * Q;
-    const double inv = 1.0 / (double)p.bn.cnt;
+    // Q divides 256 and the grid stride, so a thread keeps one channel quad.
+    const float *e0 = tab + (threadIdx.x % Q) * 24;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int q = (int)(i % Q);
         const size_t idx = (size_t)i * 4;
         const f32x4 dz = *(const f32x4 *)(p.dz + idx), s = *(const f32x4 *)(p.s + idx);
         f32x4 g;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = q * 4 + j;
-            const BnC k = bn_coef(p.bn, c);
-            const float r0 = p.red ? (float)(p.red[c] * inv) : 0.f, r1 = p.red ? (float)(p.red[C + c] * inv) : 0.f;
-            const float xh = (s[j] - k.m) * k.rstd;
-            g[j] = k.gamma * k.rstd * (dz[j] - r0 - xh * r1);
+            const float *e = e0 + j * 6;
+            const float xh = (s[j] - e[0]) * e[1];
+            g[j] = e[2] * (dz[j] - e[4] - xh * e[5]);
         }
         *(f32x4 *)(p.dz + idx) = g;
     }
 }
 
-static int bn_shape_ok(int C) { return C > 0 && (C & 3) == 0 && C <= 1024 && (256 % (C >> 2)) == 0; }
+static int bn_shape_ok(int C) { return C > 0 && (C & 3) == 0 && C <= 256 && (256 % (C >> 2)) == 0; }
 
 extern "C" int mpnn_bn_bwd_reduce(const float *dy, const mpnn_bn_ctx *ctx, float *dz, double *red_out,
                                   long n_pix, void *stream) {
@@ -109,8 +124,8 @@ extern "C" int mpnn_bn_bwd_reduce(const float *dy, const mpnn_bn_ctx *ctx, float
     if (n_pix <= 0) return 0;
     BnBwdP p = {dy, ctx->s, ctx->bn, nullptr, dz, red_out, n_pix};
     const int ppb = 256 / (ctx->bn.C >> 2);
-    long blocks = (n_pix + (long)ppb * 8 - 1) / ((long)ppb * 8);
-    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    long blocks = (n_pix + (long)ppb * 16 - 1) / ((long)ppb * 16);
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
     hipLaunchKernelGGL(bn_bwd_reduce_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     MPNN_LAUNCH_CHECK();
     return 0;
@@ -121,8 +136,8 @@ extern "C" int mpnn_bn_bwd_apply(float *dz_inout, const mpnn_bn_ctx *ctx, long n
     if (!bn_shape_ok(ctx->bn.C)) return MPNN_E_SHAPE;
     if (n_pix <= 0) return 0;
     BnBwdP p = {nullptr, ctx->s, ctx->bn, ctx->red, dz_inout, nullptr, n_pix};
-    long blocks = (n_pix * (ctx->bn.C >> 2) + 1023) / 1024;
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    long blocks = (n_pix * (ctx->bn.C >> 2) + 2047) / 2048;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipLaunchKernelGGL(bn_bwd_apply_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     MPNN_LAUNCH_CHECK();
     return 0;
@@ -143,15 +158,15 @@ __global__ void bn_finalize_k(const double *__restrict__ sums, const double *__r
     const int C = t[3];
     const double inv = 1.0 / ((double)t[4] * (double)n_img);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double mean = sums[t[0] + c] * inv;
-        double var = sums[t[0] + C + c] * inv - mean * mean;
+        const double mean = slot_sum(sums + t[0], 2 * C, c) * inv;
+        double var = slot_sum(sums + t[0], 2 * C, C + c) * inv - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         float *m = state + t[1] + c, *v = state + t[2] + c;
         *m = decay * *m + (1.f - decay) * (float)mean;
         *v = decay * *v + (1.f - decay) * (float)var;
         if (reds && grads && t[5] >= 0) {
-            grads[t[6] + c] = (float)reds[t[0] + c];          // dbeta  = sum dz
-            grads[t[5] + c] = (float)reds[t[0] + C + c];      // dgamma = sum dz * xhat
+            grads[t[6] + c] = (float)slot_sum(reds + t[0], 2 * C, c);          // dbeta  = sum dz
+            grads[t[5] + c] = (float)slot_sum(reds + t[0], 2 * C, C + c);      // dgamma = sum dz * xhat
         }
     }
 }

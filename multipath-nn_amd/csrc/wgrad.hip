@@ -1,5 +1,6 @@
 // mpnn_msconv_wgrad: weight / bias gradients of one MultiscaleConvMax scale on
-// v_mfma_f32_16x16x4_f32.
+// v_mfma_f32_16x16x4_f32, and mpnn_slab_reduce, the deterministic sum of the
+// per-workgroup partial gradients.
 //
 //   dW_horz[t][c][co] = sum_pix act(a)[pix + t][c]      * g[pix][co]
 //   dW_vert[t][c][co] = sum_pix maxpool2(v)[pix + t][c] * g[pix][co]
@@ -8,20 +9,25 @@
 // GEMM view per tap: M = 16 input channels (one chunk), N = output channels,
 // K = pixels.  grid = (pixel splits, channel chunks of A then V, cout groups).
 // A workgroup keeps 9 taps x OT cout tiles of fp32 accumulators in registers
-// (waves own taps {w, w+4, w+8}) while it walks its share of the 64-pixel
-// tiles, then adds them to the HWIO gradient with fp32 atomics (bytes of
-// atomics = splits x |dW|; the host picks the split).
+// (waves own taps {w, w+4, w+8}; wave 1's spare slot accumulates the bias
+// gradient with a one-hot A operand) while it walks its share of the 64-pixel
+// tiles, prefetching the next tile's global loads into registers under the
+// MFMAs.  Partial sums leave with plain stores into slab `blockIdx.x`
+// (fp32 atomics from hundreds of workgroups onto a few-KB gradient tensor
+// serialise: 54 us instead of < 10 for the 16->16 layers); mpnn_slab_reduce
+// adds the slabs in a fixed order, so gradients are bitwise reproducible.
 //
-// LDS: the input chunk's halo tile in the same [plane][pixel] float4 layout the
-// forward conv stages (stage_chunk is shared) but with plane stride == 1 mod 8
-// slots so that the 16 channels x 2 pixel groups of a ds_read_b32 wave-half
-// fall on 32 distinct banks; the g tile as [64 pixels][OT*16 + 4].
+// LDS: the input chunk's halo tile in the [plane][pixel] float4 layout of the
+// forward conv but with plane stride == 1 mod 8 slots so that the 16 channels x
+// 2 pixel groups of a ds_read_b32 wave-half fall on 32 distinct banks; the g
+// tile as [64 pixels][OT*16 + 4].
 #include "conv_kernel.h"
 
 struct WgP {
-    ConvP c;                 // a, v, Cv, n, H, W used by stage_chunk
+    ConvP c;                 // a, v, Cv, n, H, W, Cout
     const float *g;
-    float *dwa, *dwv, *db;
+    float *dwa, *dwv, *db;   // partial-sum destinations of split 0
+    long split_stride;       // floats between consecutive splits' destinations
     int n_tiles;
 };
 
@@ -30,77 +36,137 @@ template <> struct WGeom<0> { static constexpr int PS = 113; };
 template <> struct WGeom<1> { static constexpr int PS = 241; };
 template <> struct WGeom<2> { static constexpr int PS = 289; };
 
-template <int GK, int PS, int MODE>
-__device__ __forceinline__ void stage_chunk_ps(f32x4 *tile, const ConvP &p, const float *cA,
-                                               int n0, int y0, int x0, int c0, int np, int tid) {
+template <int GK> struct XItems {
     using G = Geom<GK>;
-    constexpr int HR = G::TH + 2, HC = G::TW + 2, NHP = G::IMG * HR * HC, NHP8 = (NHP + 7) & ~7;
-    for (int i = tid; i < NHP8 * 4; i += 256) {
-        const int q = (i >> 3) & 3;
-        const int hp = ((i >> 5) << 3) + (i & 7);
-        if (hp >= NHP) continue;
-        const int img = hp / (HR * HC);
-        const int rem = hp - img * (HR * HC);
-        const int hy = rem / HC, hx = rem - hy * HC;
-        const int n = n0 + img, y = y0 + hy - 1, x = x0 + hx - 1;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (q < np && n < p.n && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+    static constexpr int HR = G::TH + 2, HC = G::TW + 2, NHP = G::IMG * HR * HC, NHP8 = (NHP + 7) & ~7;
+    static constexpr int N = (NHP8 * 4 + 255) / 256;      // float4 items per thread
+};
+
+// Item -> (halo pixel, plane) decode shared by the load and store halves.
+template <int GK>
+__device__ __forceinline__ bool x_item(int i, int n0, int y0, int x0, int np, const ConvP &p,
+                                       int &q, int &lds_slot, int &n, int &y, int &x, bool &inb) {
+    using X = XItems<GK>;
+    using G = Geom<GK>;
+    q = (i >> 3) & 3;
+    const int hp = ((i >> 5) << 3) + (i & 7);
+    if (hp >= X::NHP) return false;
+    const int img = hp / (X::HR * X::HC);
+    const int rem = hp - img * (X::HR * X::HC);
+    const int hy = rem / X::HC, hx = rem - hy * X::HC;
+    n = n0 + img; y = y0 + hy - 1; x = x0 + hx - 1;
+    lds_slot = (img * X::HR + hy) * G::R + hx;
+    inb = q < np && n < p.n && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    return true;
+}
+
+// Global -> registers, RAW (no arithmetic on the loaded values: the loads stay in
+// flight under the MFMAs of the current tile; transforms happen in store_x).
+// MODE 0: one float4 per item; MODE 1: the four float4 of the 2x2 pooling window.
+template <int GK, int MODE>
+__device__ __forceinline__ void load_x(f32x4 (*xr)[MODE ? 4 : 1], const ConvP &p,
+                                       int n0, int y0, int x0, int c0, int np, int tid) {
+    using X = XItems<GK>;
+#pragma unroll
+    for (int k = 0; k < X::N; ++k) {
+        int q, slot, n, y, x; bool inb;
+        const bool ok = x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb);
+#pragma unroll
+        for (int w = 0; w < (MODE ? 4 : 1); ++w) xr[k][w] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok && inb) {
             const int c = c0 + q * 4;
             if (MODE == 0) {
                 const int sh = p.a.shift, C = p.a.C;
                 const size_t base = (((size_t)n * (p.H << sh) + (y << sh)) * (p.W << sh) + (x << sh)) * C;
                 if ((C & 3) == 0) {
-                    v = *(const f32x4 *)(p.a.x + base + c);
+                    xr[k][0] = *(const f32x4 *)(p.a.x + base + c);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = (c + k < C) ? p.a.x[base + c + k] : 0.f;
-                }
-                if (p.a.mode != MPNN_ACT_IDENTITY) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float *cc = cA + (c + k) * 3;
-                        v[k] = (c + k < C) ? fmaxf((v[k] - cc[0]) * cc[1] + cc[2], 0.f) : 0.f;
-                    }
+                    for (int j = 0; j < 4; ++j) xr[k][0][j] = (c + j < C) ? p.a.x[base + c + j] : 0.f;
                 }
             } else {
                 const int W2 = p.W * 2;
                 const float *s = p.v + (((size_t)n * (p.H * 2) + 2 * y) * W2 + 2 * x) * p.Cv + c;
-                const f32x4 a0 = *(const f32x4 *)s, a1 = *(const f32x4 *)(s + p.Cv);
-                const f32x4 a2 = *(const f32x4 *)(s + (size_t)W2 * p.Cv);
-                const f32x4 a3 = *(const f32x4 *)(s + (size_t)W2 * p.Cv + p.Cv);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaxf(a0[k], a1[k]), fmaxf(a2[k], a3[k]));
+                xr[k][0] = *(const f32x4 *)s;
+                xr[k][1] = *(const f32x4 *)(s + p.Cv);
+                xr[k][MODE ? 2 : 0] = *(const f32x4 *)(s + (size_t)W2 * p.Cv);
+                xr[k][MODE ? 3 : 0] = *(const f32x4 *)(s + (size_t)W2 * p.Cv + p.Cv);
             }
         }
-        tile[q * PS + (img * HR + hy) * G::R + hx] = v;
+    }
+}
+
+template <int GK, int PS, int MODE>
+__device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[MODE ? 4 : 1], const ConvP &p,
+                                        const float *cA, int n0, int y0, int x0, int c0, int np, int tid) {
+    using X = XItems<GK>;
+#pragma unroll
+    for (int k = 0; k < X::N; ++k) {
+        int q, slot, n, y, x; bool inb;
+        if (!x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb)) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (inb) {
+            if (MODE == 0) {
+                v = xr[k][0];
+                if (p.a.mode != MPNN_ACT_IDENTITY) {
+                    const int c = c0 + q * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float *cc = cA + (c + j) * 3;
+                        v[j] = (c + j < p.a.C) ? fmaxf((v[j] - cc[0]) * cc[1] + cc[2], 0.f) : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = fmaxf(fmaxf(xr[k][0][j], xr[k][1][j]), fmaxf(xr[k][MODE ? 2 : 0][j], xr[k][MODE ? 3 : 0][j]));
+            }
+        }
+        tile[q * PS + slot] = v;
     }
 }
 
 template <int GK, int OT>
-__global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
+__device__ __forceinline__ void load_g(f32x4 *gr, const WgP &p, int n0, int y0, int x0, int co0, int tid) {
+#pragma unroll
+    for (int k = 0; k < OT; ++k) {
+        const int i = tid + k * 256;                   // 64 * OT * 4 items
+        const int q = i % (OT * 4), pi = i / (OT * 4);
+        int img, ty, tx;
+        mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
+        const int n = n0 + img;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.c.n)
+            v = *(const f32x4 *)(p.g + (((size_t)n * p.c.H + y0 + ty) * p.c.W + x0 + tx) * p.c.Cout + co0 + q * 4);
+        gr[k] = v;
+    }
+}
+
+template <int GK, int OT, int PART>
+__device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt, float *cA) {
     using G = Geom<GK>;
     constexpr int PS = WGeom<GK>::PS, R = G::R, HR = G::TH + 2;
     constexpr int GS = OT * 16 + 4;                  // g tile row stride (floats)
-    __shared__ f32x4 tile[4 * PS];
-    __shared__ float gt[64 * GS];
-    __shared__ float cA[128 * 3];
-
+    constexpr int XN = XItems<GK>::N;
     const ConvP &c = p.c;
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably wave-uniform
     const int g = lane >> 4, li = lane & 15;
     const int nchA = (c.a.C + 15) >> 4;
-    const int part = (int)blockIdx.y >= nchA ? 1 : 0;
+    constexpr int part = PART;
     const int ch = part ? (int)blockIdx.y - nchA : (int)blockIdx.y;
     const int C = part ? c.Cv : c.a.C;
     const int co0 = blockIdx.z * OT * 16;
     int np = (C - ch * 16 + 3) >> 2;
     np = np > 4 ? 4 : np;
+    const bool bias_wave = wid == 1 && blockIdx.y == 0;   // slot ti = 2 of wave 1 is tap 9: unused
 
     if (part == 0 && c.a.mode != MPNN_ACT_IDENTITY) {
         for (int cc = tid; cc < c.a.C; cc += 256) {
             const BnC k = bn_coef(c.a, cc);
             cA[cc * 3] = k.m; cA[cc * 3 + 1] = k.gamma * k.rstd; cA[cc * 3 + 2] = k.beta;
         }
+        __syncthreads();
     }
 
     f32x4 acc[3][OT];
@@ -108,60 +174,71 @@ __global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
     for (int ti = 0; ti < 3; ++ti)
 #pragma unroll
         for (int nt = 0; nt < OT; ++nt) acc[ti][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dbacc = 0.f;
     const float *tf = (const float *)tile;
     const int a_lane = (li >> 2) * PS * 4 + (li & 3);      // plane + component of channel li
+    const float one_hot = li == 0 ? 1.f : 0.f;
+    // Tap slots of this wave: {wid, wid+4, wid+8}; slot 2 of waves 1-3 has no tap (9..11): it runs a
+    // clamped duplicate whose result is dropped (wave 1 / chunk 0 uses it for the bias gradient), so
+    // the hot loop is branch-free and every wave issues the same 3 MFMAs per step.
+    int tap_off[3];
+#pragma unroll
+    for (int ti = 0; ti < 3; ++ti) {
+        const int tap = min(wid + 4 * ti, 8);
+        tap_off[ti] = (tap / 3) * R + (tap % 3);
+    }
 
-    for (int t = blockIdx.x; t < p.n_tiles; t += gridDim.x) {
-        int n0, y0, x0;
+    f32x4 xr[XN][PART ? 4 : 1], gr[OT];
+    int t = blockIdx.x;
+    int n0, y0, x0, cn0 = 0, cy0 = 0, cx0 = 0;
+    if (t < p.n_tiles) {
         tile_origin<GK>(c, t, n0, y0, x0);
-        __syncthreads();
-        if (part == 0) stage_chunk_ps<GK, PS, 0>(tile, c, cA, n0, y0, x0, ch * 16, np, tid);
-        else           stage_chunk_ps<GK, PS, 1>(tile, c, cA, n0, y0, x0, ch * 16, np, tid);
-        for (int i = tid; i < 64 * OT * 4; i += 256) {
-            const int q = i % (OT * 4), pi = i / (OT * 4);
-            int img, ty, tx;
-            mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
-            const int n = n0 + img;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < c.n)
-                v = *(const f32x4 *)(p.g + (((size_t)n * c.H + y0 + ty) * c.W + x0 + tx) * c.Cout + co0 + q * 4);
-            *(f32x4 *)(gt + pi * GS + q * 4) = v;
+        load_x<GK, PART>(xr, c, n0, y0, x0, ch * 16, np, tid);
+        load_g<GK, OT>(gr, p, n0, y0, x0, co0, tid);
+        cn0 = n0; cy0 = y0; cx0 = x0;
+    }
+    for (; t < p.n_tiles; t += gridDim.x) {
+        __syncthreads();                               // previous tile's LDS reads are done
+        store_x<GK, PS, PART>(tile, xr, c, cA, cn0, cy0, cx0, ch * 16, np, tid);
+#pragma unroll
+        for (int k = 0; k < OT; ++k) {
+            const int i = tid + k * 256;
+            *(f32x4 *)(gt + (i / (OT * 4)) * GS + (i % (OT * 4)) * 4) = gr[k];
         }
         __syncthreads();
-        if (blockIdx.y == 0 && tid < OT * 16) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int pi = 0; pi < 64; ++pi) s += gt[pi * GS + tid];
-            dbacc += s;
+        const int tn = t + gridDim.x;
+        if (tn < p.n_tiles) {                          // next tile's loads fly under the MFMAs
+            tile_origin<GK>(c, tn, n0, y0, x0);
+            load_x<GK, PART>(xr, c, n0, y0, x0, ch * 16, np, tid);
+            load_g<GK, OT>(gr, p, n0, y0, x0, co0, tid);
+            cn0 = n0; cy0 = y0; cx0 = x0;
         }
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
+            float bq[4][OT], aq[4][3];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int img, ty, tx;
                 mtile_pix<GK>(kc, 4 * g + j, img, ty, tx);
                 const int slot = (img * HR + ty) * R + tx;
-                float b[OT];
 #pragma unroll
-                for (int nt = 0; nt < OT; ++nt) b[nt] = gt[(kc * 16 + 4 * g + j) * GS + nt * 16 + li];
+                for (int nt = 0; nt < OT; ++nt) bq[j][nt] = gt[(kc * 16 + 4 * g + j) * GS + nt * 16 + li];
 #pragma unroll
-                for (int ti = 0; ti < 3; ++ti) {
-                    const int tap = wid + 4 * ti;
-                    if (tap < 9) {
-                        const int dy = tap / 3, dx = tap - dy * 3;
-                        const float a = tf[(slot + dy * R + dx) * 4 + a_lane];
-#pragma unroll
-                        for (int nt = 0; nt < OT; ++nt)
-                            acc[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[ti][nt], 0, 0, 0);
-                    }
-                }
+                for (int ti = 0; ti < 3; ++ti) aq[j][ti] = tf[(slot + tap_off[ti]) * 4 + a_lane];
+                if (bias_wave) aq[j][2] = one_hot;
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+                    for (int nt = 0; nt < OT; ++nt)
+                        acc[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j][ti], bq[j][nt], acc[ti][nt], 0, 0, 0);
         }
     }
 
     // D layout: col = li (cout), row = g*4 + r (input channel of the chunk).
-    float *dw = part ? p.dwv : p.dwa;
+    const size_t soff = (size_t)blockIdx.x * p.split_stride;
+    float *dw = (part ? p.dwv : p.dwa) + soff;
 #pragma unroll
     for (int ti = 0; ti < 3; ++ti) {
         const int tap = wid + 4 * ti;
@@ -172,17 +249,29 @@ __global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
             if (cin >= C) continue;
 #pragma unroll
             for (int nt = 0; nt < OT; ++nt)
-                atomicAdd(dw + ((size_t)tap * C + cin) * c.Cout + co0 + nt * 16 + li, acc[ti][nt][r]);
+                dw[((size_t)tap * C + cin) * c.Cout + co0 + nt * 16 + li] = acc[ti][nt][r];
         }
     }
-    if (blockIdx.y == 0 && tid < OT * 16) atomicAdd(p.db + co0 + tid, dbacc);
+    if (bias_wave && g == 0) {
+#pragma unroll
+        for (int nt = 0; nt < OT; ++nt) p.db[soff + co0 + nt * 16 + li] = acc[2][nt][0];
+    }
+}
+
+template <int GK, int OT>
+__global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
+    constexpr int PS = WGeom<GK>::PS, GS = OT * 16 + 4;
+    __shared__ f32x4 tile[4 * PS];
+    __shared__ float gt[64 * GS];
+    __shared__ float cA[128 * 3];
+    if ((int)blockIdx.y >= ((p.c.a.C + 15) >> 4)) wgrad_body<GK, OT, 1>(p, tile, gt, cA);
+    else                                           wgrad_body<GK, OT, 0>(p, tile, gt, cA);
 }
 
 template <int GK>
-static int wgrad_launch(const WgP &p, int n_split, hipStream_t st) {
+static int wgrad_launch(const WgP &p, int split, hipStream_t st) {
     const ConvP &c = p.c;
     const int nch = ((c.a.C + 15) >> 4) + (c.v ? ((c.Cv + 15) >> 4) : 0);
-    int split = n_split < 1 ? 1 : (n_split > p.n_tiles ? p.n_tiles : n_split);
     dim3 block(256);
     if (c.Cout % 64 == 0) {
         hipLaunchKernelGGL((wgrad_k<GK, 4>), dim3(split, nch, c.Cout / 64), block, 0, st, p);
@@ -195,22 +284,68 @@ static int wgrad_launch(const WgP &p, int n_split, hipStream_t st) {
     return 0;
 }
 
+extern "C" int mpnn_wgrad_tiles(int n, int H, int W) {
+    if (W >= 16 && (W % 16) == 0 && (H % 4) == 0) return conv_grid_x<0>(n, H, W);
+    if (W == 8 && H == 8) return conv_grid_x<1>(n, 8, 8);
+    if (W == 4 && H == 4) return conv_grid_x<2>(n, 4, 4);
+    return MPNN_E_SHAPE;
+}
+
 extern "C" int mpnn_msconv_wgrad(const mpnn_wgrad_args *a, void *stream) {
     if (!a || !a->a.x || !a->g || !a->dwa || !a->db) return MPNN_E_ARG;
     if (a->v && !a->dwv) return MPNN_E_ARG;
     if (a->n <= 0) return 0;
     if (a->a.C > 128 || a->Cv > 128 || (a->Cv & 3)) return MPNN_E_SHAPE;
     if (a->a.C > 4 && (a->a.C & 3)) return MPNN_E_SHAPE;
+    const int tiles = mpnn_wgrad_tiles(a->n, a->H, a->W);
+    if (tiles < 0) return tiles;
+    const int split = a->n_split < 1 ? 1 : (a->n_split > tiles ? tiles : a->n_split);
+    if (split > 1 && a->split_stride <= 0) return MPNN_E_ARG;
     WgP p = {};
     p.c.a = a->a;  p.c.v = a->v;  p.c.Cv = a->v ? a->Cv : 0;
     p.c.n = a->n;  p.c.H = a->H;  p.c.W = a->W;  p.c.Cout = a->Cout;
     p.g = a->g;  p.dwa = a->dwa;  p.dwv = a->dwv;  p.db = a->db;
+    p.split_stride = a->split_stride;  p.n_tiles = tiles;
     hipStream_t st = (hipStream_t)stream;
-    if (a->W >= 16 && (a->W % 16) == 0 && (a->H % 4) == 0) {
-        p.n_tiles = conv_grid_x<0>(a->n, a->H, a->W);
-        return wgrad_launch<0>(p, a->n_split, st);
+    if (a->W >= 16) return wgrad_launch<0>(p, split, st);
+    if (a->W == 8) return wgrad_launch<1>(p, split, st);
+    return wgrad_launch<2>(p, split, st);
+}
+
+// ---------------------------------------------------------------------------
+// mpnn_slab_reduce: dst[i] = sum_{s < n_split} src[s * stride + i], fixed order.
+// table: 6 ints per work item: src_off, dst_off, count (<= 1024), n_split, stride, -.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_reduce_k(const float *__restrict__ slabs, float *__restrict__ grads,
+                                                     const int *__restrict__ table) {
+    const int *t = table + blockIdx.x * 6;
+    const int src = t[0], dst = t[1], cnt = t[2], ns = t[3], stride = t[4];
+    const int i = threadIdx.x * 4;
+    if (i >= cnt) return;
+    if (i + 4 <= cnt && ((src + i) & 3) == 0 && (stride & 3) == 0 && ((dst + i) & 3) == 0) {
+        const float *base = slabs + src + i;
+        f32x4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= ns; s += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += *(const f32x4 *)(base + (size_t)(s + u) * stride);
+        }
+        for (; s < ns; ++s) a[0] += *(const f32x4 *)(base + (size_t)s * stride);
+        *(f32x4 *)(grads + dst + i) = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    } else {
+        for (int j = i; j < min(i + 4, cnt); ++j) {
+            float acc = 0.f;
+            for (int s = 0; s < ns; ++s) acc += slabs[src + (size_t)s * stride + j];
+            grads[dst + j] = acc;
+        }
     }
-    if (a->W == 8 && a->H == 8) { p.n_tiles = conv_grid_x<1>(a->n, 8, 8); return wgrad_launch<1>(p, a->n_split, st); }
-    if (a->W == 4 && a->H == 4) { p.n_tiles = conv_grid_x<2>(a->n, 4, 4); return wgrad_launch<2>(p, a->n_split, st); }
-    return MPNN_E_SHAPE;
+}
+
+extern "C" int mpnn_slab_reduce(const float *slabs, float *grads, const int *table, int n_items, void *stream) {
+    if (n_items <= 0) return 0;
+    hipLaunchKernelGGL(slab_reduce_k, dim3(n_items), dim3(256), 0, (hipStream_t)stream, slabs, grads, table);
+    MPNN_LAUNCH_CHECK();
+    return 0;
 }

@@ -13,6 +13,7 @@ ACT_IDENTITY, ACT_BN_BATCH, ACT_BN_MOVING = 0, 1, 2
 NET_SR, NET_ACTOR, NET_CRITIC = 0, 1, 2
 HYP_LR, HYP_MU, HYP_TAU, HYP_EPS, HYP_KCPT, HYP_KDEC, HYP_KCRE, HYP_ARTR, HYP_N = 0, 1, 2, 3, 4, 5, 6, 7, 16
 MAX_NODES, MAX_SINKS = 128, 4
+BN_SLOTS = 16                  # MPNN_BN_SLOTS
 
 P = C.c_void_p
 
@@ -43,7 +44,7 @@ class DgradVertArgs(C.Structure):
 
 class WgradArgs(C.Structure):
     _fields_ = [('a', Act), ('v', P), ('Cv', C.c_int), ('g', P), ('dwa', P), ('dwv', P), ('db', P),
-                ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int), ('n_split', C.c_int)]
+                ('split_stride', C.c_long), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int), ('n_split', C.c_int)]
 
 
 class LinFwdArgs(C.Structure):
@@ -88,6 +89,8 @@ _SIGS = {
     'mpnn_msconv_dgrad_horz': [C.POINTER(DgradHorzArgs), P],
     'mpnn_msconv_dgrad_vert': [C.POINTER(DgradVertArgs), P],
     'mpnn_msconv_wgrad': [C.POINTER(WgradArgs), P],
+    'mpnn_wgrad_tiles': [C.c_int, C.c_int, C.c_int],
+    'mpnn_slab_reduce': [P, P, P, C.c_int, P],
     'mpnn_lin_fwd': [P, C.c_int, C.c_int, P],
     'mpnn_lin_bwd': [P, C.c_int, C.c_int, C.c_int, P],
     'mpnn_exit_tail_fwd': [P, C.c_int, P],

@@ -269,7 +269,7 @@ class Engine:
                 b.sum_off.append(doff)
                 tab += [doff, bn.m_avg.offset, bn.v_avg.offset, b.C[i], b.H[i] * b.W[i],
                         bn.γ.offset if b.has_dz[i] else -1, bn.β.offset, 0]
-                doff += 2 * b.C[i]
+                doff += 2 * b.C[i] * _hip.BN_SLOTS
         self.dsum = torch.zeros(max(doff, 1), dtype=torch.float64, device=dev)
         self.dred = torch.zeros(max(doff, 1), dtype=torch.float64, device=dev)
         self.n_bn = len(tab) // 8
@@ -373,7 +373,9 @@ class Engine:
         tiles = n * (H // 16) * (H // 4) if H >= 16 else (n if H == 8 else (n + 3) // 4)
         nch = (b.Cin[i] + 15) // 16 + ((b.C[i - 1] + 15) // 16 if i > 0 else 0)
         groups = max(1, b.C[i] // 64) if b.C[i] % 64 == 0 else (b.C[i] // 32 if b.C[i] % 32 == 0 else b.C[i] // 16)
-        want = max(1, 512 // (nch * groups))
+        want = max(1, 384 // (nch * groups))
+        w_bytes = 4 * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
+        want = min(want, max(1, (3 << 20) // w_bytes))          # keep a layer's slab under ~3 MB
         return max(1, min(tiles, want))
 
     def program(self, mode, n):
@@ -504,6 +506,7 @@ class Engine:
             return prog
 
         # ---- backward ----
+        slab_plan = dict(size=0, table=[], ptrs=[])
         if n_exit:
             bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit))
             bwd.append(call(lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
@@ -535,14 +538,33 @@ class Engine:
             for i in range(b.L):
                 a = _hip.WgradArgs()
                 a.a = self._act_of_input(b, i, n, act_mode)
+                pa = getattr(cp, 'w_horz_%i' % i)
+                pv = getattr(cp, 'w_vert_%i' % (i - 1)) if i > 0 else None
+                pb = getattr(cp, 'b_%i' % i)
                 if i > 0:
                     a.v, a.Cv = b.s[i - 1].data_ptr(), b.C[i - 1]
-                    a.dwv = getattr(cp, 'w_vert_%i' % (i - 1)).grad.data_ptr()
                 a.g = b.dzg[i].data_ptr()
-                a.dwa = getattr(cp, 'w_horz_%i' % i).grad.data_ptr()
-                a.db = getattr(cp, 'b_%i' % i).grad.data_ptr()
                 a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
-                a.n_split = self._wsplit(b, i, n)
+                split = self._wsplit(b, i, n)
+                a.n_split = split
+                if split == 1:
+                    a.dwa, a.db = pa.grad.data_ptr(), pb.grad.data_ptr()
+                    a.dwv = pv.grad.data_ptr() if pv is not None else None
+                    a.split_stride = 0
+                else:
+                    sizes = [pa.size, pv.size if pv is not None else 0, pb.size]
+                    stride = (sum(sizes) + 3) // 4 * 4
+                    base = slab_plan['size']
+                    slab_plan['size'] += split * stride
+                    off = base
+                    for prm, sz in zip((pa, pv, pb), sizes):
+                        if prm is None:
+                            continue
+                        for k in range(0, sz, 1024):
+                            slab_plan['table'] += [off + k, prm.offset + k, min(1024, sz - k), split, stride, 0]
+                        slab_plan['ptrs'].append((a, {id(pa): 'dwa', id(pb): 'db'}.get(id(prm), 'dwv'), off))
+                        off += sz
+                    a.split_stride = stride
                 keep.append(a)
                 fl = 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
                 bwd.append(call(lib.mpnn_msconv_wgrad, 'wgrad', C.byref(a), flops=fl,
@@ -564,6 +586,14 @@ class Engine:
                     bwd.append(call(lib.mpnn_msconv_dgrad_horz, 'dgrad_horz', C.byref(a),
                                     flops=2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * pb.C[j],
                                     tag='h%d %d->%d' % (b.H[i], b.C[i], pb.C[j])))
+        if slab_plan['size']:
+            slab = torch.empty(slab_plan['size'], device=self.dev)
+            for a, field, off in slab_plan['ptrs']:
+                setattr(a, field, slab[off:].data_ptr())
+            tab = torch.tensor(slab_plan['table'], dtype=torch.int32, device=self.dev)
+            keep += [slab, tab]
+            bwd.append(call(lib.mpnn_slab_reduce, 'slab_reduce', slab.data_ptr(), self.G.data_ptr(),
+                            tab.data_ptr(), len(slab_plan['table']) // 6))
         bwd.append(call(lib.mpnn_bn_finalize, 'bn_finalize', self.dsum.data_ptr(), self.dred.data_ptr(),
                         self.S.data_ptr(), self.G.data_ptr(), self.bn_table.data_ptr(), self.n_bn,
                         self.bn_decay, n))

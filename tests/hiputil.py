@@ -42,11 +42,25 @@ def pack_weights(ws, want_bwd=True):
     return ([packs[a:a + n] for a, n, _, _ in spans], [packs[b:b + m] if m else None for _, _, b, m in spans])
 
 
+def slots(v):
+    """A statistics vector [2C] spread (unevenly, on purpose) over the [SLOTS][2C] layout."""
+    v = np.asarray(v, np.float64)
+    out = np.zeros((_hip.BN_SLOTS, v.size))
+    w = np.random.default_rng(7).random(_hip.BN_SLOTS); w /= w.sum()
+    out[:] = w[:, None] * v[None, :]
+    out[0] += v - out.sum(0)
+    return out
+
+
+def unslot(t, c2):
+    return t.cpu().numpy().reshape(_hip.BN_SLOTS, c2).sum(0)
+
+
 def bn_dict(x, gamma, beta, m_avg=None, v_avg=None, eps=1e-6):
     """Device BatchNorm context for pre-BN array x (statistics over all leading dims)."""
     c = x.shape[-1]
     x64 = np.asarray(x, np.float64).reshape(-1, c)
-    sums = np.concatenate([x64.sum(0), (x64 ** 2).sum(0)])
+    sums = slots(np.concatenate([x64.sum(0), (x64 ** 2).sum(0)]))
     d = dict(sum=dev(sums, torch.float64), gamma=dev(gamma), beta=dev(beta),
              m_avg=dev(np.zeros(c) if m_avg is None else m_avg),
              v_avg=dev(np.ones(c) if v_avg is None else v_avg), eps=eps)
@@ -62,7 +76,7 @@ def conv_fwd(x, wh, b, v=None, wv=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0
     fw, _ = pack_weights([wh] + ([wv] if wv is not None else []), want_bwd=False)
     xd, vd, bd = dev(x), dev(v), dev(b)
     out = torch.empty((n, H, W, co), device=DEV)
-    osum = torch.zeros(2 * co, device=DEV, dtype=torch.float64)
+    osum = torch.zeros(_hip.BN_SLOTS * 2 * co, device=DEV, dtype=torch.float64)
     a = _hip.ConvFwdArgs()
     a.a = _hip.act(xd, x.shape[3], mode, shift, bn, bn_cnt)
     a.v = _hip.ptr(vd); a.Cv = v.shape[3] if v is not None else 0
@@ -71,7 +85,7 @@ def conv_fwd(x, wh, b, v=None, wv=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0
     a.n, a.H, a.W, a.Cout = n, H, W, co
     _hip.check(lib.mpnn_msconv_fwd(C.byref(a), stream()), 'msconv_fwd')
     torch.cuda.synchronize()
-    return out.cpu().numpy(), osum.cpu().numpy()
+    return out.cpu().numpy(), unslot(osum, 2 * co)
 
 
 def bn_ctx(s_dev, C_, bn, cnt, mode=_hip.ACT_BN_BATCH, red=None):
@@ -97,13 +111,13 @@ def dgrad_horz(g, w, s_prev=None, bn=None, cnt=1, extra=None):
     keep = []
     if s_prev is not None:
         sd = dev(s_prev)
-        red = torch.zeros(2 * ci, device=DEV, dtype=torch.float64)
+        red = torch.zeros(_hip.BN_SLOTS * 2 * ci, device=DEV, dtype=torch.float64)
         ctx = bn_ctx(sd, ci, bn, cnt)
         keep += [sd, ctx]
         a.prev = C.pointer(ctx); a.red_out = red.data_ptr()
     _hip.check(lib.mpnn_msconv_dgrad_horz(C.byref(a), stream()), 'dgrad_horz')
     torch.cuda.synchronize()
-    return out.cpu().numpy(), (None if red is None else red.cpu().numpy())
+    return out.cpu().numpy(), (None if red is None else unslot(red, 2 * ci))
 
 
 def dgrad_vert(g, w, s_fine, bn, cnt, dz_fine=None, red=None):
@@ -114,7 +128,7 @@ def dgrad_vert(g, w, s_fine, bn, cnt, dz_fine=None, red=None):
     _, bw = pack_weights([w])
     gd, sd = dev(g), dev(s_fine)
     buf = dev(dz_fine) if dz_fine is not None else torch.full((n, 2 * H, 2 * W, cf), 7.0, device=DEV)
-    redd = dev(red, torch.float64)
+    redd = dev(slots(red), torch.float64) if red is not None else None
     ctx = bn_ctx(sd, cf, bn, cnt, red=redd)
     a = _hip.DgradVertArgs()
     a.g = gd.data_ptr(); a.Cg = cg; a.w_pack = bw[0].data_ptr(); a.fine = C.pointer(ctx)
@@ -126,22 +140,42 @@ def dgrad_vert(g, w, s_fine, bn, cnt, dz_fine=None, red=None):
 
 
 def wgrad(x, g, v=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0, bn_cnt=1, n_split=7):
+    """Partial sums into a slab + mpnn_slab_reduce (n_split > 1) or straight into the gradients."""
     lib = _hip.load()
     n = x.shape[0]
     H, W = x.shape[1] >> shift, x.shape[2] >> shift
     ca, co = x.shape[3], g.shape[3]
+    cv = v.shape[3] if v is not None else 0
     xd, gd, vd = dev(x), dev(g), dev(v)
-    dwa = torch.zeros((3, 3, ca, co), device=DEV)
-    dwv = torch.zeros((3, 3, v.shape[3], co), device=DEV) if v is not None else None
-    db = torch.zeros(co, device=DEV)
+    sizes = [9 * ca * co, 9 * cv * co, co]
+    offs = [0, sizes[0], sizes[0] + sizes[1]]
+    total = sum(sizes)
+    stride = (total + 3) // 4 * 4
+    n_split = max(1, min(n_split, lib.mpnn_wgrad_tiles(n, H, W)))
+    grads = torch.full((total,), 3.0, device=DEV)          # poison: every element must be written
+    slab = grads if n_split == 1 else torch.full((n_split * stride,), 5.0, device=DEV)
     a = _hip.WgradArgs()
     a.a = _hip.act(xd, ca, mode, shift, bn, bn_cnt)
-    a.v = _hip.ptr(vd); a.Cv = v.shape[3] if v is not None else 0
-    a.g = gd.data_ptr(); a.dwa = dwa.data_ptr(); a.dwv = _hip.ptr(dwv); a.db = db.data_ptr()
+    a.v = _hip.ptr(vd); a.Cv = cv
+    a.g = gd.data_ptr()
+    a.dwa = slab[offs[0]:].data_ptr(); a.dwv = slab[offs[1]:].data_ptr() if cv else None
+    a.db = slab[offs[2]:].data_ptr()
+    a.split_stride = stride if n_split > 1 else 0
     a.n, a.H, a.W, a.Cout, a.n_split = n, H, W, co, n_split
     _hip.check(lib.mpnn_msconv_wgrad(C.byref(a), stream()), 'wgrad')
+    if n_split > 1:
+        tab = []
+        for o, sz in zip(offs, sizes):
+            for k in range(0, sz, 1024):
+                tab += [o + k, o + k, min(1024, sz - k), n_split, stride, 0]
+        t = dev(np.array(tab, np.int32), torch.int32)
+        _hip.check(lib.mpnn_slab_reduce(slab.data_ptr(), grads.data_ptr(), t.data_ptr(), len(tab) // 6, stream()),
+                   'slab_reduce')
     torch.cuda.synchronize()
-    return dwa.cpu().numpy(), (None if dwv is None else dwv.cpu().numpy()), db.cpu().numpy()
+    out = grads.cpu().numpy()
+    dwa = out[:sizes[0]].reshape(3, 3, ca, co)
+    dwv = out[offs[1]:offs[2]].reshape(3, 3, cv, co) if cv else None
+    return dwa, dwv, out[offs[2]:]
 
 
 def bn_bwd_reduce(dy, s, bn, cnt):
@@ -149,18 +183,18 @@ def bn_bwd_reduce(dy, s, bn, cnt):
     c = s.shape[-1]
     dyd, sd = dev(dy), dev(s)
     dz = torch.empty_like(dyd)
-    red = torch.zeros(2 * c, device=DEV, dtype=torch.float64)
+    red = torch.zeros(_hip.BN_SLOTS * 2 * c, device=DEV, dtype=torch.float64)
     ctx = bn_ctx(sd, c, bn, cnt)
     _hip.check(lib.mpnn_bn_bwd_reduce(dyd.data_ptr(), C.byref(ctx), dz.data_ptr(), red.data_ptr(),
                                       dy.size // c, stream()), 'bn_bwd_reduce')
     torch.cuda.synchronize()
-    return dz.cpu().numpy(), red.cpu().numpy()
+    return dz.cpu().numpy(), unslot(red, 2 * c)
 
 
 def bn_bwd_apply(dz, s, bn, cnt, red):
     lib = _hip.load()
     c = s.shape[-1]
-    dzd, sd, redd = dev(dz), dev(s), dev(red, torch.float64)
+    dzd, sd, redd = dev(dz), dev(s), dev(slots(red), torch.float64)
     ctx = bn_ctx(sd, c, bn, cnt, red=redd)
     _hip.check(lib.mpnn_bn_bwd_apply(dzd.data_ptr(), C.byref(ctx), dz.size // c, stream()), 'bn_bwd_apply')
     torch.cuda.synchronize()

@@ -152,7 +152,7 @@ def test_wgrad(shape):
         dwa, dwv, db = U.wgrad(x, g, v, bn=bn, mode=_hip.ACT_BN_BATCH, bn_cnt=cnt)
         bnp = (gamma, beta)
     else:
-        dwa, dwv, db = U.wgrad(x, g, v, shift=shift)
+        dwa, dwv, db = U.wgrad(x, g, v, shift=shift, n_split=1)      # direct write, no slab
     _, xs = ref_fwd(x, v, wh, wv, b, shift, bn=bnp)
     _, dwa_ref = O.conv_same_bwd(xs, wh, g)
     close(dwa, dwa_ref, 1e-4)
