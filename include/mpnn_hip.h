@@ -188,7 +188,8 @@ int mpnn_lin_bwd(const mpnn_lin_bwd_args *dev_table, int count, int n_max, int k
  * Router: BN -> ReLU -> LinTrans(R) -> BN -> ReLU -> LinTrans(n_sinks)
  * (arch_and_hypers.py:47-49; BatchNorm over the batch, layer_types.py:219-239).
  * One workgroup per exit owns the whole batch (batch statistics need every
- * sample).  Limits: n_cls <= 32, R <= 16, n_sinks <= 8. */
+ * sample; the batch is held in LDS).  Limits: n <= 128 per launch, n_cls <= 16,
+ * R <= 16, n_sinks <= 4 (MPNN_E_SHAPE beyond). */
 typedef struct {
     /* head (z == NULL: no head at this exit) */
     const float *z;  const float *y;  int n_cls;  float eps_ce;
@@ -205,7 +206,8 @@ typedef struct {
     int mode;                                         /* MPNN_ACT_BN_BATCH / _MOVING */
     int n;
 } mpnn_exit_tail_args;
-int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int count, void *stream);
+int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int count, int n_max,
+                       void *stream);
 
 typedef struct {
     mpnn_exit_tail_args f;
@@ -215,7 +217,8 @@ typedef struct {
     float *dh1;                          /* [n,R] dL/dh1                           */
     float *dg1, *db1, *dw2, *dbias2, *dg2, *db2, *dw3, *dbias3;   /* written      */
 } mpnn_exit_tail_bwd_args;
-int mpnn_exit_tail_bwd(const mpnn_exit_tail_bwd_args *dev_table, int count, void *stream);
+int mpnn_exit_tail_bwd(const mpnn_exit_tail_bwd_args *dev_table, int count, int n_max,
+                       void *stream);
 
 /* ---- the router: routing probabilities, costs and their gradients ----------
  * Replaces ActorNet._route/_route_sinks_dyn + cost assembly

@@ -19,49 +19,112 @@
 //   dL/dc_err(l) = p_tr(l) / n
 // Critic: every cost is weighted by stop_gradient(p_tr), so only c_cre
 // reaches the router: dL/dr_i = p_tr * 2 * k_cre * (r_i + target_i) / n.
+//
+// Organisation (this launch is on the step's critical path): all 256 threads
+// preload the node table and every per-sample input into LDS in one burst;
+// then one wave walks the tree top-down (p_tr, p_ev) and bottom-up, each node
+// PUSHING its value into its parent's accumulator (no child searches); all
+// per-thread arrays have compile-time bounds so nothing lives in scratch.
 #include "common.h"
 
-#define RB 64     // threads (samples) per workgroup
+#define RB 64     // samples per workgroup
+#define MSK MPNN_MAX_SINKS
 
-__global__ __launch_bounds__(RB) void route_k(const mpnn_route_args a) {
-    __shared__ float P[MPNN_MAX_NODES * RB];      // p_tr per node
-    __shared__ float V[MPNN_MAX_NODES * RB];      // actor: V ; critic: c_ev
-    __shared__ float O[MPNN_MAX_NODES * RB];      // critic: c_opt
+__global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n = a.n, NN = a.n_nodes, MS = a.max_sinks;
+    float *P = lds;                               // p_tr per node            [NN][RB]
+    float *V = P + NN * RB;                       // actor: V ; critic: c_ev  [NN][RB]
+    float *O = V + NN * RB;                       // critic: c_opt            [NN][RB]
+    float *RIN = O + NN * RB;                     // router outputs           [n_switches*MS][RB]
+    float *CE = RIN + a.n_switches * MS * RB;     // leaf c_err               [n_leaves][RB]
+    float *DC = CE + a.n_leaves * RB;             // leaf delta_cor           [n_leaves][RB]
+    int *ND = (int *)(DC + a.n_leaves * RB);      // node table               [NN][8]
+    float *OPS = (float *)(ND + NN * 8);          // node ops                 [NN]
+    {
+        const int s0 = blockIdx.x * RB;
+        const int rows_r = a.n_switches * MS, rows = rows_r + 2 * a.n_leaves;
+        for (int i = threadIdx.x; i < rows * RB; i += 256) {
+            const int row = i / RB, t = i - row * RB, s = s0 + t;
+            float v = 0.f;
+            if (s < n) {
+                if (row < rows_r) v = a.r[((size_t)(row / MS) * n + s) * MS + (row % MS)];
+                else if (row < rows_r + a.n_leaves) v = a.c_err[(size_t)(row - rows_r) * n + s];
+                else v = a.d_cor[(size_t)(row - rows_r - a.n_leaves) * n + s];
+            }
+            RIN[i] = v;                            // RIN, CE, DC are contiguous
+        }
+        for (int i = threadIdx.x; i < NN * 8; i += 256) ND[i] = a.nodes[i];
+        for (int i = threadIdx.x; i < NN; i += 256) OPS[i] = a.node_ops[i];
+    }
+    __syncthreads();
+    if (threadIdx.x >= RB) return;
     const int t = threadIdx.x;
     const int s = blockIdx.x * RB + t;
-    const bool live = s < a.n;
-    const int n = a.n, NN = a.n_nodes, MS = a.max_sinks;
+    const bool live = s < n;
     const float inv_n = 1.f / (float)a.n_total;
     const float tau = a.hyp[MPNN_HYP_TAU], eps = a.hyp[MPNN_HYP_EPS];
     const float k_cpt = a.k_cpt_vec ? (live ? a.k_cpt_vec[s] : 0.f) : a.hyp[MPNN_HYP_KCPT];
     const float k_dec = a.hyp[MPNN_HYP_KDEC], k_cre = a.hyp[MPNN_HYP_KCRE];
-    const float root_leaves = (float)a.nodes[5];
-    const bool dyn = a.net_type != MPNN_NET_SR;
+    const float inv_tau = 1.f / tau;
+    const float eps_unit = eps / (float)ND[5];    // eps / n_leaves(root)
+    const int type = a.net_type;
+    const bool dyn = type != MPNN_NET_SR;
     float l_err = 0.f, l_cpt = 0.f, l_aux = 0.f;
 
-    // ---- top-down: p_tr, p_ev (DFS preorder: parents first) ----
+    // softmax(r / tau) and arg-max (first index on ties) of switch sw for this sample
+    auto soft = [&](int sw, int ns, float *sm, int &arg) {
+        const float *r = RIN + (sw * MS) * RB + t;
+        float mx = r[0];
+        arg = 0;
+#pragma unroll
+        for (int i = 1; i < MSK; ++i)
+            if (i < ns) { if (r[i * RB] > r[arg * RB]) arg = i; mx = fmaxf(mx, r[i * RB]); }
+        float den = 0.f;
+#pragma unroll
+        for (int i = 0; i < MSK; ++i) { sm[i] = i < ns ? expf((r[i * RB] - mx) * inv_tau) : 0.f; den += sm[i]; }
+        const float inv = 1.f / den;
+#pragma unroll
+        for (int i = 0; i < MSK; ++i) sm[i] *= inv;
+    };
+
+    // ---- top-down: p_tr, p_ev (DFS preorder: parents first); own cost terms ----
+    float pev_par = 1.f;
     for (int j = 0; j < NN; ++j) {
-        const int *nd = a.nodes + j * 8;
-        const int par = nd[0], si = nd[1];
+        const int *nd = ND + j * 8;
+        const int par = nd[0], si = nd[1], leaf = nd[4];
         float ptr = 1.f, pev = 1.f;
-        if (par >= 0 && live) {
-            const int *pn = a.nodes + par * 8;
+        if (par >= 0) {
+            const int *pn = ND + par * 8;
             const int psw = pn[3], pns = pn[2];
-            const float pp = P[par * RB + t], ppe = a.p_ev[(size_t)par * n + s];
+            const float pp = P[par * RB + t], ppe = O[par * RB + t];   // O doubles as p_ev storage top-down
             if (dyn && psw >= 0 && pns >= 2) {
-                const float *r = a.r + ((size_t)psw * n + s) * MS;
-                float mx = r[0]; int arg = 0;
-                for (int i = 1; i < pns; ++i) { if (r[i] > r[arg]) arg = i; mx = fmaxf(mx, r[i]); }
-                float den = 0.f, num = 0.f;
-                for (int i = 0; i < pns; ++i) { const float e = expf((r[i] - mx) / tau); den += e; if (i == si) num = e; }
-                const float eps_p = eps * (float)pn[5] / root_leaves, eps_c = eps * (float)nd[5] / root_leaves;
-                ptr = (pp - eps_p) * (num / den) + eps_c;
+                float sm[MSK]; int arg;
+                soft(psw, pns, sm, arg);
+                float mine = 0.f;
+#pragma unroll
+                for (int i = 0; i < MSK; ++i) if (i == si) mine = sm[i];
+                ptr = (pp - eps_unit * (float)pn[5]) * mine + eps_unit * (float)nd[5];
                 pev = arg == si ? ppe : 0.f;
             } else { ptr = pp; pev = ppe; }
         }
         P[j * RB + t] = ptr;
+        O[j * RB + t] = pev;
         if (live) { a.p_tr[(size_t)j * n + s] = ptr; a.p_ev[(size_t)j * n + s] = pev; }
+        // own terms of the bottom-up recursions
+        const float cerr = leaf >= 0 ? CE[leaf * RB + t] : 0.f;
+        const float dcor = leaf >= 0 ? DC[leaf * RB + t] : 1.f;
+        const float ops = OPS[j];
+        const float w = type == MPNN_NET_SR ? 1.f : ptr;
+        if (leaf >= 0 && live && a.w_cerr) a.w_cerr[(size_t)leaf * n + s] = w * inv_n;
+        l_err += w * cerr;
+        if (type == MPNN_NET_ACTOR) { l_cpt += ptr * k_cpt * ops; V[j * RB + t] = cerr + k_cpt * ops; }
+        else if (type == MPNN_NET_CRITIC) {
+            const float ce = a.use_cls_err ? (leaf >= 0 ? 1.f - dcor : 0.f) : cerr;
+            V[j * RB + t] = ce + k_cpt * ops;      // c_ev accumulator (children pushed below)
+        }
     }
+    (void)pev_par;
 
     // ---- node statistics for TALR: sum p_tr, sum p_tr^2 ----
     if (a.node_stat) {
@@ -72,72 +135,69 @@ __global__ __launch_bounds__(RB) void route_k(const mpnn_route_args a) {
         }
     }
 
-    // ---- bottom-up (reverse preorder: children first) ----
-    for (int j = NN - 1; j >= 0; --j) {
-        const int *nd = a.nodes + j * 8;
-        const int ns = nd[2], sw = nd[3], leaf = nd[4];
-        const float p = P[j * RB + t];
-        float cerr = 0.f, dcor = 1.f;
-        if (leaf >= 0 && live) { cerr = a.c_err[(size_t)leaf * n + s]; dcor = a.d_cor[(size_t)leaf * n + s]; }
-        const float ops = a.node_ops[j];
-        if (leaf >= 0 && live && a.w_cerr)
-            a.w_cerr[(size_t)leaf * n + s] = (a.net_type == MPNN_NET_SR ? 1.f : p) * inv_n;
-        l_err += (a.net_type == MPNN_NET_SR ? 1.f : p) * cerr;
-        if (a.net_type == MPNN_NET_ACTOR) l_cpt += p * k_cpt * ops;
-
-        if (a.net_type == MPNN_NET_ACTOR) {
-            float v = cerr + k_cpt * ops;
-            if (sw >= 0 && ns >= 2) {
-                const float *r = a.r + ((size_t)sw * n + s) * MS;
+    // ---- bottom-up (reverse preorder: children first); each node pushes into its parent ----
+    if (type == MPNN_NET_CRITIC)
+        for (int j = 0; j < NN; ++j) O[j * RB + t] = V[j * RB + t];     // c_opt starts from the same own term
+    if (type != MPNN_NET_SR) {
+        for (int j = NN - 1; j >= 0; --j) {
+            const int *nd = ND + j * 8;
+            const int par = nd[0], si = nd[1], ns = nd[2], sw = nd[3];
+            const float p = P[j * RB + t];
+            if (sw >= 0 && ns >= 2) {              // dynamic switch: children are final
+                const float *r = RIN + (sw * MS) * RB + t;
                 const int *kids = a.sw_children + sw * MS;
-                float sm[MPNN_MAX_SINKS], u[MPNN_MAX_SINKS], mx = live ? r[0] : 0.f, den = 0.f, r2 = 0.f;
-                for (int i = 1; i < ns; ++i) mx = fmaxf(mx, live ? r[i] : 0.f);
-                for (int i = 0; i < ns; ++i) { sm[i] = expf(((live ? r[i] : 0.f) - mx) / tau); den += sm[i]; }
-                const float eps_l = eps * (float)nd[5] / root_leaves;
-                float ubar = 0.f;
-                for (int i = 0; i < ns; ++i) {
-                    sm[i] /= den;
-                    const float vc = V[kids[i] * RB + t];
-                    v += sm[i] * vc;
-                    u[i] = (p - eps_l) * vc;
-                    ubar += sm[i] * u[i];
-                    r2 += live ? r[i] * r[i] : 0.f;
+                float sm[MSK]; int arg;
+                soft(sw, ns, sm, arg);
+                if (type == MPNN_NET_ACTOR) {
+                    const float eps_l = eps_unit * (float)nd[5];
+                    float u[MSK], ubar = 0.f, r2 = 0.f, v = V[j * RB + t];
+#pragma unroll
+                    for (int i = 0; i < MSK; ++i) {
+                        u[i] = 0.f;
+                        if (i < ns) {
+                            const float vc = V[kids[i] * RB + t];
+                            v += sm[i] * vc;
+                            u[i] = (p - eps_l) * vc;
+                            ubar += sm[i] * u[i];
+                            r2 += r[i * RB] * r[i * RB];
+                        }
+                    }
+                    V[j * RB + t] = v;
+                    l_aux += p * k_dec * r2;
+                    if (a.want_grad && live) {
+#pragma unroll
+                        for (int i = 0; i < MSK; ++i)
+                            if (i < ns)
+                                a.dr[((size_t)sw * n + s) * MS + i] =
+                                    (sm[i] * (u[i] - ubar) * inv_tau + 2.f * k_dec * p * r[i * RB]) * inv_n;
+                    }
+                } else {
+                    float cev = V[j * RB + t], mn = 0.f, cre = 0.f;
+#pragma unroll
+                    for (int i = 0; i < MSK; ++i) {
+                        if (i < ns) {
+                            const float kev = V[kids[i] * RB + t], kopt = O[kids[i] * RB + t];
+                            mn = i == 0 ? kopt : fminf(mn, kopt);
+                            if (i == arg) cev += kev;
+                            const float d = r[i * RB] + (a.optimistic ? kopt : kev);
+                            cre += d * d;
+                            if (a.want_grad && live) a.dr[((size_t)sw * n + s) * MS + i] = p * 2.f * k_cre * d * inv_n;
+                        }
+                    }
+                    V[j * RB + t] = cev;
+                    O[j * RB + t] += mn;
+                    l_aux += p * k_cre * cre;
                 }
-                l_aux += p * k_dec * r2;
-                if (a.want_grad && live)
-                    for (int i = 0; i < ns; ++i)
-                        a.dr[((size_t)sw * n + s) * MS + i] =
-                            (sm[i] * (u[i] - ubar) / tau + 2.f * k_dec * p * r[i]) * inv_n;
-            } else {
-                for (int k = j + 1; k < NN; ++k) if (a.nodes[k * 8] == j) v += V[k * RB + t];
             }
-            V[j * RB + t] = v;
-        } else if (a.net_type == MPNN_NET_CRITIC) {
-            const float ce = a.use_cls_err ? (leaf >= 0 ? 1.f - dcor : 0.f) : cerr;
-            float cev = ce + k_cpt * ops, copt = cev;
-            if (sw >= 0 && ns >= 2) {
-                const float *r = a.r + ((size_t)sw * n + s) * MS;
-                const int *kids = a.sw_children + sw * MS;
-                int arg = 0;
-                for (int i = 1; i < ns; ++i) if (live && r[i] > r[arg]) arg = i;
-                float mn = O[kids[0] * RB + t], cre = 0.f;
-                for (int i = 0; i < ns; ++i) {
-                    const float kev = V[kids[i] * RB + t], kopt = O[kids[i] * RB + t];
-                    mn = fminf(mn, kopt);
-                    if (i == arg) cev += kev;
-                    const float tgt = a.optimistic ? kopt : kev;
-                    const float d = (live ? r[i] : 0.f) + tgt;
-                    cre += d * d;
-                    if (a.want_grad && live)
-                        a.dr[((size_t)sw * n + s) * MS + i] = p * 2.f * k_cre * d * inv_n;
+            // push into a STATIC parent (a dynamic parent reads its children itself)
+            if (par >= 0) {
+                const int *pn = ND + par * 8;
+                if (!(pn[3] >= 0 && pn[2] >= 2)) {
+                    V[par * RB + t] += V[j * RB + t];
+                    if (type == MPNN_NET_CRITIC) O[par * RB + t] += O[j * RB + t];
                 }
-                copt += mn;
-                l_aux += p * k_cre * cre;
-            } else {
-                for (int k = j + 1; k < NN; ++k)
-                    if (a.nodes[k * 8] == j) { cev += V[k * RB + t]; copt += O[k * RB + t]; }
             }
-            V[j * RB + t] = cev; O[j * RB + t] = copt;
+            (void)si;
         }
     }
 
@@ -152,7 +212,10 @@ extern "C" int mpnn_route(const mpnn_route_args *args, void *stream) {
     if (!args || !args->nodes || !args->p_tr || !args->p_ev) return MPNN_E_ARG;
     if (args->n_nodes > MPNN_MAX_NODES || args->max_sinks > MPNN_MAX_SINKS) return MPNN_E_SHAPE;
     if (args->n <= 0) return 0;
-    hipLaunchKernelGGL(route_k, dim3((args->n + RB - 1) / RB), dim3(RB), 0, (hipStream_t)stream, *args);
+    const size_t lds = (size_t)(3 * args->n_nodes + args->n_switches * args->max_sinks + 2 * args->n_leaves) * RB * 4
+                       + (size_t)args->n_nodes * 9 * 4;
+    if (lds > 160 * 1024) return MPNN_E_SHAPE;
+    hipLaunchKernelGGL(route_k, dim3((args->n + RB - 1) / RB), dim3(256), lds, (hipStream_t)stream, *args);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

@@ -93,8 +93,8 @@ _SIGS = {
     'mpnn_slab_reduce': [P, P, P, C.c_int, P],
     'mpnn_lin_fwd': [P, C.c_int, C.c_int, P],
     'mpnn_lin_bwd': [P, C.c_int, C.c_int, C.c_int, P],
-    'mpnn_exit_tail_fwd': [P, C.c_int, P],
-    'mpnn_exit_tail_bwd': [P, C.c_int, P],
+    'mpnn_exit_tail_fwd': [P, C.c_int, C.c_int, P],
+    'mpnn_exit_tail_bwd': [P, C.c_int, C.c_int, P],
     'mpnn_route': [C.POINTER(RouteArgs), P],
     'mpnn_compact_by_branch': [P, C.c_int, P, P, P],
     'mpnn_bn_finalize': [P, P, P, P, P, C.c_int, C.c_float, C.c_int, P],

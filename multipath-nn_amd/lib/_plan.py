@@ -480,7 +480,7 @@ class Engine:
         keep += [t_lf, t_lb, t_tf, t_tb]
         if n_exit:
             fwd.append(call(lib.mpnn_lin_fwd, 'lin_fwd', t_lf.data_ptr(), n_exit, n))
-            fwd.append(call(lib.mpnn_exit_tail_fwd, 'exit_tail_fwd', t_tf.data_ptr(), n_exit))
+            fwd.append(call(lib.mpnn_exit_tail_fwd, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n))
 
         # ---- route ----
         ra = _hip.RouteArgs()
@@ -508,7 +508,7 @@ class Engine:
         # ---- backward ----
         slab_plan = dict(size=0, table=[], ptrs=[])
         if n_exit:
-            bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit))
+            bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
             bwd.append(call(lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
         for b in reversed(self.blocks):
             cp = b.conv.params

@@ -5,10 +5,10 @@ identical injected weights and identical batches.
 Tolerances (fp32 kernels vs. a float64 oracle; north_star: routing statistics within 1e-3):
   per-sample costs / probabilities : 2e-4 absolute-or-relative
   gradients, parameter updates      : 2e-3 * max|ref| per tensor (measured: <= 6e-6 when no
-                                      discrete flip occurs), EXCEPT that up to 5 % of the tensors
-                                      of a step may be "flip outliers" within 3e-1: fp32 and
-                                      float64 can pick a different max-pool arg-max / ReLU side
-                                      at a near-tie.  The oracle run in fp32 against itself in
+                                      discrete flip occurs).  ONLY IF the test itself finds a
+                                      discrete decision on which fp32 and float64 disagree in that
+                                      forward pass (max-pool arg-max or ReLU side at a near-tie;
+                                      count_flips) may tensors be "flip outliers" within 3e-1.  The oracle run in fp32 against itself in
                                       float64 shows the same isolated outliers (4.8e-2 on one tensor,
                                       median 2.7e-6), e.g. one flipped element among the 256 behind a
                                       4x4-scale BatchNorm beta gradient at batch 16; a property of the
@@ -40,6 +40,27 @@ def perturb_routers(net, seed=5):
             w.assign(rng.standard_normal(w.shape) * 0.5)
             b = ℓ.router.comps[-1].params.b
             b.assign(rng.standard_normal(b.shape) * 0.2)
+
+
+def count_flips(eng, res, n, before):
+    """Discrete decisions (2x2 max-pool arg-max on the vert path, ReLU side after BatchNorm) on
+    which the fp32 product and the float64 oracle disagree in this forward pass."""
+    from oracle import np_ops as O
+    flips = 0
+    for b in eng.blocks:
+        pre = res['out'][id(b.conv)]['pre_bn']
+        for i in range(b.L):
+            s_p = b.s[i][:n].cpu().numpy().astype(np.float64)
+            s_o = pre[i].detach().numpy()
+            if i < b.L - 1:
+                flips += int((O.pool2_argfirst(s_p) != O.pool2_argfirst(s_o)).sum())
+            if b.has_dz[i]:
+                bn = b.bns[i].params
+                g, be = (before[id(bn.γ)].cpu().numpy().astype(np.float64), before[id(bn.β)].cpu().numpy().astype(np.float64))
+                y_p, _, _ = O.bn_train(s_p, g, be)
+                y_o, _, _ = O.bn_train(s_o, g, be)
+                flips += int(((y_p > 0) != (y_o > 0)).sum())
+    return flips
 
 
 def rel(a, b):
@@ -119,7 +140,9 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3):
             judge('grad', p, np.abs(g - g_ref).max(), scale, 1e-6)
             judge('update', p, np.abs(d - d_ref).max(), np.abs(d_ref).max(), 1e-7)
         assert not bad, (t, bad[:8])
-        assert len(outliers) <= 0.05 * n_checked, (t, len(outliers), n_checked, outliers[:8])
+        if outliers:      # only legitimate when a discrete decision differs between fp32 and float64
+            flips = count_flips(eng, res, n, before)
+            assert flips > 0, (t, 'no max-pool / ReLU flip, yet', len(outliers), 'tensors beyond 2e-3', outliers[:8])
     # evaluation pass: moving-average BatchNorm, hard routing, statistics
     x0, y = batch(n, c0, seed=99)
     feed = {net.x0: x0, net.y: y, **{k: v for k, v in feeds(net, 0).items()}}
