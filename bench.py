@@ -72,6 +72,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=128, help='per-GPU batch (arch_and_hypers.py:35)')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--streams', action='store_true',
+                    help='multi-stream DAG schedule (measured slower under hipGraph: cross-stream edges cost more than the overlap gains)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -87,6 +89,7 @@ def main():
     net.to(dev)
     eng = net.engine()
     eng.use_graph = not args.no_graph
+    eng.multi_stream = args.streams
     _dp.attach(net)
     n = args.batch
     x0, y = synthetic(n, rank, dev)
@@ -135,7 +138,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'cifar10-ac: ac_chain(k_cpt=0) 8-block actor-routed chain, 32x32x3, 10 classes',
                        'global_batch': n * world, 'per_gpu_batch': n, 'parallelism': 'dp%d' % world,
-                       'hip_graph': bool(eng.use_graph)},
+                       'hip_graph': bool(eng.use_graph), 'streams': eng.n_streams if eng.multi_stream else 1},
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
                          'frac': ach / PEAK_F32_MFMA, 'traffic': None,
                          'kernel': '%s [%s]' % (dom[0], dom[1]), 'kernel_ms': dom[3],

@@ -29,9 +29,11 @@ extern "C" {
 #define MPNN_E_ARG     (-2)   /* inconsistent arguments                     */
 
 /* BatchNorm statistics are accumulated with fp64 atomics into MPNN_BN_SLOTS
- * replicated slots (a workgroup adds to slot blockIdx % MPNN_BN_SLOTS) so that
+ * replicated slots (a workgroup adds to slot blockIdx % nslot) so that
  * thousands of workgroups do not serialise on one address; readers add the
- * slots.  A statistics buffer is therefore [MPNN_BN_SLOTS][2*C] doubles. */
+ * slots.  A statistics buffer is [MPNN_BN_SLOTS][2*C] doubles of which the
+ * first `nslot` are used (few slots for layers with few workgroups: every
+ * consumer workgroup re-adds them in its prologue). */
 #define MPNN_BN_SLOTS 16
 
 #define MPNN_ACT_IDENTITY 0   /* raw values (pyramid input, gradients)      */
@@ -52,6 +54,7 @@ typedef struct {
     int   C;
     int   shift;
     int   mode;            /* MPNN_ACT_*                                       */
+    int   nslot;           /* slots of `sum` actually in use (1..MPNN_BN_SLOTS) */
 } mpnn_act;
 
 /* ---- weight packing ------------------------------------------------------
@@ -77,6 +80,7 @@ typedef struct {
     const float *bias;                              /* [Cout]                  */
     float  *out;                                    /* [n, H, W, Cout]         */
     double *out_sum;                                /* [SLOTS][2*Cout], accumulated */
+    int out_nslot;                                  /* slots of out_sum to spread over */
     int n, H, W, Cout;
 } mpnn_conv_fwd_args;
 int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
@@ -93,6 +97,7 @@ typedef struct {
     const float *s;        /* pre-BN values [n,H,W,C]                          */
     mpnn_act bn;           /* the BatchNorm of s (x field unused)              */
     const double *red;     /* [SLOTS][2*C] sum dz, sum dz*xhat (NULL: zero)    */
+    int red_nslot;         /* slots of red in use                              */
 } mpnn_bn_ctx;
 int mpnn_bn_bwd_reduce(const float *dy, const mpnn_bn_ctx *ctx, float *dz,
                        double *red_out, long n_pix, void *stream);
@@ -274,9 +279,9 @@ int mpnn_compact_by_branch(const float *p_ev, int n, int *idx_out, int *count_ou
  * Moving averages (layer_types.py:233-234) from the forward sums and
  * dgamma / dbeta from the backward reductions, for every conv BatchNorm in one
  * launch.  table: 8 ints per BN: sum_off (doubles; same offset in `reds`; each
- * a [SLOTS][2*C] block),
+ * a [SLOTS][2*C] block of which table[7] slots are in use),
  * mavg_off, vavg_off (floats in `state`), C, pixels per image, gamma_goff,
- * beta_goff (floats in `grads`; -1: no gradient), reserved. */
+ * beta_goff (floats in `grads`; -1: no gradient), nslot. */
 int mpnn_bn_finalize(const double *sums, const double *reds, float *state, float *grads,
                      const int *table, int n_bn, float decay, int n_img, void *stream);
 

@@ -16,10 +16,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct BnC { float m, rstd, gamma, beta; };
 
 // Sum of one statistic over the replicated slots.
-__device__ __forceinline__ double slot_sum(const double *base, int C2, int idx) {
+__device__ __forceinline__ double slot_sum(const double *base, int C2, int idx, int nslot) {
     double t = 0.0;
-#pragma unroll
-    for (int s = 0; s < MPNN_BN_SLOTS; ++s) t += base[s * C2 + idx];
+#pragma unroll 4
+    for (int s = 0; s < nslot; ++s) t += base[s * C2 + idx];
     return t;
 }
 
@@ -29,8 +29,8 @@ __device__ __forceinline__ BnC bn_coef(const mpnn_act &b, int c) {
     k.beta = b.beta[c];
     if (b.mode == MPNN_ACT_BN_BATCH) {
         const double inv = 1.0 / (double)b.cnt;
-        const double mean = slot_sum(b.sum, 2 * b.C, c) * inv;
-        double var = slot_sum(b.sum, 2 * b.C, b.C + c) * inv - mean * mean;
+        const double mean = slot_sum(b.sum, 2 * b.C, c, b.nslot) * inv;
+        double var = slot_sum(b.sum, 2 * b.C, b.C + c, b.nslot) * inv - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         k.m = (float)mean;
         k.rstd = rsqrtf((float)var + b.eps);

@@ -11,6 +11,7 @@ extern "C" int mpnn_msconv_dgrad_horz(const mpnn_dgrad_horz_args *a, void *strea
     if (a->prev) {
         if (!a->prev->s || !a->red_out) return MPNN_E_ARG;
         p.sprev = a->prev->s;  p.pbn = a->prev->bn;  p.red_out = a->red_out;
+        p.out_nslot = a->prev->red_nslot < 1 ? 1 : a->prev->red_nslot;
         return conv_launch<EPI_DGH_BN>(p, (hipStream_t)stream);
     }
     return conv_launch<EPI_DGH_RAW>(p, (hipStream_t)stream);
@@ -24,5 +25,6 @@ extern "C" int mpnn_msconv_dgrad_vert(const mpnn_dgrad_vert_args *a, void *strea
     p.n = a->n;  p.H = a->H;  p.W = a->W;  p.Cout = a->Cout;
     p.out = a->dz_g_fine;  p.sprev = a->fine->s;  p.pbn = a->fine->bn;
     p.red = a->fine_has_dz ? a->fine->red : nullptr;  p.has_dz = a->fine_has_dz;
+    p.red_nslot = a->fine->red_nslot < 1 ? 1 : a->fine->red_nslot;
     return conv_launch<EPI_DGV>(p, (hipStream_t)stream);
 }

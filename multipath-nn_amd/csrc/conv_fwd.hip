@@ -10,5 +10,6 @@ extern "C" int mpnn_msconv_fwd(const mpnn_conv_fwd_args *a, void *stream) {
     p.wa = a->wa_pack;  p.wv = a->wv_pack;
     p.n = a->n;  p.H = a->H;  p.W = a->W;  p.Cout = a->Cout;
     p.bias = a->bias;  p.out = a->out;  p.out_sum = a->out_sum;
+    p.out_nslot = a->out_nslot < 1 ? 1 : (a->out_nslot > MPNN_BN_SLOTS ? MPNN_BN_SLOTS : a->out_nslot);
     return conv_launch<EPI_FWD>(p, (hipStream_t)stream);
 }

@@ -27,6 +27,7 @@
 // pixels of one plane in the 8 lanes of a ds_write_b128 group.
 #pragma once
 #include "common.h"
+#include <cstdlib>
 
 enum { EPI_FWD = 0, EPI_DGH_BN = 1, EPI_DGH_RAW = 2, EPI_DGV = 3 };
 
@@ -38,7 +39,10 @@ struct ConvP {
     const float *bias;  float *out;  double *out_sum;      // EPI_FWD
     const float *extra;                                     // EPI_DGH_*
     const float *sprev;  mpnn_act pbn;  double *red_out;    // EPI_DGH_BN / EPI_DGV
-    const double *red;  int has_dz;                         // EPI_DGV
+    const double *red;  int has_dz;  int red_nslot;         // EPI_DGV
+    int out_nslot;                                          // slots of out_sum / red_out
+    int n_tiles;                                            // set by the launcher
+    int dbg;                                                // ablation mask (MPNN_CONV_DBG), 0 in production
 };
 
 // Geometry kinds.  TH x TW output pixels per image x IMG images = 64 pixels;
@@ -74,71 +78,130 @@ static inline int conv_grid_x(int n, int H, int W) {
     return (n + 3) >> 2;
 }
 
-// Stage one 16-channel chunk of the halo tile.  MODE 0: operand A (optional
-// BN+ReLU, optional pyramid subsampling); MODE 1: 2x2 max-pool of the finer map.
-template <int GK, int MODE>
-__device__ __forceinline__ void stage_chunk(f32x4 *tile, const ConvP &p, const float *cA,
-                                            int n0, int y0, int x0, int c0, int np, int tid) {
+// ---------------------------------------------------------------------------
+// Staging: global -> registers (RAW, no arithmetic, so the loads stay in flight
+// under the MFMAs of the unit being computed) and registers -> LDS (transform
+// applied here).  An "item" is one float4 slot of the halo tile: item i of a
+// thread block maps to (plane q, halo pixel hp) with 8 consecutive pixels of
+// one plane in 8 consecutive lanes (conflict-free ds_write_b128 groups, 512-B
+// contiguous global segments).
+// MODE 0: operand A (optional BN+ReLU, optional pyramid subsampling), one
+// float4 per item; MODE 1: 2x2 max-pool of the finer map, four float4 per item.
+// ---------------------------------------------------------------------------
+template <int GK> struct XItems {
     using G = Geom<GK>;
-    constexpr int HR = G::TH + 2, HC = G::TW + 2, NHP = G::IMG * HR * HC, NHP8 = (NHP + 7) & ~7;
-    for (int i = tid; i < NHP8 * 4; i += 256) {
-        const int q = (i >> 3) & 3;
-        const int hp = ((i >> 5) << 3) + (i & 7);
-        if (hp >= NHP) continue;
-        const int img = hp / (HR * HC);
-        const int rem = hp - img * (HR * HC);
-        const int hy = rem / HC, hx = rem - hy * HC;
-        const int n = n0 + img, y = y0 + hy - 1, x = x0 + hx - 1;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (q < np && n < p.n && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+    static constexpr int HR = G::TH + 2, HC = G::TW + 2, NHP = G::IMG * HR * HC, NHP8 = (NHP + 7) & ~7;
+    static constexpr int N = (NHP8 * 4 + 255) / 256;      // items per thread
+};
+
+template <int GK>
+__device__ __forceinline__ bool x_item(int i, int n0, int y0, int x0, int np, const ConvP &p,
+                                       int &q, int &lds_slot, int &n, int &y, int &x, bool &inb) {
+    using X = XItems<GK>;
+    using G = Geom<GK>;
+    q = (i >> 3) & 3;
+    const int hp = ((i >> 5) << 3) + (i & 7);
+    if (hp >= X::NHP) return false;
+    const int img = hp / (X::HR * X::HC);
+    const int rem = hp - img * (X::HR * X::HC);
+    const int hy = rem / X::HC, hx = rem - hy * X::HC;
+    n = n0 + img; y = y0 + hy - 1; x = x0 + hx - 1;
+    lds_slot = (img * X::HR + hy) * G::R + hx;
+    inb = q < np && n < p.n && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    return true;
+}
+
+template <int GK, int MODE, int XW>
+__device__ __forceinline__ void load_x(f32x4 (*xr)[XW], const ConvP &p, int n0, int y0, int x0, int c0, int np, int tid) {
+    using X = XItems<GK>;
+    static_assert(MODE == 0 || XW == 4, "pooling needs four raw registers per item");
+#pragma unroll
+    for (int k = 0; k < X::N; ++k) {
+        int q, slot, n, y, x; bool inb;
+        const bool ok = x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb);
+#pragma unroll
+        for (int w = 0; w < (MODE ? 4 : 1); ++w) xr[k][w] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok && inb) {
             const int c = c0 + q * 4;
             if (MODE == 0) {
                 const int sh = p.a.shift, C = p.a.C;
                 const size_t base = (((size_t)n * (p.H << sh) + (y << sh)) * (p.W << sh) + (x << sh)) * C;
                 if ((C & 3) == 0) {
-                    v = *(const f32x4 *)(p.a.x + base + c);
+                    xr[k][0] = *(const f32x4 *)(p.a.x + base + c);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = (c + k < C) ? p.a.x[base + c + k] : 0.f;
-                }
-                if (p.a.mode != MPNN_ACT_IDENTITY) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float *cc = cA + (c + k) * 3;
-                        v[k] = fmaxf((v[k] - cc[0]) * cc[1] + cc[2], 0.f);
-                    }
+                    for (int j = 0; j < 4; ++j) xr[k][0][j] = (c + j < C) ? p.a.x[base + c + j] : 0.f;
                 }
             } else {
                 const int W2 = p.W * 2;
                 const float *s = p.v + (((size_t)n * (p.H * 2) + 2 * y) * W2 + 2 * x) * p.Cv + c;
-                const f32x4 a0 = *(const f32x4 *)s, a1 = *(const f32x4 *)(s + p.Cv);
-                const f32x4 a2 = *(const f32x4 *)(s + (size_t)W2 * p.Cv);
-                const f32x4 a3 = *(const f32x4 *)(s + (size_t)W2 * p.Cv + p.Cv);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaxf(a0[k], a1[k]), fmaxf(a2[k], a3[k]));
+                xr[k][0] = *(const f32x4 *)s;
+                xr[k][1 % XW] = *(const f32x4 *)(s + p.Cv);
+                xr[k][2 % XW] = *(const f32x4 *)(s + (size_t)W2 * p.Cv);
+                xr[k][3 % XW] = *(const f32x4 *)(s + (size_t)W2 * p.Cv + p.Cv);
             }
         }
-        tile[q * G::P + (img * HR + hy) * G::R + hx] = v;
     }
 }
 
+template <int GK, int PS, int MODE, int XW>
+__device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], const ConvP &p, const float *cA,
+                                        int n0, int y0, int x0, int c0, int np, int tid) {
+    using X = XItems<GK>;
+#pragma unroll
+    for (int k = 0; k < X::N; ++k) {
+        int q, slot, n, y, x; bool inb;
+        if (!x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb)) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (inb) {
+            if (MODE == 0) {
+                v = xr[k][0];
+                if (p.a.mode != MPNN_ACT_IDENTITY) {
+                    const int c = c0 + q * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float *cc = cA + (c + j) * 3;
+                        v[j] = (c + j < p.a.C) ? fmaxf((v[j] - cc[0]) * cc[1] + cc[2], 0.f) : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = fmaxf(fmaxf(xr[k][0][j], xr[k][1 % XW][j]), fmaxf(xr[k][2 % XW][j], xr[k][3 % XW][j]));
+            }
+        }
+        tile[q * PS + slot] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The kernel.  A workgroup is persistent over its share of the 64-pixel tiles;
+// its work is a sequence of units (tile, operand part, 16-channel chunk).  LDS
+// is double-buffered: while the MFMAs of unit u read buffer u&1, the raw global
+// loads of unit u+1 are in flight, and they are transformed and written to the
+// other buffer before the single barrier that ends the unit.
+// ---------------------------------------------------------------------------
 template <int GK, int MT, int NT, int WM, int WN, bool SMALL_A, int EPI>
 __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
     using G = Geom<GK>;
     constexpr int P = G::P, R = G::R, HR = G::TH + 2;
     constexpr int CT = WN * NT * 16;
+    constexpr int XW = EPI == EPI_FWD ? 4 : 1;      // only the forward conv has a pooled operand
+    constexpr int XN = XItems<GK>::N;
     static_assert(WM * WN == 4 && WM * MT == 4, "4 waves, 4 M-tiles per workgroup");
 
-    __shared__ f32x4 tile[4 * P];
+    constexpr int BI = 36 * CT;                     // float4 items of one weight chunk: [9 taps][4 g][CT]
+    constexpr int BN = (BI + 255) / 256;
+    __shared__ f32x4 tile[2][4 * P];
+    __shared__ f32x4 wtile[2][BI];
     __shared__ float cA[128 * 3];
     __shared__ float cE[CT * 5];
     __shared__ double redbuf[WM * CT * 2];
 
-    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int wm = wid / WN, wn = wid - wm * WN;
-    int n0, y0, x0;
-    tile_origin<GK>(p, blockIdx.x, n0, y0, x0);
     const int co0 = blockIdx.y * CT;
     const int cw = co0 + wn * NT * 16 + li;          // this lane's first output channel
 
@@ -156,12 +219,16 @@ __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
             if (EPI == EPI_DGH_BN) { e[3] = k.beta; e[4] = 0.f; }
             else {
                 const double inv = 1.0 / (double)p.pbn.cnt;
-                e[3] = p.red ? (float)(slot_sum(p.red, 2 * p.pbn.C, co0 + c) * inv) : 0.f;             // dbeta / cnt
-                e[4] = p.red ? (float)(slot_sum(p.red, 2 * p.pbn.C, p.pbn.C + co0 + c) * inv) : 0.f;   // dgamma / cnt
+                e[3] = p.red ? (float)(slot_sum(p.red, 2 * p.pbn.C, co0 + c, p.red_nslot) * inv) : 0.f;             // dbeta / cnt
+                e[4] = p.red ? (float)(slot_sum(p.red, 2 * p.pbn.C, p.pbn.C + co0 + c, p.red_nslot) * inv) : 0.f;   // dgamma / cnt
             }
         }
     }
+    __syncthreads();
 
+    float bias_r[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias_r[nt] = (EPI == EPI_FWD) ? p.bias[cw + nt * 16] : 0.f;
     int slot0[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -169,35 +236,101 @@ __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
         mtile_pix<GK>(wm * MT + mt, li, img, ty, tx);
         slot0[mt] = (img * HR + ty) * R + tx;
     }
+    const int nchA = (p.a.C + 15) >> 4, nchV = p.v ? ((p.Cv + 15) >> 4) : 0, upt = nchA + nchV;
 
+    const int my_tiles = ((int)blockIdx.x < p.n_tiles) ? (p.n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int n_units = my_tiles * upt;
+
+    // unit decode
+    auto decode = [&](int u, int &t, int &part, int &ch, int &np) {
+        const int ti = u / upt, q = u - ti * upt;
+        t = blockIdx.x + ti * gridDim.x;
+        part = q >= nchA ? 1 : 0;
+        ch = part ? q - nchA : q;
+        const int C = part ? p.Cv : p.a.C;
+        np = (C - ch * 16 + 3) >> 2;
+        np = np > 4 ? 4 : np;
+    };
+
+    // Weight chunk (part, ch) of the k-interleaved pack -> registers -> LDS [tap][g][CT] float4.
+    f32x4 br[BN];
+    auto load_b = [&](int part_, int ch_) {
+        const float *wp = part_ ? p.wv : p.wa;
+        const int nch = part_ ? nchV : nchA;
+#pragma unroll
+        for (int k = 0; k < BN; ++k) {
+            const int i = tid + k * 256;
+            br[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < BI) {
+                const int c4 = i % CT, tg = i / CT, gg = tg & 3, tap = tg >> 2;
+                br[k] = *(const f32x4 *)(wp + ((size_t)((tap * nch + ch_) * 4 + gg) * p.Cout + co0 + c4) * 4);
+            }
+        }
+    };
+    auto store_b = [&](f32x4 *dst) {
+#pragma unroll
+        for (int k = 0; k < BN; ++k) { const int i = tid + k * 256; if (i < BI) dst[i] = br[k]; }
+    };
+    const bool b_once = upt == 1;                    // one unit per tile: the weights never change
+
+    f32x4 xr[XN][XW];
     f32x4 acc[MT][NT];
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-        const int C = part == 0 ? p.a.C : (p.v ? p.Cv : 0);
-        if (C == 0) continue;
-        const float *wp = part == 0 ? p.wa : p.wv;
-        const int nch = (C + 15) >> 4;
-        for (int ch = 0; ch < nch; ++ch) {
-            __syncthreads();
-            int np = (C - ch * 16 + 3) >> 2;
-            np = np > 4 ? 4 : np;
-            if (part == 0) stage_chunk<GK, 0>(tile, p, cA, n0, y0, x0, ch * 16, np, tid);
-            else           stage_chunk<GK, 1>(tile, p, cA, n0, y0, x0, ch * 16, np, tid);
-            __syncthreads();
+    int t, part, ch, np, n0, y0, x0;               // current unit
+    int t2, part2, ch2, np2, m0, v0, u0;           // next unit (origin m0, v0, u0)
+    if (n_units > 0) {
+        decode(0, t, part, ch, np);
+        tile_origin<GK>(p, t, n0, y0, x0);
+        bool pooled = false;
+        if constexpr (XW == 4) {
+            if (part) {
+                pooled = true;
+                load_x<GK, 1, XW>(xr, p, n0, y0, x0, ch * 16, np, tid);
+                store_x<GK, P, 1, XW>(tile[0], xr, p, cA, n0, y0, x0, ch * 16, np, tid);
+            }
+        }
+        if (!pooled) {
+            load_x<GK, 0, XW>(xr, p, n0, y0, x0, ch * 16, np, tid);
+            store_x<GK, P, 0, XW>(tile[0], xr, p, cA, n0, y0, x0, ch * 16, np, tid);
+        }
+        load_b(part, ch);
+        store_b(wtile[0]);
+    }
+    __syncthreads();
+
+    for (int u = 0; u < n_units; ++u) {
+        const f32x4 *cur = tile[u & 1];
+        const bool more = u + 1 < n_units;
+        if (more && !(p.dbg & 2)) {
+            decode(u + 1, t2, part2, ch2, np2);
+            tile_origin<GK>(p, t2, m0, v0, u0);
+            bool pooled = false;
+            if constexpr (XW == 4) {
+                if (part2) { pooled = true; load_x<GK, 1, XW>(xr, p, m0, v0, u0, ch2 * 16, np2, tid); }
+            }
+            if (!pooled) load_x<GK, 0, XW>(xr, p, m0, v0, u0, ch2 * 16, np2, tid);
+            if (!b_once) load_b(part2, ch2);
+        }
+        // ----------------------------- MFMAs of unit u -----------------------------
+        if (!(p.dbg & 1)) {
+            const f32x4 *wl = b_once ? wtile[0] : wtile[u & 1];
+            const int wcol = wn * NT * 16 + li;
             if (SMALL_A && part == 0) {
-                const float *tf = (const float *)tile;
+                const float *tf = (const float *)cur;
+                const float *wf = (const float *)wl;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int dy = tap / 3, dx = tap - dy * 3;
                     float b[NT], a[MT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        b[nt] = wp[((size_t)(tap * 4) * p.Cout + cw + nt * 16) * 4 + g];
+                    for (int nt = 0; nt < NT; ++nt) b[nt] = wf[((tap * 4) * CT + wcol + nt * 16) * 4 + g];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) a[mt] = tf[(slot0[mt] + dy * R + dx) * 4 + g];
 #pragma unroll
@@ -210,90 +343,101 @@ __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int dy = tap / 3, dx = tap - dy * 3;
-                    const float *wt = wp + ((size_t)((tap * nch + ch) * 4 + g) * p.Cout + cw) * 4;
-                    f32x4 b[NT], a[MT];
+                    f32x4 a[MT], bq[NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4 *)(wt + nt * 64);
+                    for (int nt = 0; nt < NT; ++nt) bq[nt] = wl[(tap * 4 + g) * CT + wcol + nt * 16];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a[mt] = tile[g * P + slot0[mt] + dy * R + dx];
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = cur[g * P + slot0[mt] + dy * R + dx];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], bq[nt][j], acc[mt][nt], 0, 0, 0);
                 }
             }
         }
-    }
-
-    // ------------------------------- epilogue --------------------------------
-    // D layout: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel of the M-tile).
-    float s1[NT], s2[NT];
+        // ----------------------------- epilogue of a finished tile -----------------
+        // D layout: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel of the M-tile).
+        if ((!more || t2 != t) && !(p.dbg & 4)) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
-
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+                for (int r = 0; r < 4; ++r) {
+                    int img, ty, tx;
+                    mtile_pix<GK>(wm * MT + mt, g * 4 + r, img, ty, tx);
+                    const int n = n0 + img, y = y0 + ty, x = x0 + tx;
+                    if (n >= p.n) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int img, ty, tx;
-            mtile_pix<GK>(wm * MT + mt, g * 4 + r, img, ty, tx);
-            const int n = n0 + img, y = y0 + ty, x = x0 + tx;
-            if (n >= p.n) continue;
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int co = cw + nt * 16;
+                        const int cl = co - co0;
+                        float val = acc[mt][nt][r];
+                        if (EPI == EPI_FWD) {
+                            const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
+                            val += bias_r[nt];
+                            p.out[idx] = val;
+                            s1[nt] += val; s2[nt] += val * val;
+                        } else if (EPI == EPI_DGH_RAW) {
+                            const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
+                            if (p.extra) val += p.extra[idx];
+                            p.out[idx] = val;
+                        } else if (EPI == EPI_DGH_BN) {
+                            const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
+                            if (p.extra) val += p.extra[idx];
+                            const float *e = cE + cl * 5;
+                            const float d = p.sprev[idx] - e[0];
+                            const float yv = d * e[2] + e[3];
+                            const float dz = yv > 0.f ? val : 0.f;
+                            p.out[idx] = dz;
+                            s1[nt] += dz; s2[nt] += dz * (d * e[1]);
+                        } else {  // EPI_DGV: val = d(pooled fine map) at coarse pixel (y, x)
+                            const float *e = cE + cl * 5;
+                            const int W2 = p.W * 2;
+                            const size_t i00 = (((size_t)n * (p.H * 2) + 2 * y) * W2 + 2 * x) * p.Cout + co;
+                            const size_t ix[4] = {i00, i00 + p.Cout, i00 + (size_t)W2 * p.Cout,
+                                                  i00 + (size_t)W2 * p.Cout + p.Cout};
+                            float sv[4];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int co = cw + nt * 16;
-                const int cl = co - co0;
-                float val = acc[mt][nt][r];
-                if (EPI == EPI_FWD) {
-                    const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
-                    val += p.bias[co];
-                    p.out[idx] = val;
-                    s1[nt] += val; s2[nt] += val * val;
-                } else if (EPI == EPI_DGH_RAW) {
-                    const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
-                    if (p.extra) val += p.extra[idx];
-                    p.out[idx] = val;
-                } else if (EPI == EPI_DGH_BN) {
-                    const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
-                    if (p.extra) val += p.extra[idx];
-                    const float *e = cE + cl * 5;
-                    const float d = p.sprev[idx] - e[0];
-                    const float yv = d * e[2] + e[3];
-                    const float dz = yv > 0.f ? val : 0.f;
-                    p.out[idx] = dz;
-                    s1[nt] += dz; s2[nt] += dz * (d * e[1]);
-                } else {  // EPI_DGV: val = d(pooled fine map) at coarse pixel (y, x)
-                    const float *e = cE + cl * 5;
-                    const int W2 = p.W * 2;
-                    const size_t i00 = (((size_t)n * (p.H * 2) + 2 * y) * W2 + 2 * x) * p.Cout + co;
-                    const size_t ix[4] = {i00, i00 + p.Cout, i00 + (size_t)W2 * p.Cout,
-                                          i00 + (size_t)W2 * p.Cout + p.Cout};
-                    float sv[4];
+                            for (int k = 0; k < 4; ++k) sv[k] = p.sprev[ix[k]];
+                            int arg = 0; float mx = sv[0];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) sv[k] = p.sprev[ix[k]];
-                    int arg = 0; float mx = sv[0];
+                            for (int k = 1; k < 4; ++k) if (sv[k] > mx) { mx = sv[k]; arg = k; }
 #pragma unroll
-                    for (int k = 1; k < 4; ++k) if (sv[k] > mx) { mx = sv[k]; arg = k; }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float dzf = p.has_dz ? p.out[ix[k]] : 0.f;
-                        const float xh = (sv[k] - e[0]) * e[1];
-                        float gk = e[2] * (dzf - e[3] - xh * e[4]);
-                        if (k == arg) gk += val;
-                        p.out[ix[k]] = gk;
+                            for (int k = 0; k < 4; ++k) {
+                                const float dzf = p.has_dz ? p.out[ix[k]] : 0.f;
+                                const float xh = (sv[k] - e[0]) * e[1];
+                                float gk = e[2] * (dzf - e[3] - xh * e[4]);
+                                if (k == arg) gk += val;
+                                p.out[ix[k]] = gk;
+                            }
+                        }
                     }
                 }
             }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // ----------------------------- stage unit u+1, advance ----------------------
+        if (more && !(p.dbg & 2)) {
+            f32x4 *nxt = tile[(u + 1) & 1];
+            bool pooled = false;
+            if constexpr (XW == 4) {
+                if (part2) { pooled = true; store_x<GK, P, 1, XW>(nxt, xr, p, cA, m0, v0, u0, ch2 * 16, np2, tid); }
+            }
+            if (!pooled) store_x<GK, P, 0, XW>(nxt, xr, p, cA, m0, v0, u0, ch2 * 16, np2, tid);
+            if (!b_once) store_b(wtile[(u + 1) & 1]);
+            t = t2; part = part2; ch = ch2; np = np2; n0 = m0; y0 = v0; x0 = u0;
+        }
+        __syncthreads();
     }
 
     if (EPI == EPI_FWD || EPI == EPI_DGH_BN) {
         double *dst = EPI == EPI_FWD ? p.out_sum : p.red_out;
         if (dst) {
-            __syncthreads();     // (redbuf is separate from tile, but keep phases ordered)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const double a1 = reduce_g4((double)s1[nt]);
@@ -309,7 +453,7 @@ __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
                 double a1 = 0.0, a2 = 0.0;
 #pragma unroll
                 for (int w = 0; w < WM; ++w) { a1 += redbuf[(w * CT + tid) * 2]; a2 += redbuf[(w * CT + tid) * 2 + 1]; }
-                double *slot = dst + (size_t)(blockIdx.x % MPNN_BN_SLOTS) * 2 * p.Cout;
+                double *slot = dst + (size_t)(blockIdx.x % p.out_nslot) * 2 * p.Cout;
                 atomicAdd(slot + co0 + tid, a1);
                 atomicAdd(slot + p.Cout + co0 + tid, a2);
             }
@@ -319,19 +463,29 @@ __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
 
 // ------------------------------- host dispatch -------------------------------
 template <int GK, int MT, int NT, int WM, int WN, int EPI>
-static int conv_launch_cfg(const ConvP &p, bool small_a, hipStream_t st) {
+static int conv_launch_cfg(ConvP &p, bool small_a, hipStream_t st) {
     constexpr int CT = WN * NT * 16;
-    dim3 grid(conv_grid_x<GK>(p.n, p.H, p.W), p.Cout / CT), block(256);
-    if (EPI == EPI_FWD && small_a)
-        hipLaunchKernelGGL((conv_k<GK, MT, NT, WM, WN, true, EPI>), grid, block, 0, st, p);
-    else
-        hipLaunchKernelGGL((conv_k<GK, MT, NT, WM, WN, false, EPI>), grid, block, 0, st, p);
+    p.n_tiles = conv_grid_x<GK>(p.n, p.H, p.W);
+    { const char *e = getenv("MPNN_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+    const int gy = p.Cout / CT;
+    int gx = p.n_tiles;
+    const int cap = 1024 / gy > 64 ? 1024 / gy : 64;      // persistent: a few workgroups per CU
+    if (gx > cap) gx = cap;
+    dim3 grid(gx, gy), block(256);
+    if constexpr (EPI == EPI_FWD) {
+        if (small_a) {
+            hipLaunchKernelGGL((conv_k<GK, MT, NT, WM, WN, true, EPI>), grid, block, 0, st, p);
+            MPNN_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((conv_k<GK, MT, NT, WM, WN, false, EPI>), grid, block, 0, st, p);
     MPNN_LAUNCH_CHECK();
     return 0;
 }
 
 template <int GK, int EPI>
-static int conv_launch_geom(const ConvP &p, bool small_a, hipStream_t st) {
+static int conv_launch_geom(ConvP &p, bool small_a, hipStream_t st) {
     const int Co = p.Cout;
     if (Co % 16) return MPNN_E_SHAPE;
     // 4x4 maps have few spatial tiles: prefer narrow channel tiles there.
@@ -341,7 +495,7 @@ static int conv_launch_geom(const ConvP &p, bool small_a, hipStream_t st) {
 }
 
 template <int EPI>
-static int conv_launch(const ConvP &p, hipStream_t st) {
+static int conv_launch(ConvP &p, hipStream_t st) {
     if (p.n <= 0) return 0;
     if (p.a.C > 128 || p.Cv > 128 || (p.Cv & 3)) return MPNN_E_SHAPE;
     const bool small_a = p.a.C <= 4;

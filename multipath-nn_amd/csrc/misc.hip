@@ -44,7 +44,7 @@ extern "C" int mpnn_pack_weights(const float *params, float *packs, const int *d
 // mpnn_bn_bwd_reduce / mpnn_bn_bwd_apply (elementwise forms; the conv
 // epilogues hold the fused forms).  C % 4 == 0 and (C/4) | 256.
 // ---------------------------------------------------------------------------
-struct BnBwdP { const float *dy; const float *s; mpnn_act bn; const double *red; float *dz; double *red_out; long n_pix; };
+struct BnBwdP { const float *dy; const float *s; mpnn_act bn; const double *red; float *dz; double *red_out; long n_pix; int red_nslot; };
 
 // Per-workgroup coefficient table in LDS: [C][6] = m, rstd, gamma*rstd, beta, red0/cnt, red1/cnt.
 __device__ __forceinline__ void bn_table(const BnBwdP &p, float *tab) {
@@ -54,8 +54,8 @@ __device__ __forceinline__ void bn_table(const BnBwdP &p, float *tab) {
         const BnC k = bn_coef(p.bn, c);
         float *e = tab + c * 6;
         e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd; e[3] = k.beta;
-        e[4] = p.red ? (float)(slot_sum(p.red, 2 * C, c) * inv) : 0.f;
-        e[5] = p.red ? (float)(slot_sum(p.red, 2 * C, C + c) * inv) : 0.f;
+        e[4] = p.red ? (float)(slot_sum(p.red, 2 * C, c, p.red_nslot) * inv) : 0.f;
+        e[5] = p.red ? (float)(slot_sum(p.red, 2 * C, C + c, p.red_nslot) * inv) : 0.f;
     }
     __syncthreads();
 }
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(const BnBwdP p) {
         const int c = threadIdx.x, cq = c >> 2, cj = c & 3;
         double a1 = 0, a2 = 0;
         for (int r = 0; r < ppb; ++r) { a1 += sh[(r * Q + cq) * 8 + cj]; a2 += sh[(r * Q + cq) * 8 + 4 + cj]; }
-        double *slot = p.red_out + (size_t)(blockIdx.x % MPNN_BN_SLOTS) * 2 * C;
+        double *slot = p.red_out + (size_t)(blockIdx.x % p.red_nslot) * 2 * C;
         atomicAdd(slot + c, a1);
         atomicAdd(slot + C + c, a2);
     }
@@ -122,7 +122,7 @@ extern "C" int mpnn_bn_bwd_reduce(const float *dy, const mpnn_bn_ctx *ctx, float
     if (!dy || !ctx || !ctx->s || !dz || !red_out) return MPNN_E_ARG;
     if (!bn_shape_ok(ctx->bn.C)) return MPNN_E_SHAPE;
     if (n_pix <= 0) return 0;
-    BnBwdP p = {dy, ctx->s, ctx->bn, nullptr, dz, red_out, n_pix};
+    BnBwdP p = {dy, ctx->s, ctx->bn, nullptr, dz, red_out, n_pix, ctx->red_nslot < 1 ? 1 : ctx->red_nslot};
     const int ppb = 256 / (ctx->bn.C >> 2);
     long blocks = (n_pix + (long)ppb * 16 - 1) / ((long)ppb * 16);
     blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
@@ -135,7 +135,7 @@ extern "C" int mpnn_bn_bwd_apply(float *dz_inout, const mpnn_bn_ctx *ctx, long n
     if (!dz_inout || !ctx || !ctx->s) return MPNN_E_ARG;
     if (!bn_shape_ok(ctx->bn.C)) return MPNN_E_SHAPE;
     if (n_pix <= 0) return 0;
-    BnBwdP p = {nullptr, ctx->s, ctx->bn, ctx->red, dz_inout, nullptr, n_pix};
+    BnBwdP p = {nullptr, ctx->s, ctx->bn, ctx->red, dz_inout, nullptr, n_pix, ctx->red_nslot < 1 ? 1 : ctx->red_nslot};
     long blocks = (n_pix * (ctx->bn.C >> 2) + 2047) / 2048;
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipLaunchKernelGGL(bn_bwd_apply_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
@@ -158,15 +158,15 @@ __global__ void bn_finalize_k(const double *__restrict__ sums, const double *__r
     const int C = t[3];
     const double inv = 1.0 / ((double)t[4] * (double)n_img);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double mean = slot_sum(sums + t[0], 2 * C, c) * inv;
-        double var = slot_sum(sums + t[0], 2 * C, C + c) * inv - mean * mean;
+        const double mean = slot_sum(sums + t[0], 2 * C, c, t[7]) * inv;
+        double var = slot_sum(sums + t[0], 2 * C, C + c, t[7]) * inv - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         float *m = state + t[1] + c, *v = state + t[2] + c;
         *m = decay * *m + (1.f - decay) * (float)mean;
         *v = decay * *v + (1.f - decay) * (float)var;
         if (reds && grads && t[5] >= 0) {
-            grads[t[6] + c] = (float)slot_sum(reds + t[0], 2 * C, c);          // dbeta  = sum dz
-            grads[t[5] + c] = (float)slot_sum(reds + t[0], 2 * C, C + c);      // dgamma = sum dz * xhat
+            grads[t[6] + c] = (float)slot_sum(reds + t[0], 2 * C, c, t[7]);          // dbeta  = sum dz
+            grads[t[5] + c] = (float)slot_sum(reds + t[0], 2 * C, C + c, t[7]);      // dgamma = sum dz * xhat
         }
     }
 }

@@ -36,96 +36,6 @@ template <> struct WGeom<0> { static constexpr int PS = 113; };
 template <> struct WGeom<1> { static constexpr int PS = 241; };
 template <> struct WGeom<2> { static constexpr int PS = 289; };
 
-template <int GK> struct XItems {
-    using G = Geom<GK>;
-    static constexpr int HR = G::TH + 2, HC = G::TW + 2, NHP = G::IMG * HR * HC, NHP8 = (NHP + 7) & ~7;
-    static constexpr int N = (NHP8 * 4 + 255) / 256;      // float4 items per thread
-};
-
-// Item -> (halo pixel, plane) decode shared by the load and store halves.
-template <int GK>
-__device__ __forceinline__ bool x_item(int i, int n0, int y0, int x0, int np, const ConvP &p,
-                                       int &q, int &lds_slot, int &n, int &y, int &x, bool &inb) {
-    using X = XItems<GK>;
-    using G = Geom<GK>;
-    q = (i >> 3) & 3;
-    const int hp = ((i >> 5) << 3) + (i & 7);
-    if (hp >= X::NHP) return false;
-    const int img = hp / (X::HR * X::HC);
-    const int rem = hp - img * (X::HR * X::HC);
-    const int hy = rem / X::HC, hx = rem - hy * X::HC;
-    n = n0 + img; y = y0 + hy - 1; x = x0 + hx - 1;
-    lds_slot = (img * X::HR + hy) * G::R + hx;
-    inb = q < np && n < p.n && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-    return true;
-}
-
-// Global -> registers, RAW (no arithmetic on the loaded values: the loads stay in
-// flight under the MFMAs of the current tile; transforms happen in store_x).
-// MODE 0: one float4 per item; MODE 1: the four float4 of the 2x2 pooling window.
-template <int GK, int MODE>
-__device__ __forceinline__ void load_x(f32x4 (*xr)[MODE ? 4 : 1], const ConvP &p,
-                                       int n0, int y0, int x0, int c0, int np, int tid) {
-    using X = XItems<GK>;
-#pragma unroll
-    for (int k = 0; k < X::N; ++k) {
-        int q, slot, n, y, x; bool inb;
-        const bool ok = x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb);
-#pragma unroll
-        for (int w = 0; w < (MODE ? 4 : 1); ++w) xr[k][w] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok && inb) {
-            const int c = c0 + q * 4;
-            if (MODE == 0) {
-                const int sh = p.a.shift, C = p.a.C;
-                const size_t base = (((size_t)n * (p.H << sh) + (y << sh)) * (p.W << sh) + (x << sh)) * C;
-                if ((C & 3) == 0) {
-                    xr[k][0] = *(const f32x4 *)(p.a.x + base + c);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xr[k][0][j] = (c + j < C) ? p.a.x[base + c + j] : 0.f;
-                }
-            } else {
-                const int W2 = p.W * 2;
-                const float *s = p.v + (((size_t)n * (p.H * 2) + 2 * y) * W2 + 2 * x) * p.Cv + c;
-                xr[k][0] = *(const f32x4 *)s;
-                xr[k][1] = *(const f32x4 *)(s + p.Cv);
-                xr[k][MODE ? 2 : 0] = *(const f32x4 *)(s + (size_t)W2 * p.Cv);
-                xr[k][MODE ? 3 : 0] = *(const f32x4 *)(s + (size_t)W2 * p.Cv + p.Cv);
-            }
-        }
-    }
-}
-
-template <int GK, int PS, int MODE>
-__device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[MODE ? 4 : 1], const ConvP &p,
-                                        const float *cA, int n0, int y0, int x0, int c0, int np, int tid) {
-    using X = XItems<GK>;
-#pragma unroll
-    for (int k = 0; k < X::N; ++k) {
-        int q, slot, n, y, x; bool inb;
-        if (!x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb)) continue;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (inb) {
-            if (MODE == 0) {
-                v = xr[k][0];
-                if (p.a.mode != MPNN_ACT_IDENTITY) {
-                    const int c = c0 + q * 4;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float *cc = cA + (c + j) * 3;
-                        v[j] = (c + j < p.a.C) ? fmaxf((v[j] - cc[0]) * cc[1] + cc[2], 0.f) : 0.f;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    v[j] = fmaxf(fmaxf(xr[k][0][j], xr[k][1][j]), fmaxf(xr[k][MODE ? 2 : 0][j], xr[k][MODE ? 3 : 0][j]));
-            }
-        }
-        tile[q * PS + slot] = v;
-    }
-}
-
 template <int GK, int OT>
 __device__ __forceinline__ void load_g(f32x4 *gr, const WgP &p, int n0, int y0, int x0, int co0, int tid) {
 #pragma unroll
@@ -192,13 +102,13 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     int n0, y0, x0, cn0 = 0, cy0 = 0, cx0 = 0;
     if (t < p.n_tiles) {
         tile_origin<GK>(c, t, n0, y0, x0);
-        load_x<GK, PART>(xr, c, n0, y0, x0, ch * 16, np, tid);
+        load_x<GK, PART, (PART ? 4 : 1)>(xr, c, n0, y0, x0, ch * 16, np, tid);
         load_g<GK, OT>(gr, p, n0, y0, x0, co0, tid);
         cn0 = n0; cy0 = y0; cx0 = x0;
     }
     for (; t < p.n_tiles; t += gridDim.x) {
         __syncthreads();                               // previous tile's LDS reads are done
-        store_x<GK, PS, PART>(tile, xr, c, cA, cn0, cy0, cx0, ch * 16, np, tid);
+        store_x<GK, PS, PART, (PART ? 4 : 1)>(tile, xr, c, cA, cn0, cy0, cx0, ch * 16, np, tid);
 #pragma unroll
         for (int k = 0; k < OT; ++k) {
             const int i = tid + k * 256;
@@ -208,7 +118,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         const int tn = t + gridDim.x;
         if (tn < p.n_tiles) {                          // next tile's loads fly under the MFMAs
             tile_origin<GK>(c, tn, n0, y0, x0);
-            load_x<GK, PART>(xr, c, n0, y0, x0, ch * 16, np, tid);
+            load_x<GK, PART, (PART ? 4 : 1)>(xr, c, n0, y0, x0, ch * 16, np, tid);
             load_g<GK, OT>(gr, p, n0, y0, x0, co0, tid);
             cn0 = n0; cy0 = y0; cx0 = x0;
         }

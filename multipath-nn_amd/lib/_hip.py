@@ -20,16 +20,18 @@ P = C.c_void_p
 
 class Act(C.Structure):
     _fields_ = [('x', P), ('sum', P), ('gamma', P), ('beta', P), ('m_avg', P), ('v_avg', P),
-                ('eps', C.c_float), ('cnt', C.c_int), ('C', C.c_int), ('shift', C.c_int), ('mode', C.c_int)]
+                ('eps', C.c_float), ('cnt', C.c_int), ('C', C.c_int), ('shift', C.c_int), ('mode', C.c_int),
+                ('nslot', C.c_int)]
 
 
 class ConvFwdArgs(C.Structure):
     _fields_ = [('a', Act), ('v', P), ('Cv', C.c_int), ('wa_pack', P), ('wv_pack', P), ('bias', P),
-                ('out', P), ('out_sum', P), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int)]
+                ('out', P), ('out_sum', P), ('out_nslot', C.c_int), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int),
+                ('Cout', C.c_int)]
 
 
 class BnCtx(C.Structure):
-    _fields_ = [('s', P), ('bn', Act), ('red', P)]
+    _fields_ = [('s', P), ('bn', Act), ('red', P), ('red_nslot', C.c_int)]
 
 
 class DgradHorzArgs(C.Structure):
@@ -138,10 +140,11 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def act(x=None, C_=0, mode=ACT_IDENTITY, shift=0, bn=None, cnt=1):
+def act(x=None, C_=0, mode=ACT_IDENTITY, shift=0, bn=None, cnt=1, nslot=BN_SLOTS):
     """Build an mpnn_act.  bn = dict(sum=, gamma=, beta=, m_avg=, v_avg=, eps=) of tensors."""
     a = Act()
     a.x = ptr(x); a.C = int(C_); a.mode = int(mode); a.shift = int(shift); a.cnt = int(cnt)
+    a.nslot = int(bn.get('nslot', nslot)) if bn is not None else int(nslot)
     if bn is not None:
         a.sum = ptr(bn.get('sum')); a.gamma = ptr(bn['gamma']); a.beta = ptr(bn['beta'])
         a.m_avg = ptr(bn['m_avg']); a.v_avg = ptr(bn['v_avg']); a.eps = float(bn['eps'])

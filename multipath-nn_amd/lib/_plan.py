@@ -82,6 +82,10 @@ class Engine:
         torch.cuda.set_device(self.dev)
         self.n_max = 0
         self.use_graph = bool(int(os.environ.get('MPNN_GRAPH', '0')))
+        self.multi_stream = bool(int(os.environ.get('MPNN_STREAMS', '0')))
+        self._streams = []
+        self._event_keep = []
+        self.n_streams = 1
         self.world = 1
         self.allreduce = None            # callable(G) installed by lib/_dp.py
         self._keep = []
@@ -268,7 +272,7 @@ class Engine:
                 bn = b.bns[i].params
                 b.sum_off.append(doff)
                 tab += [doff, bn.m_avg.offset, bn.v_avg.offset, b.C[i], b.H[i] * b.W[i],
-                        bn.γ.offset if b.has_dz[i] else -1, bn.β.offset, 0]
+                        bn.γ.offset if b.has_dz[i] else -1, bn.β.offset, self._nslot(b, i)]
                 doff += 2 * b.C[i] * _hip.BN_SLOTS
         self.dsum = torch.zeros(max(doff, 1), dtype=torch.float64, device=dev)
         self.dred = torch.zeros(max(doff, 1), dtype=torch.float64, device=dev)
@@ -347,10 +351,17 @@ class Engine:
         self.r, self.dr = z(ns * n * self.max_sinks), z(ns * n * self.max_sinks)
 
     # ------------------------------------------------------------------ programs
+    @staticmethod
+    def _nslot(b, i):
+        """Statistics slots of scale i: many workgroups -> many slots; few -> few (every consumer
+        workgroup re-adds the slots in its prologue)."""
+        return {32: 16, 16: 16, 8: 8}.get(b.H[i], 4)
+
     def _bn(self, b, i, with_sum=True):
         bn = b.bns[i].params
         return dict(sum=self.dsum[b.sum_off[i]:] if with_sum else None, gamma=bn.γ.data, beta=bn.β.data,
-                    m_avg=bn.m_avg.data, v_avg=bn.v_avg.data, eps=float(b.bns[i].hypers.ϵ))
+                    m_avg=bn.m_avg.data, v_avg=bn.v_avg.data, eps=float(b.bns[i].hypers.ϵ),
+                    nslot=self._nslot(b, i))
 
     def _act_of_input(self, b, i, n, mode):
         """mpnn_act of the block's input at scale i."""
@@ -364,6 +375,7 @@ class Engine:
         ctx.s = b.s[i].data_ptr()
         ctx.bn = _hip.act(None, b.C[i], _hip.ACT_BN_BATCH, 0, self._bn(b, i), n * b.H[i] * b.W[i])
         ctx.red = self.dred[b.sum_off[i]:].data_ptr() if with_red else None
+        ctx.red_nslot = self._nslot(b, i)
         self._keep.append(ctx)
         return ctx
 
@@ -389,13 +401,33 @@ class Engine:
         ϕ = net.hypers
         fwd, bwd = [], []
 
-        def call(fn, what, *args, flops=0.0, tag=''):
+        def call(fn, what, *args, flops=0.0, tag='', stream=0, waits=(), records=None):
             def launch(st):
                 _hip.check(fn(*args, st), what)
             launch.what, launch.flops, launch.tag = what, float(flops), tag
+            launch.stream, launch.waits, launch.records = stream, tuple(waits), records
             return launch
 
+        def marker(kind):                     # 'fork' / 'join' of the side streams
+            def launch(st):
+                pass
+            launch.what, launch.flops, launch.tag = kind, 0.0, ''
+            launch.stream, launch.waits, launch.records = 0, (), None
+            return launch
+
+        # Streams: 0 = main (the 4x4 maps: the critical path through every block); 1.. = one per
+        # larger map size; the last two = weight-gradient side streams (leaves of the DAG).
+        sizes = sorted({h for b in self.blocks for h in b.H}, reverse=True)
+        sid = {h: (0 if h == sizes[-1] else 1 + k) for k, h in enumerate(sizes)}
+        n_scale_streams = len(sizes)
+        wg_streams = (n_scale_streams, n_scale_streams + 1)
+        self.n_streams = n_scale_streams + 2
+        bid = {id(b): k for k, b in enumerate(self.blocks)}
+        F = lambda b, i: 'F%d_%d' % (bid[id(b)], i)
+        Gn = lambda b, i: 'G%d_%d' % (bid[id(b)], i)
+
         # ---- forward convs ----
+        fwd.append(marker('fork'))
         for b in self.blocks:
             cp = b.conv.params
             for i in range(b.L):
@@ -408,11 +440,15 @@ class Engine:
                 a.bias = getattr(cp, 'b_%i' % i).data.data_ptr()
                 a.out = b.s[i].data_ptr()
                 a.out_sum = self.dsum[b.sum_off[i]:].data_ptr() if mode == 'tr' else None
+                a.out_nslot = self._nslot(b, i)
                 a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
                 keep.append(a)
                 fl = 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
                 fwd.append(call(lib.mpnn_msconv_fwd, 'msconv_fwd', C.byref(a), flops=fl,
-                                tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])))
+                                tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i]),
+                                stream=sid[b.H[i]], waits=[F(b, i - 1)] if i > 0 else [], records=F(b, i)))
+
+        fwd.append(marker('join'))
 
         # ---- exits ----
         dyn = bool(getattr(ϕ, 'dyn_k_cpt', False))
@@ -510,6 +546,7 @@ class Engine:
         if n_exit:
             bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
             bwd.append(call(lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
+        bwd.append(marker('fork'))
         for b in reversed(self.blocks):
             cp = b.conv.params
             L1 = b.L - 1
@@ -518,10 +555,10 @@ class Engine:
                 ctx = self._bn_ctx(b, L1, n, with_red=False)
                 bwd.append(call(lib.mpnn_bn_bwd_reduce, 'bn_bwd_reduce', b.dx.data_ptr(), C.byref(ctx),
                                 b.dzg[L1].data_ptr(), self.dred[b.sum_off[L1]:].data_ptr(),
-                                n * b.H[L1] * b.W[L1]))
+                                n * b.H[L1] * b.W[L1], stream=sid[b.H[L1]]))
             ctx = self._bn_ctx(b, L1, n)
             bwd.append(call(lib.mpnn_bn_bwd_apply, 'bn_bwd_apply', b.dzg[L1].data_ptr(), C.byref(ctx),
-                            n * b.H[L1] * b.W[L1]))
+                            n * b.H[L1] * b.W[L1], stream=sid[b.H[L1]], records=Gn(b, L1)))
             for i in range(L1, 0, -1):
                 a = _hip.DgradVertArgs()
                 fine = self._bn_ctx(b, i - 1, n)
@@ -534,7 +571,8 @@ class Engine:
                 keep.append(a)
                 bwd.append(call(lib.mpnn_msconv_dgrad_vert, 'dgrad_vert', C.byref(a),
                                 flops=2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * b.C[i - 1],
-                                tag='h%d %d->%d' % (b.H[i], b.C[i], b.C[i - 1])))
+                                tag='h%d %d->%d' % (b.H[i], b.C[i], b.C[i - 1]),
+                                stream=sid[b.H[i - 1]], waits=[Gn(b, i)], records=Gn(b, i - 1)))
             for i in range(b.L):
                 a = _hip.WgradArgs()
                 a.a = self._act_of_input(b, i, n, act_mode)
@@ -568,7 +606,8 @@ class Engine:
                 keep.append(a)
                 fl = 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
                 bwd.append(call(lib.mpnn_msconv_wgrad, 'wgrad', C.byref(a), flops=fl,
-                                tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])))
+                                tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i]),
+                                stream=wg_streams[i % 2], waits=[Gn(b, i)]))
             if b.parent is not None:
                 pb = b.parent
                 for i in range(b.L):
@@ -585,7 +624,8 @@ class Engine:
                     keep.append(a)
                     bwd.append(call(lib.mpnn_msconv_dgrad_horz, 'dgrad_horz', C.byref(a),
                                     flops=2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * pb.C[j],
-                                    tag='h%d %d->%d' % (b.H[i], b.C[i], pb.C[j])))
+                                    tag='h%d %d->%d' % (b.H[i], b.C[i], pb.C[j]), stream=sid[b.H[i]]))
+        bwd.append(marker('join'))
         if slab_plan['size']:
             slab = torch.empty(slab_plan['size'], device=self.dev)
             for a, field, off in slab_plan['ptrs']:
@@ -636,11 +676,56 @@ class Engine:
         self.hyp.copy_(h, non_blocking=True)
         return n, feed.get(net.mode, net.mode.default)
 
-    def _launch(self, ops):
-        st = torch.cuda.current_stream().cuda_stream
+    def _launch(self, ops, sec=0):
+        """Run a program section.  Sequential order is a valid topological order; with
+        ``multi_stream`` the independent launches of the per-scale dependency DAG go to side
+        streams (under graph capture they become parallel branches of the hipGraph)."""
+        main = torch.cuda.current_stream()
+        if not self.multi_stream:
+            for op in ops:
+                op(main.cuda_stream)
+            return
+        # One set of side streams per section: re-forking streams that were already joined inside
+        # the same hipGraph capture crashes hipStreamEndCapture (ROCm 7.2).
+        while len(self._streams) <= sec:
+            self._streams.append(None)
+        if self._streams[sec] is None or len(self._streams[sec]) < self.n_streams - 1:
+            self._streams[sec] = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_streams - 1)]
+        streams = [main] + self._streams[sec][:self.n_streams - 1]
+        events, forked = {}, False
+        keep = self._event_keep            # events must outlive an open graph capture (HIP)
         for op in ops:
-            op(st)
-
+            if op.what == 'fork':
+                e = torch.cuda.Event()
+                keep.append(e)
+                e.record(main)
+                for s_ in streams[1:]:
+                    s_.wait_event(e)
+                forked = True
+                continue
+            if op.what == 'join':
+                # every forked stream rejoins main, used or not (a stream left dangling inside a
+                # graph capture is an error)
+                for s_ in streams[1:]:
+                    e = torch.cuda.Event()
+                    keep.append(e)
+                    e.record(s_)
+                    main.wait_event(e)
+                forked = False
+                continue
+            st = streams[op.stream]
+            for w in op.waits:
+                ev = events.get(w)
+                if ev is not None and ev[0] != op.stream:
+                    st.wait_event(ev[1])
+            with torch.cuda.stream(st):
+                op(st.cuda_stream)
+            if op.records:
+                e = torch.cuda.Event()
+                keep.append(e)
+                e.record(st)
+                events[op.records] = (op.stream, e)
+        assert not forked, 'program section ended with side streams still forked'
     def _zero(self, train):
         self.loss.zero_()
         if train:
@@ -662,11 +747,14 @@ class Engine:
     def _phase_a(self, prog, train):
         self._zero(train)
         self._pack()
-        self._launch(prog['fwd'])
+        self._launch(prog['fwd'], 0)
         if train:
-            self._launch(prog['bwd'])
+            self._launch(prog['bwd'], 1)
 
     def run(self, feed, train):
+        if len(self._event_keep) > 4096:
+            torch.cuda.synchronize()
+            self._event_keep.clear()
         n, mode = self._stage(feed)
         if train and mode != 'tr':
             raise ValueError("net.train.run needs net.mode: 'tr' in the feed")
@@ -720,7 +808,7 @@ class Engine:
         stream is the stream every kernel of the plan is launched on).  Returns
         [(what, tag, flops, mean_ms)] for one (mode, n) program, forward then backward."""
         prog = self.program(mode, n)
-        ops = list(prog['fwd']) + (list(prog['bwd']) if mode == 'tr' else [])
+        ops = [o for o in list(prog['fwd']) + (list(prog['bwd']) if mode == 'tr' else []) if o.what not in ('fork', 'join')]
         st = torch.cuda.current_stream()
         out = []
         self._zero(mode == 'tr')

@@ -81,7 +81,7 @@ def conv_fwd(x, wh, b, v=None, wv=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0
     a.a = _hip.act(xd, x.shape[3], mode, shift, bn, bn_cnt)
     a.v = _hip.ptr(vd); a.Cv = v.shape[3] if v is not None else 0
     a.wa_pack = fw[0].data_ptr(); a.wv_pack = fw[1].data_ptr() if wv is not None else None
-    a.bias = bd.data_ptr(); a.out = out.data_ptr(); a.out_sum = osum.data_ptr()
+    a.bias = bd.data_ptr(); a.out = out.data_ptr(); a.out_sum = osum.data_ptr(); a.out_nslot = _hip.BN_SLOTS
     a.n, a.H, a.W, a.Cout = n, H, W, co
     _hip.check(lib.mpnn_msconv_fwd(C.byref(a), stream()), 'msconv_fwd')
     torch.cuda.synchronize()
@@ -93,6 +93,7 @@ def bn_ctx(s_dev, C_, bn, cnt, mode=_hip.ACT_BN_BATCH, red=None):
     ctx.s = s_dev.data_ptr()
     ctx.bn = _hip.act(None, C_, mode, 0, bn, cnt)
     ctx.red = _hip.ptr(red)
+    ctx.red_nslot = _hip.BN_SLOTS
     return ctx
 
 
