@@ -1,0 +1,93 @@
+"""Datasets and host-side augmentation.
+
+Counterpart of the reference's ``scripts/lib/data.py``: same ``Dataset`` API, same
+archive format (a pickled dict in ``arr_0`` of an ``.npz``; prep-data:60,134-136,191)
+and the SAME random-number law, draw for draw, on ``numpy.random``'s global stream:
+per sample ``randint(0, N)``, then ``rand() < 0.5`` for a flip if the class is
+symmetric, then ``randint(-r, r + 1, 2)`` for the shift (data.py:10-34).  Seeding
+numpy therefore reproduces the reference's batches bit for bit
+(tests/golden/data_aug_golden.npz was produced by the reference module).
+
+Unlike the reference's per-sample copy loop, the pixels are moved with one
+vectorised gather per batch; the mean fill (data.py:19) is per image and channel.
+"""
+import numpy as np
+import numpy.random as rand
+
+__all__ = ['Dataset']
+
+
+def _draw_augmentation(n, n_src, y, m_sym, r_shift):
+    """The reference's RNG call sequence (data.py:24-34), without touching pixels."""
+    j = np.empty(n, np.int64); flip = np.zeros(n, bool); sh = np.zeros((n, 2), np.int64)
+    for i in range(n):
+        j[i] = rand.randint(0, n_src)
+        if m_sym[np.argmax(y[j[i]])]:
+            flip[i] = not (rand.rand() < 0.5)          # rand_flip keeps `a` when rand() < 0.5
+        sh[i] = rand.randint(-r_shift, r_shift + 1, 2)
+    return j, flip, sh
+
+
+def augmented_batch(x0, y, n, m_sym, r_shift):
+    j, flip, sh = _draw_augmentation(n, len(x0), y, m_sym, r_shift)
+    h, w = x0.shape[1:3]
+    src = x0[j].astype(np.float64)
+    src[flip] = src[flip][:, :, ::-1]
+    u = np.arange(h)[None, :] + sh[:, 0:1]             # b[u, v] = a[u + du, v + dv]
+    v = np.arange(w)[None, :] + sh[:, 1:2]
+    ok = ((u >= 0) & (u < h))[:, :, None] & ((v >= 0) & (v < w))[:, None, :]
+    out = src[np.arange(n)[:, None, None], np.clip(u, 0, h - 1)[:, :, None], np.clip(v, 0, w - 1)[:, None, :]]
+    fill = src.mean(axis=(1, 2))
+    out = np.where(ok[..., None], out, fill[:, None, None, :])
+    return out, y[j].astype(np.float64)
+
+
+def batch(x0, y, n):
+    i = rand.randint(0, len(x0), n)
+    return np.take(x0, i, axis=0), np.take(y, i, axis=0)
+
+
+def full_set(x0, y, n):
+    for i in range(0, len(x0), n):
+        yield x0[i:i + n], y[i:i + n]
+
+
+class Dataset:
+    def __init__(self, path=None, arrays=None):
+        archive = arrays if arrays is not None else np.load(path, allow_pickle=True)['arr_0'][()]
+        self.x0_tr, self.x0_ts = archive['x0_tr'], archive['x0_ts']
+        self.y_tr, self.y_ts = archive['y_tr'], archive['y_ts']
+        self.m_sym = archive['m_sym']
+        self.x0_vl, self.y_vl = self.x0_tr[:0], self.y_tr[:0]
+
+    @classmethod
+    def synthetic(cls, n_tr=1024, n_ts=256, shape=(32, 32, 3), n_cls=10, seed=0):
+        """Stand-in with the statistics the benchmark uses (uniform pixels, uniform labels)."""
+        g = np.random.default_rng(seed)
+        mk = lambda n: (g.random((n,) + tuple(shape), dtype=np.float32),
+                        np.eye(n_cls, dtype=np.float32)[g.integers(0, n_cls, n)])
+        (x_tr, y_tr), (x_ts, y_ts) = mk(n_tr), mk(n_ts)
+        return cls(arrays=dict(x0_tr=x_tr, y_tr=y_tr, x0_ts=x_ts, y_ts=y_ts, m_sym=np.ones(n_cls, bool)))
+
+    @property
+    def x0_shape(self):
+        return self.x0_tr.shape[1:]
+
+    @property
+    def y_shape(self):
+        return self.y_tr.shape[1:]
+
+    def augmented_training_batch(self, n=128, r_shift=4):
+        return augmented_batch(self.x0_tr, self.y_tr, n, self.m_sym, r_shift)
+
+    def training_batch(self, n=128):
+        return batch(self.x0_tr, self.y_tr, n)
+
+    def test_batch(self, n=128):
+        return batch(self.x0_ts, self.y_ts, n)
+
+    def training_set(self, n=128):
+        yield from full_set(self.x0_tr, self.y_tr, n)
+
+    def test_set(self, n=128):
+        yield from full_set(self.x0_ts, self.y_ts, n)

@@ -1,0 +1,61 @@
+"""Network descriptors: dataset-averaged statistics in the reference's schema.
+
+Counterpart of ``scripts/lib/desc.py``: ``net_desc`` returns
+``{type, stats_tr, stats_ts, root: {name, stats_tr, stats_ts, sinks: [...]}}`` with every
+statistic of ``state_tensors`` (scripts/train-nets:117-130) averaged over the FULL training
+and test sets in evaluation mode (desc.py:10-36), so the reference's figure scripts can
+read the ``*-stats.npy`` files this build writes.  ``render_net_desc`` is a plain-text
+summary (cosmetic; not byte-compatible with the reference's box drawing).
+"""
+import numpy as np
+
+__all__ = ['net_desc', 'render_net_desc']
+
+
+def mean_net_state(net, data, hypers):
+    """One evaluation pass per batch; per-sample statistics are summed on the device and
+    divided by the sample count at the end (desc.py:10-22)."""
+    sums, count = None, 0
+    for x0, y in data:
+        net.eval({net.x0: x0, net.y: y, **hypers})
+        state = net.state()
+        part = {k: v.sum(0).double() for k, v in state.items()}
+        sums = part if sums is None else {k: sums[k] + part[k] for k in part}
+        count += len(x0)
+    if sums is None:
+        return {}
+    return {k: (v / count).cpu().numpy().tolist() for k, v in sums.items()}
+
+
+def layer_desc(ℓ, stats_tr, stats_ts):
+    pick = lambda st: {k: v for (t, k), v in st.items() if t is ℓ}
+    return {'name': ℓ.name, 'stats_tr': pick(stats_tr), 'stats_ts': pick(stats_ts),
+            'sinks': [layer_desc(s, stats_tr, stats_ts) for s in ℓ.sinks]}
+
+
+def net_desc(net, dataset, hypers={}, state=None):
+    stats_tr = mean_net_state(net, dataset.training_set(), hypers)
+    stats_ts = mean_net_state(net, dataset.test_set(), hypers)
+    pick = lambda st: {k: v for (t, k), v in st.items() if t is net}
+    return {'type': type(net).__name__, 'stats_tr': pick(stats_tr), 'stats_ts': pick(stats_ts),
+            'root': layer_desc(net.root, stats_tr, stats_ts)}
+
+
+def _scalars(stats):
+    items = sorted((k, v) for k, v in stats.items() if np.ndim(v) == 0)
+    return '(' + '; '.join('%s=%.3g' % kv for kv in items) + ')' if items else ''
+
+
+def _render_layer(d, key, depth):
+    lines = ['%s%s %s' % ('  ' * depth, d['name'], _scalars(d[key]))]
+    for s in d['sinks']:
+        lines += _render_layer(s, key, depth + 1)
+    return lines
+
+
+def render_net_desc(desc, name='Network'):
+    out = ['== %s ==' % name]
+    for title, key in (('Training Set', 'stats_tr'), ('Test Set', 'stats_ts')):
+        out += ['%s: [%s] %s' % (title, desc['type'], _scalars(desc[key]))]
+        out += _render_layer(desc['root'], key, 1)
+    return '\n'.join(out)

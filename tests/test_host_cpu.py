@@ -1,0 +1,126 @@
+"""CPU: host-side logic and the C-ABI boundary (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'mpnn_hip.h')
+
+
+def test_library_exports_every_declared_symbol():
+    from lib import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    declared = set(re.findall(r'^(?:int|const char \*)\s*(mpnn_\w+)\(', open(HEADER).read(), re.M))
+    assert declared and declared == set(_hip.EXPORTS), declared ^ set(_hip.EXPORTS)
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    lib.mpnn_version.restype = ctypes.c_char_p
+    assert b'gfx950' in lib.mpnn_version()
+    # a pure-host entry point may be called without a GPU
+    assert lib.mpnn_wgrad_tiles(128, 32, 32) == 2048 and lib.mpnn_wgrad_tiles(128, 4, 4) == 32
+    assert lib.mpnn_wgrad_tiles(5, 4, 4) == 2 and lib.mpnn_wgrad_tiles(1, 7, 7) == -1
+
+
+def test_ctypes_structs_match_the_c_layout():
+    """sizeof/offsetof of every argument record, as gcc sees the header, vs. the ctypes mirror."""
+    from lib import _hip
+    pairs = [('mpnn_act', _hip.Act), ('mpnn_conv_fwd_args', _hip.ConvFwdArgs), ('mpnn_bn_ctx', _hip.BnCtx),
+             ('mpnn_dgrad_horz_args', _hip.DgradHorzArgs), ('mpnn_dgrad_vert_args', _hip.DgradVertArgs),
+             ('mpnn_wgrad_args', _hip.WgradArgs), ('mpnn_lin_fwd_args', _hip.LinFwdArgs),
+             ('mpnn_lin_bwd_args', _hip.LinBwdArgs), ('mpnn_exit_tail_args', _hip.ExitTailArgs),
+             ('mpnn_exit_tail_bwd_args', _hip.ExitTailBwdArgs), ('mpnn_route_args', _hip.RouteArgs)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mpnn_hip.h"', 'int main(void){']
+    for cname, cls in pairs:
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, f))
+        lines.append('printf("\\n");')
+    lines.append('return 0;}')
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, 'a.c'), os.path.join(d, 'a.out')
+        open(src, 'w').write('\n'.join(lines))
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), src, '-o', exe])
+        out = subprocess.check_output([exe]).decode().splitlines()
+    for (cname, cls), line in zip(pairs, out):
+        nums = [int(x) for x in line.split()[1:]]
+        assert nums[0] == ctypes.sizeof(cls), (cname, nums[0], ctypes.sizeof(cls))
+        assert nums[1:] == [getattr(cls, f).offset for f, _ in cls._fields_], cname
+    for name, val in re.findall(r'#define (MPNN_\w+)\s+\(?(-?\d+)\)?', open(HEADER).read()):
+        py = {'MPNN_BN_SLOTS': _hip.BN_SLOTS, 'MPNN_MAX_NODES': _hip.MAX_NODES, 'MPNN_MAX_SINKS': _hip.MAX_SINKS,
+              'MPNN_HYP_N': _hip.HYP_N, 'MPNN_HYP_TAU': _hip.HYP_TAU, 'MPNN_HYP_EPS': _hip.HYP_EPS,
+              'MPNN_NET_CRITIC': _hip.NET_CRITIC, 'MPNN_ACT_BN_MOVING': _hip.ACT_BN_MOVING}.get(name)
+        if py is not None:
+            assert py == int(val), name
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import arch_and_hypers as A
+    from lib._hip import HipError
+    net = A.sr_chain(1)((32, 32, 3), (10,))
+    with pytest.raises(HipError):
+        net.train.run({net.x0: np.zeros((2, 32, 32, 3)), net.y: np.zeros((2, 10)), net.mode: 'tr'})
+
+
+def test_operator_surface_and_unicode_keywords():
+    import arch_and_hypers as A
+    from lib import layer_types as L, net_types as N
+    for name in ['BatchNorm', 'Chain', 'CrossEntropyError', 'LinTrans', 'MultiscaleBatchNorm', 'MultiscaleConvMax',
+                 'MultiscaleLLN', 'MultiscaleRect', 'Rect', 'Select', 'Softmax', 'ToPyramid', 'Conv', 'MaxPool',
+                 'GlobalMaxPool', 'NoOp', 'Dropout', 'SquaredError', 'Layer']:
+        assert hasattr(L, name)
+    net = A.cr_chain(k_cpt=1e-9, optimistic=True)((32, 32, 3), (10,))
+    assert isinstance(net, N.CriticNet) and net.hypers.optimistic and net.hypers.τ == 0.01
+    # keyword identifiers are NFKC-normalised by Python; string lookups must agree (lib/_plan.py:_attr)
+    from lib._plan import _attr
+    assert _attr(net.hypers, 'ϵ') == 1e-6 and _attr(net.hypers, 'α_cpt') == 1e7
+    blk = [ℓ for ℓ in net.layers if ℓ.name == 'ReConvMax'][0]
+    conv = blk.comps[0]
+    assert conv.params.w_horz_0.shape == (3, 3, 3, 16) and conv.params.w_vert_2.shape == (3, 3, 16, 16)
+    assert blk.router.comps[-1].params.w.init == ('normal', 0.0)          # σ_w = 0: routers start at zero
+    assert [s.shape for s in blk.x] == [(32, 32, 16), (16, 16, 16), (8, 8, 16), (4, 4, 16)]
+    dyn = A.ac_chain(dyn_k_cpt=True)((32, 32, 3), (10,))
+    r0 = [ℓ for ℓ in dyn.layers if ℓ.router][0].router
+    assert r0.comps[1].params.w.shape == (257, 16)                         # flatten(4x4x16) + k_cpt column
+    with pytest.raises(NotImplementedError):
+        L.MultiscaleLLN().link([L.Sym((4, 4, 3))], None, 'tr')
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/scripts/arch_and_hypers.py'), reason='reference not mounted')
+def test_reference_spec_file_drops_in_unchanged():
+    """The reference's own arch_and_hypers.py, imported against THIS lib/ (same module names)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_arch', '/root/reference/scripts/arch_and_hypers.py')
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    import arch_and_hypers as A
+    for mk_ref, mk in ((ref.sr_chain(5), A.sr_chain(5)), (ref.ac_chain(k_cpt=2e-9), A.ac_chain(k_cpt=2e-9)),
+                       (ref.cr_chain(k_cpt=0.0, use_cls_err=True), A.cr_chain(k_cpt=0.0, use_cls_err=True))):
+        a, b = mk_ref((32, 32, 3), (10,)), mk((32, 32, 3), (10,))
+        assert type(a).__name__ == type(b).__name__ and vars(a.hypers) == vars(b.hypers)
+        la, lb = list(a.layers), list(b.layers)
+        assert [ℓ.name for ℓ in la] == [ℓ.name for ℓ in lb] and [ℓ.n_ops for ℓ in la] == [ℓ.n_ops for ℓ in lb]
+        assert [(p.name, p.shape, p.init) for p in a._all_params] == [(p.name, p.shape, p.init) for p in b._all_params]
+    assert (ref.arch, ref.k_cpts, ref.n_iter) == (A.arch, A.k_cpts, A.n_iter)
+
+
+def test_train_nets_experiment_keys():
+    import runpy
+    ns = runpy.run_path(os.path.join(ROOT, 'multipath-nn_amd', 'train-nets'), run_name='not_main')
+    keys = set(ns['experiments'])
+    assert {'hybrid-sr', 'hybrid-ac', 'hybrid-ac-nokdec', 'hybrid-ac-notalr', 'hybrid-ac-tree', 'hybrid-cr',
+            'hybrid-cr-opt', 'hybrid-cr-clserr', 'hybrid-cr-notalr', 'cifar2-sr', 'cifar2-ac', 'cifar5-sr',
+            'cifar5-ac', 'cifar10-sr', 'cifar10-ac'} <= keys            # scripts/train-nets:28-88
+    assert {'cifar10-cr', 'mnist-sr'} <= keys                             # BASELINE.json configs
+    assert len(ns['experiments']['cifar10-ac'].nets) == 8 and len(ns['experiments']['cifar10-sr'].nets) == 8
