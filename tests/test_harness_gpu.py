@@ -1,0 +1,111 @@
+"""GPU: the callers either side of the hot path (SURVEY 8 a16 and the 'next' rows): on-device
+branch compaction, dataset-averaged statistics in the reference's schema, save/load, the
+train-nets driver."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 128, 1000, 1024, 1025, 5000])
+def test_compact_by_branch(n):
+    """Ordered indices of the samples that reach a node (p_ev > 0) and their count, on device:
+    wave64 ballot + popcount prefix (empty, ragged and multi-pass sizes)."""
+    from lib import _hip
+    lib = _hip.load()
+    rng = np.random.default_rng(n)
+    for frac in (0.0, 0.3, 1.0):
+        p = (rng.random(n) < frac).astype(np.float32)
+        pd = torch.from_numpy(p).cuda()
+        idx = torch.full((n,), -1, dtype=torch.int32, device='cuda')
+        cnt = torch.zeros(1, dtype=torch.int32, device='cuda')
+        _hip.check(lib.mpnn_compact_by_branch(pd.data_ptr(), n, idx.data_ptr(), cnt.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), 'compact')
+        want = np.nonzero(p > 0)[0]
+        assert int(cnt.item()) == len(want)
+        assert np.array_equal(idx.cpu().numpy()[:len(want)], want)
+
+
+def make_trained_net(steps=6):
+    import arch_and_hypers as A
+    from lib.data import Dataset
+    ds = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+    net = A.ac_chain(k_cpt=1.6e-8, seed=5)(ds.x0_shape, ds.y_shape)
+    np.random.seed(0)
+    for t in range(steps):
+        x0, y = ds.augmented_training_batch(A.batch_size)
+        net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.05, net.τ: A.τ_ds(t)})
+    return net, ds
+
+
+def test_net_desc_schema_and_consistency():
+    """desc.py:24-36 schema; ragged last batches (300 = 2*128 + 44); routing histogram sums to 1;
+    acc = sum of per-leaf p_cor; moc between the first exit's cost and the full chain's."""
+    from lib.desc import net_desc, render_net_desc
+    net, ds = make_trained_net()
+    desc = net_desc(net, ds, {net.τ: 1.0})
+    assert set(desc) == {'type', 'stats_tr', 'stats_ts', 'root'} and desc['type'] == 'ActorNet'
+    for key in ('stats_tr', 'stats_ts'):
+        assert set(desc[key]) == {'acc', 'moc'}
+        leaves, stack = [], [desc['root']]
+        while stack:
+            d = stack.pop()
+            assert set(d) == {'name', 'stats_tr', 'stats_ts', 'sinks'}
+            stack += d['sinks']
+            if not d['sinks']:
+                leaves.append(d)
+        assert len(leaves) == 8
+        for d in leaves:
+            assert set(d[key]) == {'p_cor', 'p_inc', 'p_cor_by_cls', 'p_inc_by_cls', 'p_tr', 'c_err'}
+            assert len(d[key]['p_cor_by_cls']) == 10
+        hist = [d[key]['p_cor'] + d[key]['p_inc'] for d in leaves]
+        assert abs(sum(hist) - 1) < 1e-6
+        assert abs(sum(d[key]['p_cor'] for d in leaves) - desc[key]['acc']) < 1e-6
+        assert 1368608 - 1 <= desc[key]['moc'] <= 20699872 + 1
+        assert abs(sum(d[key]['p_tr'] for d in leaves) - 1) < 1e-4
+    # the first switch carries x_rte (mean |router output|), train-nets:127-128
+    first_block = desc['root']['sinks'][0]
+    assert 'x_rte' in first_block['stats_ts']
+    assert 'ActorNet' in render_net_desc(desc, 'demo')
+
+
+def test_serdes_roundtrip(tmp_path):
+    from lib.serdes import write_net, read_net
+    net, ds = make_trained_net(3)
+    path = str(tmp_path / 'net.npy')
+    write_net(path, net, with_optimizer=True)
+    rec = np.load(path, allow_pickle=True)[()]
+    assert set(rec) == {'type', 'root', 'hypers', 'params'} and rec['type'] == 'ActorNet'      # serdes.py:40-44
+    assert set(rec['root']) >= {'type', 'name', 'hypers', 'params', 'sinks', 'comps', 'router'}
+    net2 = read_net(path)
+    for p, q in zip(net._all_params, net2._all_params):
+        assert (p.name, p.shape) == (q.name, q.shape) and torch.equal(p.data.cpu(), q.data.cpu())
+        if p.trainable:
+            assert torch.equal(p.accum.cpu(), q.accum.cpu())
+    x0, y = next(ds.test_set())
+    net.eval({net.x0: x0, net.y: y}); net2.eval({net2.x0: x0, net2.y: y})
+    a, b = net.state(), net2.state()
+    assert torch.equal(a[(net, 'moc')].cpu(), b[(net2, 'moc')].cpu())
+    # and training continues identically from the restored momentum
+    x0, y = next(ds.training_set())
+    for m in (net, net2):
+        m.train.run({m.x0: x0, m.y: y, m.mode: 'tr', m.λ_lrn: 0.05, m.τ: 1.0})
+    assert np.abs(net.engine().P.cpu().numpy() - net2.engine().P.cpu().numpy()).max() < 1e-6
+
+
+def test_train_nets_cli(tmp_path):
+    out = str(tmp_path / 'nets')
+    cmd = [sys.executable, os.path.join(ROOT, 'multipath-nn_amd', 'train-nets'), 'cifar10-cr', '--synthetic',
+           '--iters', '4', '--log-every', '2', '--nets', '1', '--out', out]
+    subprocess.check_call(cmd, cwd=str(tmp_path))
+    base = os.path.join(out, 'cifar10-cr')
+    for f in ('0001.npy', '0001-stats.npy', '0001-log.txt', '0001-stats/00000002.npy', '0001-stats/00000004.npy'):
+        assert os.path.exists(os.path.join(base, f)), f                      # scripts/train-nets:149-157
+    desc = np.load(os.path.join(base, '0001-stats.npy'), allow_pickle=True)[()]
+    assert desc['type'] == 'CriticNet' and 0 <= desc['stats_ts']['acc'] <= 1
