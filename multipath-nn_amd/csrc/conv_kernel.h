@@ -488,9 +488,13 @@ template <int GK, int EPI>
 static int conv_launch_geom(ConvP &p, bool small_a, hipStream_t st) {
     const int Co = p.Cout;
     if (Co % 16) return MPNN_E_SHAPE;
-    // 4x4 maps have few spatial tiles: prefer narrow channel tiles there.
-    if (Co % 64 == 0 && GK != 2) return conv_launch_cfg<GK, 2, 2, 2, 2, EPI>(p, small_a, st);
-    if (Co % 32 == 0) return conv_launch_cfg<GK, 2, 1, 2, 2, EPI>(p, small_a, st);
+    // Small maps have few spatial tiles and are latency-bound: narrow channel tiles give more,
+    // shorter workgroups there.  MPNN_CONV_CT (16/32/64) overrides the choice for experiments.
+    static const int force = [] { const char *e = getenv("MPNN_CONV_CT"); return e ? atoi(e) : 0; }();
+    int ct = (Co % 64 == 0 && GK == 0) ? 64 : 16;          // measured: 16 beats 32/64 on 8x8 and 4x4 maps
+    if (force && Co % force == 0) ct = force;
+    if (ct == 64) return conv_launch_cfg<GK, 2, 2, 2, 2, EPI>(p, small_a, st);
+    if (ct == 32) return conv_launch_cfg<GK, 2, 1, 2, 2, EPI>(p, small_a, st);
     return conv_launch_cfg<GK, 1, 1, 4, 1, EPI>(p, small_a, st);
 }
 

@@ -6,7 +6,7 @@
 // every exit of the tree), K split over 16 waves in the forward, and ONE
 // backward kernel in which a thread owns a feature k, streams the batch rows
 // (dY broadcast from LDS, X prefetched 16 rows at a time) and produces dX, dW
-// and db in a single deterministic pass (no atomics).
+// and db in a single pass (row groups add their dW/db partials with fp32 atomics).
 #include "common.h"
 
 // ------------------------------- forward ------------------------------------
@@ -93,7 +93,7 @@ extern "C" int mpnn_lin_fwd(const mpnn_lin_fwd_args *dev_table, int count, int n
 //   dX[r][k]   = sum_s sum_m dY_s[r][m] * W_s[k][m]
 //   dW_s[k][m] += act(X)[r][k] * dY_s[r][m]           db_s[m] = sum_r dY_s[r][m]
 // W rows live in registers, dY rows are staged in LDS (<= LB_ROWS rows per pass).
-#define LB_ROWS 128
+#define LB_ROWS 32
 __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__restrict__ tab) {
     const mpnn_lin_bwd_args &a = tab[blockIdx.y];
     const int C = a.a.C, K = a.HW * C;
@@ -115,7 +115,9 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
         acc[m] = 0.f; acc[16 + m] = 0.f;
     }
     float dbs = 0.f;
-    for (int r0 = 0; r0 < a.n; r0 += LB_ROWS) {
+    // blockIdx.z owns rows [z*LB_ROWS, ...) with stride gridDim.z*LB_ROWS: four times the workgroups,
+    // a quarter of the serial row loop; dW/db are then ADDED into the (zeroed) gradient tensors.
+    for (int r0 = blockIdx.z * LB_ROWS; r0 < a.n; r0 += gridDim.z * LB_ROWS) {
         const int nr = min(LB_ROWS, a.n - r0);
         __syncthreads();
         for (int i = tid; i < LB_ROWS * 32; i += 256) {
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int rr = rb + u;
-                if (rr >= nr) break;
+                if (rr >= nr) continue;            // (no `break`: the loop must stay fully unrolled)
                 float x = xv[u];
                 if (bn && k < K) x = fmaxf((x - cm) * ca + cb, 0.f);
                 const f32x4 *d4 = (const f32x4 *)(dys + rr * 32);
@@ -153,26 +155,39 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
             }
         }
     }
-    if (k < kext) {
+    // dW block of this workgroup = rows [k0, k0+256) of a [K(+1)][M] tensor: contiguous in memory.
+    // Transpose the per-thread rows through LDS so every atomic wave-instruction adds 256 contiguous
+    // bytes (one lane per row would put 64 lanes in 64 different 64-B segments: ~17x slower).
+    __shared__ float tr[256 * 17];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (!a.w[s] || !a.dw[s]) continue;
-            if (k == K && !a.extra_col[s]) continue;
-            const int M = a.M[s];
+    for (int s = 0; s < 2; ++s) {
+        if (!a.w[s] || !a.dw[s]) continue;          // uniform
+        const int M = a.M[s];
+        const int krows = a.extra_col[s] ? K + 1 : K;
+        __syncthreads();
 #pragma unroll
-            for (int m = 0; m < 16; ++m) if (m < M) a.dw[s][(size_t)k * M + m] = acc[s * 16 + m];
+        for (int m = 0; m < 16; ++m) tr[tid * 17 + m] = acc[s * 16 + m];
+        __syncthreads();
+        const int k0 = blockIdx.x * 256;
+        const int rows = min(256, krows - k0);
+        float *dst = a.dw[s] + (size_t)k0 * M;
+        for (int i = tid; i < rows * M; i += 256) {
+            const int kk = i / M, m = i - kk * M;
+            atomicAdd(dst + i, tr[kk * 17 + m]);
         }
     }
     if (blockIdx.x == 0 && tid < 32) {
         const int s = tid >> 4, m = tid & 15;
-        if (a.w[s] && a.db[s] && m < a.M[s]) a.db[s][m] = dbs;
+        if (a.w[s] && a.db[s] && m < a.M[s]) atomicAdd(a.db[s] + m, dbs);
     }
 }
 
 extern "C" int mpnn_lin_bwd(const mpnn_lin_bwd_args *dev_table, int count, int n_max, int k_max, void *stream) {
     if (count <= 0 || n_max <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    hipLaunchKernelGGL(lin_bwd_k, dim3((k_max + 1 + 255) / 256, count), dim3(256), 0, (hipStream_t)stream, dev_table);
+    const int zsplit = n_max > 3 * LB_ROWS ? 4 : (n_max > LB_ROWS ? 2 : 1);
+    hipLaunchKernelGGL(lin_bwd_k, dim3((k_max + 1 + 255) / 256, count, zsplit), dim3(256), 0, (hipStream_t)stream,
+                       dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

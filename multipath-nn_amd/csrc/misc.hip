@@ -13,10 +13,11 @@ __global__ __launch_bounds__(256) void pack_k(const float *__restrict__ params, 
     const int src = d[0], fwd = d[1], bwd = d[2], Cin = d[3], Cout = d[4];
     const int tap = blockIdx.y;
     const float *W = params + src;
+    const int t0 = blockIdx.z * 256 + threadIdx.x, tstride = gridDim.z * 256;
     if (fwd >= 0) {
         const int nch = (Cin + 15) >> 4, per_tap = nch * 16 * Cout;
         float *dst = packs + fwd + (size_t)tap * per_tap;
-        for (int i = threadIdx.x; i < per_tap; i += 256) {
+        for (int i = t0; i < per_tap; i += tstride) {
             const int j = i & 3, co = (i >> 2) % Cout, rest = (i >> 2) / Cout;   // rest = ch*4 + gb
             const int c = rest * 4 + j;
             dst[i] = c < Cin ? W[((size_t)tap * Cin + c) * Cout + co] : 0.f;
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(256) void pack_k(const float *__restrict__ params, 
     if (bwd >= 0) {
         const int nch = (Cout + 15) >> 4, per_tap = nch * 16 * Cin;
         float *dst = packs + bwd + (size_t)tap * per_tap;
-        for (int i = threadIdx.x; i < per_tap; i += 256) {
+        for (int i = t0; i < per_tap; i += tstride) {
             const int j = i & 3, ci = (i >> 2) % Cin, rest = (i >> 2) / Cin;
             const int co = rest * 4 + j;
             dst[i] = co < Cout ? W[((size_t)(8 - tap) * Cin + ci) * Cout + co] : 0.f;
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void pack_k(const float *__restrict__ params, 
 
 extern "C" int mpnn_pack_weights(const float *params, float *packs, const int *desc, int n_desc, void *stream) {
     if (n_desc <= 0) return 0;
-    hipLaunchKernelGGL(pack_k, dim3(n_desc, 9), dim3(256), 0, (hipStream_t)stream, params, packs, desc);
+    hipLaunchKernelGGL(pack_k, dim3(n_desc, 9, 8), dim3(256), 0, (hipStream_t)stream, params, packs, desc);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

@@ -274,8 +274,11 @@ class Engine:
                 tab += [doff, bn.m_avg.offset, bn.v_avg.offset, b.C[i], b.H[i] * b.W[i],
                         bn.γ.offset if b.has_dz[i] else -1, bn.β.offset, self._nslot(b, i)]
                 doff += 2 * b.C[i] * _hip.BN_SLOTS
-        self.dsum = torch.zeros(max(doff, 1), dtype=torch.float64, device=dev)
-        self.dred = torch.zeros(max(doff, 1), dtype=torch.float64, device=dev)
+        # dsum | dred | loss live in ONE byte arena so a step zeroes them with a single memset
+        nd = max(doff, 1)
+        self._zarena = torch.zeros((2 * nd + 4) * 8, dtype=torch.uint8, device=dev)
+        z64 = self._zarena.view(torch.float64)
+        self.dsum, self.dred, self.loss = z64[:nd], z64[nd:2 * nd], z64[2 * nd:2 * nd + 4]
         self.n_bn = len(tab) // 8
         self.bn_table = torch.tensor(tab, dtype=torch.int32, device=dev)
         self.bn_decay = float(self.blocks[0].bns[0].hypers.d) if self.blocks else 0.9
@@ -296,7 +299,6 @@ class Engine:
         self.node_ops_host = ops
         self.hyp = torch.zeros(_hip.HYP_N, device=dev)
         self.hyp_host = torch.zeros(_hip.HYP_N).pin_memory()
-        self.loss = torch.zeros(4, dtype=torch.float64, device=dev)
 
     def init_params(self, seed=None):
         """Draw every parameter from the reference's initialisation law
@@ -727,11 +729,11 @@ class Engine:
                 events[op.records] = (op.stream, e)
         assert not forked, 'program section ended with side streams still forked'
     def _zero(self, train):
-        self.loss.zero_()
         if train:
-            self.dsum.zero_()
-            self.dred.zero_()
+            self._zarena.zero_()
             self.G.zero_()
+        else:
+            self.loss.zero_()
 
     def _pack(self):
         _hip.check(self.lib.mpnn_pack_weights(self.P.data_ptr(), self.packs.data_ptr(), self.pack_desc.data_ptr(),
