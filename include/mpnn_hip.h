@@ -133,6 +133,9 @@ typedef struct {
     int n, H, W, Cout;                   /* H, W = COARSE size; Cout = fine chans  */
 } mpnn_dgrad_vert_args;
 int mpnn_msconv_dgrad_vert(const mpnn_dgrad_vert_args *args, void *stream);
+/* Both input gradients of one scale (same g, independent outputs) as ONE launch. */
+int mpnn_msconv_dgrad_pair(const mpnn_dgrad_horz_args *horz, const mpnn_dgrad_vert_args *vert,
+                           void *stream);
 
 /* ---- multiscale conv block, weight gradients -------------------------------
  * dW_horz = act(a)^T (*) g, dW_vert = maxpool2x2(v)^T (*) g, db = sum g.

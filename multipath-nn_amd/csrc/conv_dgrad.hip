@@ -1,6 +1,42 @@
 // Input-gradient convolutions of a MultiscaleConvMax scale (see conv_kernel.h).
 #include "conv_kernel.h"
 
+static int fill_horz(const mpnn_dgrad_horz_args *a, ConvP &p) {
+    if (!a || !a->g || !a->w_pack || !a->out) return MPNN_E_ARG;
+    p.a.x = a->g;  p.a.C = a->Cg;  p.a.mode = MPNN_ACT_IDENTITY;  p.a.shift = 0;
+    p.wa = a->w_pack;
+    p.n = a->n;  p.H = a->H;  p.W = a->W;  p.Cout = a->Cout;
+    p.extra = a->dy_extra;  p.out = a->out;
+    if (a->prev) {
+        if (!a->prev->s || !a->red_out) return MPNN_E_ARG;
+        p.sprev = a->prev->s;  p.pbn = a->prev->bn;  p.red_out = a->red_out;
+        p.out_nslot = a->prev->red_nslot < 1 ? 1 : a->prev->red_nslot;
+    }
+    return 0;
+}
+
+static int fill_vert(const mpnn_dgrad_vert_args *a, ConvP &p) {
+    if (!a || !a->g || !a->w_pack || !a->fine || !a->fine->s || !a->dz_g_fine) return MPNN_E_ARG;
+    p.a.x = a->g;  p.a.C = a->Cg;  p.a.mode = MPNN_ACT_IDENTITY;  p.a.shift = 0;
+    p.wa = a->w_pack;
+    p.n = a->n;  p.H = a->H;  p.W = a->W;  p.Cout = a->Cout;
+    p.out = a->dz_g_fine;  p.sprev = a->fine->s;  p.pbn = a->fine->bn;
+    p.red = a->fine_has_dz ? a->fine->red : nullptr;  p.has_dz = a->fine_has_dz;
+    p.red_nslot = a->fine->red_nslot < 1 ? 1 : a->fine->red_nslot;
+    return 0;
+}
+
+// Both input gradients of one scale (they read the same g) in ONE launch.
+extern "C" int mpnn_msconv_dgrad_pair(const mpnn_dgrad_horz_args *h, const mpnn_dgrad_vert_args *v, void *stream) {
+    ConvP ph = {}, pv = {};
+    int rc = fill_horz(h, ph);
+    if (rc) return rc;
+    rc = fill_vert(v, pv);
+    if (rc) return rc;
+    if (!h->prev) return MPNN_E_ARG;               // the paired form always carries the producer's BN backward
+    return conv_launch_pair<EPI_DGH_BN, EPI_DGV>(ph, pv, (hipStream_t)stream);
+}
+
 extern "C" int mpnn_msconv_dgrad_horz(const mpnn_dgrad_horz_args *a, void *stream) {
     if (!a || !a->g || !a->w_pack || !a->out) return MPNN_E_ARG;
     ConvP p = {};

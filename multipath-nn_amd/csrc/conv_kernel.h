@@ -181,8 +181,16 @@ __device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], cons
 // loads of unit u+1 are in flight, and they are transformed and written to the
 // other buffer before the single barrier that ends the unit.
 // ---------------------------------------------------------------------------
+// LDS bytes of one workgroup (all variants of a launch share one arena).
+template <int GK, int WM, int CT>
+struct ConvSmem {
+    static constexpr int TILE = 2 * 4 * Geom<GK>::P * 16, WT = 2 * 36 * CT * 16, CA = 128 * 3 * 4, CE = CT * 5 * 4,
+                         RED = WM * CT * 2 * 8;
+    static constexpr int BYTES = TILE + WT + CA + ((CE + 15) & ~15) + RED;
+};
+
 template <int GK, int MT, int NT, int WM, int WN, bool SMALL_A, int EPI>
-__global__ __launch_bounds__(256) void conv_k(const ConvP p) {
+__device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const int by, const int gx, char *smem) {
     using G = Geom<GK>;
     constexpr int P = G::P, R = G::R, HR = G::TH + 2;
     constexpr int CT = WN * NT * 16;
@@ -192,17 +200,18 @@ __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
 
     constexpr int BI = 36 * CT;                     // float4 items of one weight chunk: [9 taps][4 g][CT]
     constexpr int BN = (BI + 255) / 256;
-    __shared__ f32x4 tile[2][4 * P];
-    __shared__ f32x4 wtile[2][BI];
-    __shared__ float cA[128 * 3];
-    __shared__ float cE[CT * 5];
-    __shared__ double redbuf[WM * CT * 2];
+    using SM = ConvSmem<GK, WM, CT>;
+    f32x4 (*tile)[4 * P] = (f32x4 (*)[4 * P])smem;
+    f32x4 (*wtile)[BI] = (f32x4 (*)[BI])(smem + SM::TILE);
+    float *cA = (float *)(smem + SM::TILE + SM::WT);
+    float *cE = cA + 128 * 3;
+    double *redbuf = (double *)(smem + SM::TILE + SM::WT + SM::CA + ((SM::CE + 15) & ~15));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int wm = wid / WN, wn = wid - wm * WN;
-    const int co0 = blockIdx.y * CT;
+    const int co0 = by * CT;
     const int cw = co0 + wn * NT * 16 + li;          // this lane's first output channel
 
     if (EPI == EPI_FWD && p.a.mode != MPNN_ACT_IDENTITY) {
@@ -238,13 +247,13 @@ __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
     }
     const int nchA = (p.a.C + 15) >> 4, nchV = p.v ? ((p.Cv + 15) >> 4) : 0, upt = nchA + nchV;
 
-    const int my_tiles = ((int)blockIdx.x < p.n_tiles) ? (p.n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int my_tiles = (bx < p.n_tiles) ? (p.n_tiles - 1 - bx) / gx + 1 : 0;
     const int n_units = my_tiles * upt;
 
     // unit decode
     auto decode = [&](int u, int &t, int &part, int &ch, int &np) {
         const int ti = u / upt, q = u - ti * upt;
-        t = blockIdx.x + ti * gridDim.x;
+        t = bx + ti * gx;
         part = q >= nchA ? 1 : 0;
         ch = part ? q - nchA : q;
         const int C = part ? p.Cv : p.a.C;
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
                 double a1 = 0.0, a2 = 0.0;
 #pragma unroll
                 for (int w = 0; w < WM; ++w) { a1 += redbuf[(w * CT + tid) * 2]; a2 += redbuf[(w * CT + tid) * 2 + 1]; }
-                double *slot = dst + (size_t)(blockIdx.x % p.out_nslot) * 2 * p.Cout;
+                double *slot = dst + (size_t)(bx % p.out_nslot) * 2 * p.Cout;
                 atomicAdd(slot + co0 + tid, a1);
                 atomicAdd(slot + p.Cout + co0 + tid, a2);
             }
@@ -461,16 +470,64 @@ __global__ __launch_bounds__(256) void conv_k(const ConvP p) {
     }
 }
 
+template <int GK, int MT, int NT, int WM, int WN, bool SMALL_A, int EPI>
+__global__ __launch_bounds__(256) void conv_k(const ConvP p) {
+    __shared__ __attribute__((aligned(16))) char smem[ConvSmem<GK, WM, WN * NT * 16>::BYTES];
+    conv_body<GK, MT, NT, WM, WN, SMALL_A, EPI>(p, blockIdx.x, blockIdx.y, gridDim.x, smem);
+}
+
+// Two independent convs over the SAME input map in one launch: rows [0, gy0) of the grid run the
+// first (dgrad-horz) body, the rest the second (dgrad-vert) body.  Their serial latency chains
+// (prologue, first loads, epilogue drain) overlap instead of adding up across two launches.
+template <int GK, int MT, int NT, int WM, int WN, int EPI0, int EPI1>
+__global__ __launch_bounds__(256) void conv_pair_k(const ConvP p0, const ConvP p1, const int gy0, const int gx0,
+                                                   const int gx1) {
+    __shared__ __attribute__((aligned(16))) char smem[ConvSmem<GK, WM, WN * NT * 16>::BYTES];
+    if ((int)blockIdx.y < gy0) {
+        if ((int)blockIdx.x < gx0) conv_body<GK, MT, NT, WM, WN, false, EPI0>(p0, blockIdx.x, blockIdx.y, gx0, smem);
+    } else {
+        if ((int)blockIdx.x < gx1) conv_body<GK, MT, NT, WM, WN, false, EPI1>(p1, blockIdx.x, blockIdx.y - gy0, gx1, smem);
+    }
+}
+
 // ------------------------------- host dispatch -------------------------------
+static inline int conv_cap_gx(int n_tiles, int gy) {
+    const int cap = 1024 / gy > 64 ? 1024 / gy : 64;      // persistent: a few workgroups per CU
+    return n_tiles > cap ? cap : n_tiles;
+}
+
+// Pair launch (both convs use 16-channel tiles: cfg <1,1,4,1>).
+template <int GK, int EPI0, int EPI1>
+static int conv_launch_pair_geom(ConvP &p0, ConvP &p1, hipStream_t st) {
+    if ((p0.Cout % 16) || (p1.Cout % 16)) return MPNN_E_SHAPE;
+    p0.n_tiles = p1.n_tiles = conv_grid_x<GK>(p0.n, p0.H, p0.W);
+    p0.dbg = p1.dbg = 0;
+    const int gy0 = p0.Cout / 16, gy1 = p1.Cout / 16;
+    const int gx0 = conv_cap_gx(p0.n_tiles, gy0), gx1 = conv_cap_gx(p1.n_tiles, gy1);
+    dim3 grid(gx0 > gx1 ? gx0 : gx1, gy0 + gy1), block(256);
+    hipLaunchKernelGGL((conv_pair_k<GK, 1, 1, 4, 1, EPI0, EPI1>), grid, block, 0, st, p0, p1, gy0, gx0, gx1);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int EPI0, int EPI1>
+static int conv_launch_pair(ConvP &p0, ConvP &p1, hipStream_t st) {
+    if (p0.n <= 0) return 0;
+    if (p0.H != p1.H || p0.W != p1.W || p0.n != p1.n) return MPNN_E_ARG;
+    if (p0.a.C > 128 || p1.a.C > 128 || (p0.a.C & 3) || (p1.a.C & 3)) return MPNN_E_SHAPE;
+    if (p0.W >= 16 && (p0.W % 16) == 0 && (p0.H % 4) == 0) return conv_launch_pair_geom<0, EPI0, EPI1>(p0, p1, st);
+    if (p0.W == 8 && p0.H == 8) return conv_launch_pair_geom<1, EPI0, EPI1>(p0, p1, st);
+    if (p0.W == 4 && p0.H == 4) return conv_launch_pair_geom<2, EPI0, EPI1>(p0, p1, st);
+    return MPNN_E_SHAPE;
+}
+
 template <int GK, int MT, int NT, int WM, int WN, int EPI>
 static int conv_launch_cfg(ConvP &p, bool small_a, hipStream_t st) {
     constexpr int CT = WN * NT * 16;
     p.n_tiles = conv_grid_x<GK>(p.n, p.H, p.W);
     { const char *e = getenv("MPNN_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int gy = p.Cout / CT;
-    int gx = p.n_tiles;
-    const int cap = 1024 / gy > 64 ? 1024 / gy : 64;      // persistent: a few workgroups per CU
-    if (gx > cap) gx = cap;
+    const int gx = conv_cap_gx(p.n_tiles, gy);
     dim3 grid(gx, gy), block(256);
     if constexpr (EPI == EPI_FWD) {
         if (small_a) {

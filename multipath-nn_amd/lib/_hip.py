@@ -90,6 +90,7 @@ _SIGS = {
     'mpnn_bn_bwd_apply': [P, C.POINTER(BnCtx), C.c_long, P],
     'mpnn_msconv_dgrad_horz': [C.POINTER(DgradHorzArgs), P],
     'mpnn_msconv_dgrad_vert': [C.POINTER(DgradVertArgs), P],
+    'mpnn_msconv_dgrad_pair': [C.POINTER(DgradHorzArgs), C.POINTER(DgradVertArgs), P],
     'mpnn_msconv_wgrad': [C.POINTER(WgradArgs), P],
     'mpnn_wgrad_tiles': [C.c_int, C.c_int, C.c_int],
     'mpnn_slab_reduce': [P, P, P, C.c_int, P],

@@ -393,7 +393,7 @@ class Engine:
         return max(1, min(tiles, want))
 
     def program(self, mode, n):
-        key = (mode, n)
+        key = (mode, n, self.multi_stream)
         if key in self._progs:
             return self._progs[key]
         self._ensure_capacity(n)
@@ -561,7 +561,9 @@ class Engine:
             ctx = self._bn_ctx(b, L1, n)
             bwd.append(call(lib.mpnn_bn_bwd_apply, 'bn_bwd_apply', b.dzg[L1].data_ptr(), C.byref(ctx),
                             n * b.H[L1] * b.W[L1], stream=sid[b.H[L1]], records=Gn(b, L1)))
-            for i in range(L1, 0, -1):
+            pair = (not self.multi_stream) and b.parent is not None
+
+            def vert_args(i):
                 a = _hip.DgradVertArgs()
                 fine = self._bn_ctx(b, i - 1, n)
                 a.g, a.Cg = b.dzg[i].data_ptr(), b.C[i]
@@ -571,10 +573,40 @@ class Engine:
                 a.dz_g_fine = b.dzg[i - 1].data_ptr()
                 a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i - 1]
                 keep.append(a)
-                bwd.append(call(lib.mpnn_msconv_dgrad_vert, 'dgrad_vert', C.byref(a),
-                                flops=2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * b.C[i - 1],
-                                tag='h%d %d->%d' % (b.H[i], b.C[i], b.C[i - 1]),
-                                stream=sid[b.H[i - 1]], waits=[Gn(b, i)], records=Gn(b, i - 1)))
+                return a
+
+            def horz_args(i):
+                pb, j = b.parent, b.in_map[i]
+                a = _hip.DgradHorzArgs()
+                a.g, a.Cg = b.dzg[i].data_ptr(), b.C[i]
+                a.w_pack = self.packs[b.pack['w_horz_%i' % i][1]:].data_ptr()
+                a.dy_extra = pb.dx.data_ptr() if (pb.has_exit and j == pb.L - 1) else None
+                prev = self._bn_ctx(pb, j, n, with_red=False)
+                a.prev = C.pointer(prev)
+                a.out = pb.dzg[j].data_ptr()
+                a.red_out = self.dred[pb.sum_off[j]:].data_ptr()
+                a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], pb.C[j]
+                keep.append(a)
+                return a
+
+            fl_v = lambda i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * b.C[i - 1]
+            fl_h = lambda i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * b.parent.C[b.in_map[i]]
+            # scale chain, coarsest first: g(b,i) -> [dgrad-vert -> g(b,i-1)] (+ dgrad-horz of scale i in
+            # the same launch: both read g(b,i))
+            for i in range(L1, 0, -1):
+                if pair:
+                    bwd.append(call(lib.mpnn_msconv_dgrad_pair, 'dgrad_pair', C.byref(horz_args(i)),
+                                    C.byref(vert_args(i)), flops=fl_v(i) + fl_h(i),
+                                    tag='h%d %d->%d|%d' % (b.H[i], b.C[i], b.parent.C[b.in_map[i]], b.C[i - 1])))
+                else:
+                    bwd.append(call(lib.mpnn_msconv_dgrad_vert, 'dgrad_vert', C.byref(vert_args(i)), flops=fl_v(i),
+                                    tag='h%d %d->%d' % (b.H[i], b.C[i], b.C[i - 1]),
+                                    stream=sid[b.H[i - 1]], waits=[Gn(b, i)], records=Gn(b, i - 1)))
+            if b.parent is not None:
+                for i in ([0] if pair else range(b.L)):
+                    bwd.append(call(lib.mpnn_msconv_dgrad_horz, 'dgrad_horz', C.byref(horz_args(i)), flops=fl_h(i),
+                                    tag='h%d %d->%d' % (b.H[i], b.C[i], b.parent.C[b.in_map[i]]),
+                                    stream=sid[b.H[i]]))
             for i in range(b.L):
                 a = _hip.WgradArgs()
                 a.a = self._act_of_input(b, i, n, act_mode)
@@ -610,23 +642,6 @@ class Engine:
                 bwd.append(call(lib.mpnn_msconv_wgrad, 'wgrad', C.byref(a), flops=fl,
                                 tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i]),
                                 stream=wg_streams[i % 2], waits=[Gn(b, i)]))
-            if b.parent is not None:
-                pb = b.parent
-                for i in range(b.L):
-                    j = b.in_map[i]
-                    a = _hip.DgradHorzArgs()
-                    a.g, a.Cg = b.dzg[i].data_ptr(), b.C[i]
-                    a.w_pack = self.packs[b.pack['w_horz_%i' % i][1]:].data_ptr()
-                    a.dy_extra = pb.dx.data_ptr() if (pb.has_exit and j == pb.L - 1) else None
-                    prev = self._bn_ctx(pb, j, n, with_red=False)
-                    a.prev = C.pointer(prev)
-                    a.out = pb.dzg[j].data_ptr()
-                    a.red_out = self.dred[pb.sum_off[j]:].data_ptr()
-                    a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], pb.C[j]
-                    keep.append(a)
-                    bwd.append(call(lib.mpnn_msconv_dgrad_horz, 'dgrad_horz', C.byref(a),
-                                    flops=2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * pb.C[j],
-                                    tag='h%d %d->%d' % (b.H[i], b.C[i], pb.C[j]), stream=sid[b.H[i]]))
         bwd.append(marker('join'))
         if slab_plan['size']:
             slab = torch.empty(slab_plan['size'], device=self.dev)
