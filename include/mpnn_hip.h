@@ -155,6 +155,10 @@ typedef struct {
     int n_split;
 } mpnn_wgrad_args;
 int mpnn_msconv_wgrad(const mpnn_wgrad_args *args, void *stream);
+/* Everything the backward pass does with g of one scale -- dgrad-horz (NULL: none), dgrad-vert
+ * (NULL: none) and the weight gradients -- as ONE launch of independent workgroups. */
+int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *horz, const mpnn_dgrad_vert_args *vert,
+                          const mpnn_wgrad_args *wgrad, void *stream);
 /* Number of 64-pixel tiles (upper bound of n_split) for a map, or MPNN_E_SHAPE. */
 int mpnn_wgrad_tiles(int n, int H, int W);
 /* dst[i] = sum_{s<n_split} src[s*stride + i].  table: 6 ints per work item:

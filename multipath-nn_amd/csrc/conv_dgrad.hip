@@ -1,7 +1,7 @@
 // Input-gradient convolutions of a MultiscaleConvMax scale (see conv_kernel.h).
 #include "conv_kernel.h"
 
-static int fill_horz(const mpnn_dgrad_horz_args *a, ConvP &p) {
+int mpnn_fill_dgrad_horz(const mpnn_dgrad_horz_args *a, ConvP &p) {
     if (!a || !a->g || !a->w_pack || !a->out) return MPNN_E_ARG;
     p.a.x = a->g;  p.a.C = a->Cg;  p.a.mode = MPNN_ACT_IDENTITY;  p.a.shift = 0;
     p.wa = a->w_pack;
@@ -15,7 +15,7 @@ static int fill_horz(const mpnn_dgrad_horz_args *a, ConvP &p) {
     return 0;
 }
 
-static int fill_vert(const mpnn_dgrad_vert_args *a, ConvP &p) {
+int mpnn_fill_dgrad_vert(const mpnn_dgrad_vert_args *a, ConvP &p) {
     if (!a || !a->g || !a->w_pack || !a->fine || !a->fine->s || !a->dz_g_fine) return MPNN_E_ARG;
     p.a.x = a->g;  p.a.C = a->Cg;  p.a.mode = MPNN_ACT_IDENTITY;  p.a.shift = 0;
     p.wa = a->w_pack;
@@ -29,9 +29,9 @@ static int fill_vert(const mpnn_dgrad_vert_args *a, ConvP &p) {
 // Both input gradients of one scale (they read the same g) in ONE launch.
 extern "C" int mpnn_msconv_dgrad_pair(const mpnn_dgrad_horz_args *h, const mpnn_dgrad_vert_args *v, void *stream) {
     ConvP ph = {}, pv = {};
-    int rc = fill_horz(h, ph);
+    int rc = mpnn_fill_dgrad_horz(h, ph);
     if (rc) return rc;
-    rc = fill_vert(v, pv);
+    rc = mpnn_fill_dgrad_vert(v, pv);
     if (rc) return rc;
     if (!h->prev) return MPNN_E_ARG;               // the paired form always carries the producer's BN backward
     return conv_launch_pair<EPI_DGH_BN, EPI_DGV>(ph, pv, (hipStream_t)stream);

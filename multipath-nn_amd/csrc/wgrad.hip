@@ -53,7 +53,8 @@ __device__ __forceinline__ void load_g(f32x4 *gr, const WgP &p, int n0, int y0, 
 }
 
 template <int GK, int OT, int PART>
-__device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt, float *cA) {
+__device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt, float *cA,
+                                           const int bx, const int by, const int bz, const int gx) {
     using G = Geom<GK>;
     constexpr int PS = WGeom<GK>::PS, R = G::R, HR = G::TH + 2;
     constexpr int GS = OT * 16 + 4;                  // g tile row stride (floats)
@@ -64,12 +65,12 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     const int g = lane >> 4, li = lane & 15;
     const int nchA = (c.a.C + 15) >> 4;
     constexpr int part = PART;
-    const int ch = part ? (int)blockIdx.y - nchA : (int)blockIdx.y;
+    const int ch = part ? by - nchA : by;
     const int C = part ? c.Cv : c.a.C;
-    const int co0 = blockIdx.z * OT * 16;
+    const int co0 = bz * OT * 16;
     int np = (C - ch * 16 + 3) >> 2;
     np = np > 4 ? 4 : np;
-    const bool bias_wave = wid == 1 && blockIdx.y == 0;   // slot ti = 2 of wave 1 is tap 9: unused
+    const bool bias_wave = wid == 1 && by == 0;           // slot ti = 2 of wave 1 is tap 9: unused
 
     if (part == 0 && c.a.mode != MPNN_ACT_IDENTITY) {
         for (int cc = tid; cc < c.a.C; cc += 256) {
@@ -98,7 +99,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     }
 
     f32x4 xr[XN][PART ? 4 : 1], gr[OT];
-    int t = blockIdx.x;
+    int t = bx;
     int n0, y0, x0, cn0 = 0, cy0 = 0, cx0 = 0;
     if (t < p.n_tiles) {
         tile_origin<GK>(c, t, n0, y0, x0);
@@ -106,7 +107,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         load_g<GK, OT>(gr, p, n0, y0, x0, co0, tid);
         cn0 = n0; cy0 = y0; cx0 = x0;
     }
-    for (; t < p.n_tiles; t += gridDim.x) {
+    for (; t < p.n_tiles; t += gx) {
         __syncthreads();                               // previous tile's LDS reads are done
         store_x<GK, PS, PART, (PART ? 4 : 1)>(tile, xr, c, cA, cn0, cy0, cx0, ch * 16, np, tid);
 #pragma unroll
@@ -115,7 +116,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
             *(f32x4 *)(gt + (i / (OT * 4)) * GS + (i % (OT * 4)) * 4) = gr[k];
         }
         __syncthreads();
-        const int tn = t + gridDim.x;
+        const int tn = t + gx;
         if (tn < p.n_tiles) {                          // next tile's loads fly under the MFMAs
             tile_origin<GK>(c, tn, n0, y0, x0);
             load_x<GK, PART, (PART ? 4 : 1)>(xr, c, n0, y0, x0, ch * 16, np, tid);
@@ -147,7 +148,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     }
 
     // D layout: col = li (cout), row = g*4 + r (input channel of the chunk).
-    const size_t soff = (size_t)blockIdx.x * p.split_stride;
+    const size_t soff = (size_t)bx * p.split_stride;
     float *dw = (part ? p.dwv : p.dwa) + soff;
 #pragma unroll
     for (int ti = 0; ti < 3; ++ti) {
@@ -174,9 +175,46 @@ __global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
     __shared__ f32x4 tile[4 * PS];
     __shared__ float gt[64 * GS];
     __shared__ float cA[128 * 3];
-    if ((int)blockIdx.y >= ((p.c.a.C + 15) >> 4)) wgrad_body<GK, OT, 1>(p, tile, gt, cA);
-    else                                           wgrad_body<GK, OT, 0>(p, tile, gt, cA);
+    if ((int)blockIdx.y >= ((p.c.a.C + 15) >> 4)) wgrad_body<GK, OT, 1>(p, tile, gt, cA, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+    else                                           wgrad_body<GK, OT, 0>(p, tile, gt, cA, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
+
+// ---------------------------------------------------------------------------
+// mpnn_msconv_bwd_scale: everything the backward pass does with g(b, i) -- the input gradients
+// through the horz and vert convs and the weight gradients -- as ONE launch.  The three bodies
+// are independent (they only share their input), so their workgroups overlap in time instead of
+// queueing as three launches with a serial latency chain each.  Grid rows:
+//   [0, gyh)            dgrad-horz tiles  (16 output channels each)
+//   [gyh, gyh+gyv)      dgrad-vert tiles
+//   [gyh+gyv, ...)      wgrad (chunk, 16-cout group) pairs
+// ---------------------------------------------------------------------------
+struct BwdScaleP {
+    ConvP h, v;  WgP w;
+    int gyh, gyv, gxh, gxv, gxw, nchw;           // nchw = channel chunks (A + V) of the wgrad
+};
+
+template <int GK, int OT>
+__global__ __launch_bounds__(256) void bwd_scale_k(const BwdScaleP q) {
+    constexpr int CB = ConvSmem<GK, 4, 16>::BYTES;
+    constexpr int GS = OT * 16 + 4;
+    constexpr int WB = 4 * WGeom<GK>::PS * 16 + 64 * GS * 4 + 128 * 3 * 4;
+    __shared__ __attribute__((aligned(16))) char smem[CB > WB ? CB : WB];
+    const int by = blockIdx.y, bx = blockIdx.x;
+    if (by < q.gyh) {
+        if (bx < q.gxh) conv_body<GK, 1, 1, 4, 1, false, EPI_DGH_BN>(q.h, bx, by, q.gxh, smem);
+    } else if (by < q.gyh + q.gyv) {
+        if (bx < q.gxv) conv_body<GK, 1, 1, 4, 1, false, EPI_DGV>(q.v, bx, by - q.gyh, q.gxv, smem);
+    } else if (bx < q.gxw) {
+        const int r = by - q.gyh - q.gyv;
+        const int chunk = r % q.nchw, bz = r / q.nchw;
+        f32x4 *tile = (f32x4 *)smem;
+        float *gt = (float *)(smem + 4 * WGeom<GK>::PS * 16);
+        float *cA = gt + 64 * GS;
+        if (chunk >= ((q.w.c.a.C + 15) >> 4)) wgrad_body<GK, OT, 1>(q.w, tile, gt, cA, bx, chunk, bz, q.gxw);
+        else                                   wgrad_body<GK, OT, 0>(q.w, tile, gt, cA, bx, chunk, bz, q.gxw);
+    }
+}
+
 
 template <int GK>
 static int wgrad_launch(const WgP &p, int split, hipStream_t st) {
@@ -220,6 +258,71 @@ extern "C" int mpnn_msconv_wgrad(const mpnn_wgrad_args *a, void *stream) {
     if (a->W >= 16) return wgrad_launch<0>(p, split, st);
     if (a->W == 8) return wgrad_launch<1>(p, split, st);
     return wgrad_launch<2>(p, split, st);
+}
+
+static int fill_wgrad(const mpnn_wgrad_args *a, WgP &p, int &split) {
+    if (!a || !a->a.x || !a->g || !a->dwa || !a->db) return MPNN_E_ARG;
+    if (a->v && !a->dwv) return MPNN_E_ARG;
+    if (a->a.C > 128 || a->Cv > 128 || (a->Cv & 3)) return MPNN_E_SHAPE;
+    if (a->a.C > 4 && (a->a.C & 3)) return MPNN_E_SHAPE;
+    const int tiles = mpnn_wgrad_tiles(a->n, a->H, a->W);
+    if (tiles < 0) return tiles;
+    split = a->n_split < 1 ? 1 : (a->n_split > tiles ? tiles : a->n_split);
+    if (split > 1 && a->split_stride <= 0) return MPNN_E_ARG;
+    p.c.a = a->a;  p.c.v = a->v;  p.c.Cv = a->v ? a->Cv : 0;
+    p.c.n = a->n;  p.c.H = a->H;  p.c.W = a->W;  p.c.Cout = a->Cout;
+    p.g = a->g;  p.dwa = a->dwa;  p.dwv = a->dwv;  p.db = a->db;
+    p.split_stride = a->split_stride;  p.n_tiles = tiles;
+    return 0;
+}
+
+int mpnn_fill_dgrad_horz(const mpnn_dgrad_horz_args *a, ConvP &p);     // conv_dgrad.hip
+int mpnn_fill_dgrad_vert(const mpnn_dgrad_vert_args *a, ConvP &p);
+
+template <int GK>
+static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hipStream_t st) {
+    const int tiles = conv_grid_x<GK>(q.w.c.n, q.w.c.H, q.w.c.W);
+    q.gyh = has_h ? q.h.Cout / 16 : 0;
+    q.gyv = has_v ? q.v.Cout / 16 : 0;
+    q.h.n_tiles = q.v.n_tiles = tiles;
+    q.gxh = has_h ? conv_cap_gx(tiles, q.gyh) : 0;
+    q.gxv = has_v ? conv_cap_gx(tiles, q.gyv) : 0;
+    q.gxw = split;
+    q.nchw = ((q.w.c.a.C + 15) >> 4) + (q.w.c.v ? ((q.w.c.Cv + 15) >> 4) : 0);
+    const bool wide = (q.w.c.Cout % 64) == 0;           // 64-channel weight-gradient groups for wide layers
+    const int gyw = q.nchw * (q.w.c.Cout / (wide ? 64 : 16));
+    int gx = q.gxw;
+    if (q.gxh > gx) gx = q.gxh;
+    if (q.gxv > gx) gx = q.gxv;
+    const dim3 grid(gx, q.gyh + q.gyv + gyw);
+    if (wide) hipLaunchKernelGGL((bwd_scale_k<GK, 4>), grid, dim3(256), 0, st, q);
+    else      hipLaunchKernelGGL((bwd_scale_k<GK, 1>), grid, dim3(256), 0, st, q);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *h, const mpnn_dgrad_vert_args *v,
+                                     const mpnn_wgrad_args *w, void *stream) {
+    if (!w) return MPNN_E_ARG;
+    if (w->n <= 0) return 0;
+    BwdScaleP q = {};
+    int split = 1, rc = fill_wgrad(w, q.w, split);
+    if (rc) return rc;
+    if (w->Cout % 16) return MPNN_E_SHAPE;
+    if (h) {
+        if (!h->prev) return MPNN_E_ARG;
+        if ((rc = mpnn_fill_dgrad_horz(h, q.h))) return rc;
+        if (h->H != w->H || h->W != w->W || h->n != w->n || (h->Cout % 16) || (h->Cg & 3)) return MPNN_E_ARG;
+    }
+    if (v) {
+        if ((rc = mpnn_fill_dgrad_vert(v, q.v))) return rc;
+        if (v->H != w->H || v->W != w->W || v->n != w->n || (v->Cout % 16) || (v->Cg & 3)) return MPNN_E_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (w->W >= 16 && (w->W % 16) == 0 && (w->H % 4) == 0) return bwd_scale_launch<0>(q, h, v, split, st);
+    if (w->W == 8 && w->H == 8) return bwd_scale_launch<1>(q, h, v, split, st);
+    if (w->W == 4 && w->H == 4) return bwd_scale_launch<2>(q, h, v, split, st);
+    return MPNN_E_SHAPE;
 }
 
 // ---------------------------------------------------------------------------

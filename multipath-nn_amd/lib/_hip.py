@@ -92,6 +92,7 @@ _SIGS = {
     'mpnn_msconv_dgrad_vert': [C.POINTER(DgradVertArgs), P],
     'mpnn_msconv_dgrad_pair': [C.POINTER(DgradHorzArgs), C.POINTER(DgradVertArgs), P],
     'mpnn_msconv_wgrad': [C.POINTER(WgradArgs), P],
+    'mpnn_msconv_bwd_scale': [C.POINTER(DgradHorzArgs), C.POINTER(DgradVertArgs), C.POINTER(WgradArgs), P],
     'mpnn_wgrad_tiles': [C.c_int, C.c_int, C.c_int],
     'mpnn_slab_reduce': [P, P, P, C.c_int, P],
     'mpnn_lin_fwd': [P, C.c_int, C.c_int, P],

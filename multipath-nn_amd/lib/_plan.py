@@ -381,15 +381,17 @@ class Engine:
         self._keep.append(ctx)
         return ctx
 
-    def _wsplit(self, b, i, n):
+    def _wsplit(self, b, i, n, fused=False):
         """Workgroups the pixel range of a wgrad launch is divided over."""
         H = b.H[i]
         tiles = n * (H // 16) * (H // 4) if H >= 16 else (n if H == 8 else (n + 3) // 4)
         nch = (b.Cin[i] + 15) // 16 + ((b.C[i - 1] + 15) // 16 if i > 0 else 0)
         groups = max(1, b.C[i] // 64) if b.C[i] % 64 == 0 else (b.C[i] // 32 if b.C[i] % 32 == 0 else b.C[i] // 16)
-        want = max(1, 384 // (nch * groups))
+        if fused:
+            groups = b.C[i] // 64 if b.C[i] % 64 == 0 else b.C[i] // 16    # as mpnn_msconv_bwd_scale
+        want = max(1, 512 // (nch * groups))
         w_bytes = 4 * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
-        want = min(want, max(1, (3 << 20) // w_bytes))          # keep a layer's slab under ~3 MB
+        want = min(want, max(1, (12 << 20) // w_bytes))         # keep a layer's slab under ~12 MB
         return max(1, min(tiles, want))
 
     def program(self, mode, n):
@@ -561,7 +563,6 @@ class Engine:
             ctx = self._bn_ctx(b, L1, n)
             bwd.append(call(lib.mpnn_bn_bwd_apply, 'bn_bwd_apply', b.dzg[L1].data_ptr(), C.byref(ctx),
                             n * b.H[L1] * b.W[L1], stream=sid[b.H[L1]], records=Gn(b, L1)))
-            pair = (not self.multi_stream) and b.parent is not None
 
             def vert_args(i):
                 a = _hip.DgradVertArgs()
@@ -591,23 +592,7 @@ class Engine:
 
             fl_v = lambda i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * b.C[i - 1]
             fl_h = lambda i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * b.parent.C[b.in_map[i]]
-            # scale chain, coarsest first: g(b,i) -> [dgrad-vert -> g(b,i-1)] (+ dgrad-horz of scale i in
-            # the same launch: both read g(b,i))
-            for i in range(L1, 0, -1):
-                if pair:
-                    bwd.append(call(lib.mpnn_msconv_dgrad_pair, 'dgrad_pair', C.byref(horz_args(i)),
-                                    C.byref(vert_args(i)), flops=fl_v(i) + fl_h(i),
-                                    tag='h%d %d->%d|%d' % (b.H[i], b.C[i], b.parent.C[b.in_map[i]], b.C[i - 1])))
-                else:
-                    bwd.append(call(lib.mpnn_msconv_dgrad_vert, 'dgrad_vert', C.byref(vert_args(i)), flops=fl_v(i),
-                                    tag='h%d %d->%d' % (b.H[i], b.C[i], b.C[i - 1]),
-                                    stream=sid[b.H[i - 1]], waits=[Gn(b, i)], records=Gn(b, i - 1)))
-            if b.parent is not None:
-                for i in ([0] if pair else range(b.L)):
-                    bwd.append(call(lib.mpnn_msconv_dgrad_horz, 'dgrad_horz', C.byref(horz_args(i)), flops=fl_h(i),
-                                    tag='h%d %d->%d' % (b.H[i], b.C[i], b.parent.C[b.in_map[i]]),
-                                    stream=sid[b.H[i]]))
-            for i in range(b.L):
+            def wgrad_args(i):
                 a = _hip.WgradArgs()
                 a.a = self._act_of_input(b, i, n, act_mode)
                 pa = getattr(cp, 'w_horz_%i' % i)
@@ -617,7 +602,7 @@ class Engine:
                     a.v, a.Cv = b.s[i - 1].data_ptr(), b.C[i - 1]
                 a.g = b.dzg[i].data_ptr()
                 a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
-                split = self._wsplit(b, i, n)
+                split = self._wsplit(b, i, n, fused=not self.multi_stream)
                 a.n_split = split
                 if split == 1:
                     a.dwa, a.db = pa.grad.data_ptr(), pb.grad.data_ptr()
@@ -638,10 +623,34 @@ class Engine:
                         off += sz
                     a.split_stride = stride
                 keep.append(a)
-                fl = 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
-                bwd.append(call(lib.mpnn_msconv_wgrad, 'wgrad', C.byref(a), flops=fl,
-                                tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i]),
-                                stream=wg_streams[i % 2], waits=[Gn(b, i)]))
+                return a
+
+            fl_w = lambda i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
+            if not self.multi_stream:
+                # One launch per scale, coarsest first: everything that consumes g(b,i) -- dgrad-horz,
+                # dgrad-vert (which produces g(b,i-1) for the next launch) and the weight gradients.
+                for i in range(L1, -1, -1):
+                    h = horz_args(i) if b.parent is not None else None
+                    v = vert_args(i) if i > 0 else None
+                    fl = fl_w(i) + (fl_h(i) if h is not None else 0) + (fl_v(i) if v is not None else 0)
+                    bwd.append(call(lib.mpnn_msconv_bwd_scale, 'bwd_scale',
+                                    C.byref(h) if h is not None else None, C.byref(v) if v is not None else None,
+                                    C.byref(wgrad_args(i)), flops=fl,
+                                    tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])))
+            else:
+                for i in range(L1, 0, -1):
+                    bwd.append(call(lib.mpnn_msconv_dgrad_vert, 'dgrad_vert', C.byref(vert_args(i)), flops=fl_v(i),
+                                    tag='h%d %d->%d' % (b.H[i], b.C[i], b.C[i - 1]),
+                                    stream=sid[b.H[i - 1]], waits=[Gn(b, i)], records=Gn(b, i - 1)))
+                if b.parent is not None:
+                    for i in range(b.L):
+                        bwd.append(call(lib.mpnn_msconv_dgrad_horz, 'dgrad_horz', C.byref(horz_args(i)), flops=fl_h(i),
+                                        tag='h%d %d->%d' % (b.H[i], b.C[i], b.parent.C[b.in_map[i]]),
+                                        stream=sid[b.H[i]]))
+                for i in range(b.L):
+                    bwd.append(call(lib.mpnn_msconv_wgrad, 'wgrad', C.byref(wgrad_args(i)), flops=fl_w(i),
+                                    tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i]),
+                                    stream=wg_streams[i % 2], waits=[Gn(b, i)]))
         bwd.append(marker('join'))
         if slab_plan['size']:
             slab = torch.empty(slab_plan['size'], device=self.dev)
