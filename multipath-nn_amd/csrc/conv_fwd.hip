@@ -13,3 +13,83 @@ extern "C" int mpnn_msconv_fwd(const mpnn_conv_fwd_args *a, void *stream) {
     p.out_nslot = a->out_nslot < 1 ? 1 : (a->out_nslot > MPNN_BN_SLOTS ? MPNN_BN_SLOTS : a->out_nslot);
     return conv_launch<EPI_FWD>(p, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------
+// mpnn_msconv_fwd_group: up to four forward convs that do not depend on each other (one wavefront
+// level of the block x scale grid: F(b, k) needs only F(b-1, k) and F(b, k-1)) as ONE launch.
+// Rows of the grid are dealt to the members; each member runs the body of its own geometry.
+// The members' serial latency chains overlap instead of queueing as separate launches.
+// ---------------------------------------------------------------------------
+struct FwdGroupP { ConvP p[4]; int gk[4], small[4], gy[4], gx[4], y0[4]; int n; };
+
+__global__ __launch_bounds__(256) void fwd_group_k(const FwdGroupP q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // sized by the host for the members present
+    const int by = blockIdx.y, bx = blockIdx.x;
+    int m = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (k < q.n && by >= q.y0[k]) m = k;
+    if (bx >= q.gx[m]) return;
+    const ConvP &p = q.p[m];
+    const int yy = by - q.y0[m], gx = q.gx[m];
+    switch (q.gk[m] * 2 + q.small[m]) {
+        case 0: conv_body<0, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
+        case 1: conv_body<0, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
+        case 2: conv_body<1, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
+        case 3: conv_body<1, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
+        case 4: conv_body<2, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
+        default: conv_body<2, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
+    }
+}
+
+static int fill_fwd(const mpnn_conv_fwd_args *a, ConvP &p) {
+    if (!a || !a->a.x || !a->wa_pack || !a->out || !a->bias) return MPNN_E_ARG;
+    if (a->v && !a->wv_pack) return MPNN_E_ARG;
+    p.a = a->a;
+    p.v = a->v;  p.Cv = a->v ? a->Cv : 0;
+    p.wa = a->wa_pack;  p.wv = a->wv_pack;
+    p.n = a->n;  p.H = a->H;  p.W = a->W;  p.Cout = a->Cout;
+    p.bias = a->bias;  p.out = a->out;  p.out_sum = a->out_sum;
+    p.out_nslot = a->out_nslot < 1 ? 1 : (a->out_nslot > MPNN_BN_SLOTS ? MPNN_BN_SLOTS : a->out_nslot);
+    return 0;
+}
+
+extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, int count, void *stream) {
+    if (count <= 0) return 0;
+    if (!args || count > 4) return MPNN_E_ARG;
+    FwdGroupP q = {};
+    int rows = 0, gxm = 0;
+    for (int k = 0; k < count; ++k) {
+        ConvP &p = q.p[k];
+        int rc = fill_fwd(&args[k], p);
+        if (rc) return rc;
+        if (p.n <= 0 || (p.Cout % 16) || p.a.C > 128 || p.Cv > 128 || (p.Cv & 3)) return MPNN_E_SHAPE;
+        q.small[k] = p.a.C <= 4;
+        if (!q.small[k] && (p.a.C & 3)) return MPNN_E_SHAPE;
+        if (p.W >= 16 && (p.W % 16) == 0 && (p.H % 4) == 0) { q.gk[k] = 0; p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); }
+        else if (p.W == 8 && p.H == 8) { q.gk[k] = 1; p.n_tiles = conv_grid_x<1>(p.n, 8, 8); }
+        else if (p.W == 4 && p.H == 4) { q.gk[k] = 2; p.n_tiles = conv_grid_x<2>(p.n, 4, 4); }
+        else return MPNN_E_SHAPE;
+        q.gy[k] = p.Cout / 16;
+        q.y0[k] = rows;
+        rows += q.gy[k];
+    }
+    // Share the ~1024 resident workgroup slots (256 CUs x 4) between the members in proportion to
+    // their tile-rows, so that every member is resident from the start (a member that fills all
+    // slots by itself makes the others queue behind it and the launch takes the SUM of its members).
+    long total = 0;
+    for (int k = 0; k < count; ++k) total += (long)q.p[k].n_tiles * q.gy[k];
+    for (int k = 0; k < count; ++k) {
+        long g = count == 1 ? conv_cap_gx(q.p[k].n_tiles, q.gy[k]) : (1024L * q.p[k].n_tiles) / (total > 0 ? total : 1);
+        if (g < 16) g = 16;
+        if (g > q.p[k].n_tiles) g = q.p[k].n_tiles;
+        q.gx[k] = (int)g;
+        if (q.gx[k] > gxm) gxm = q.gx[k];
+    }
+    q.n = count;
+    const int bytes[3] = {ConvSmem<0, 4, 16>::BYTES, ConvSmem<1, 4, 16>::BYTES, ConvSmem<2, 4, 16>::BYTES};
+    int lds = 0;
+    for (int k = 0; k < count; ++k) if (bytes[q.gk[k]] > lds) lds = bytes[q.gk[k]];
+    hipLaunchKernelGGL(fwd_group_k, dim3(gxm, rows), dim3(256), lds, (hipStream_t)stream, q);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}

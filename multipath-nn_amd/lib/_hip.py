@@ -86,6 +86,7 @@ class RouteArgs(C.Structure):
 _SIGS = {
     'mpnn_pack_weights': [P, P, P, C.c_int, P],
     'mpnn_msconv_fwd': [C.POINTER(ConvFwdArgs), P],
+    'mpnn_msconv_fwd_group': [C.POINTER(ConvFwdArgs), C.c_int, P],
     'mpnn_bn_bwd_reduce': [P, C.POINTER(BnCtx), P, P, C.c_long, P],
     'mpnn_bn_bwd_apply': [P, C.POINTER(BnCtx), C.c_long, P],
     'mpnn_msconv_dgrad_horz': [C.POINTER(DgradHorzArgs), P],

@@ -432,26 +432,54 @@ class Engine:
 
         # ---- forward convs ----
         fwd.append(marker('fork'))
-        for b in self.blocks:
-            cp = b.conv.params
-            for i in range(b.L):
-                a = _hip.ConvFwdArgs()
-                a.a = self._act_of_input(b, i, n, act_mode)
-                if i > 0:
-                    a.v, a.Cv = b.s[i - 1].data_ptr(), b.C[i - 1]
-                    a.wv_pack = self.packs[b.pack['w_vert_%i' % (i - 1)][0]:].data_ptr()
-                a.wa_pack = self.packs[b.pack['w_horz_%i' % i][0]:].data_ptr()
-                a.bias = getattr(cp, 'b_%i' % i).data.data_ptr()
-                a.out = b.s[i].data_ptr()
-                a.out_sum = self.dsum[b.sum_off[i]:].data_ptr() if mode == 'tr' else None
-                a.out_nslot = self._nslot(b, i)
-                a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
-                keep.append(a)
-                fl = 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
-                fwd.append(call(lib.mpnn_msconv_fwd, 'msconv_fwd', C.byref(a), flops=fl,
-                                tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i]),
-                                stream=sid[b.H[i]], waits=[F(b, i - 1)] if i > 0 else [], records=F(b, i)))
 
+        def fwd_args(b, i, a):
+            cp = b.conv.params
+            a.a = self._act_of_input(b, i, n, act_mode)
+            if i > 0:
+                a.v, a.Cv = b.s[i - 1].data_ptr(), b.C[i - 1]
+                a.wv_pack = self.packs[b.pack['w_vert_%i' % (i - 1)][0]:].data_ptr()
+            a.wa_pack = self.packs[b.pack['w_horz_%i' % i][0]:].data_ptr()
+            a.bias = getattr(cp, 'b_%i' % i).data.data_ptr()
+            a.out = b.s[i].data_ptr()
+            a.out_sum = self.dsum[b.sum_off[i]:].data_ptr() if mode == 'tr' else None
+            a.out_nslot = self._nslot(b, i)
+            a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
+
+        fl_f = lambda b, i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
+        tag_f = lambda b, i: 'h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])
+        groupable = all(b.parent is not None or b.in_map is None for b in self.blocks) and \
+            all(c % 16 == 0 and not (c % 64 == 0 and h >= 16) for b in self.blocks for c, h in zip(b.C, b.H))
+        if not self.multi_stream and groupable and all(len(self.nodes[b.node.parent].layer.sinks) >= 1 for b in self.blocks):
+            # Wavefront over the block x scale grid: F(b, k) needs only F(b-1, k) and F(b, k-1), so level
+            # d = depth(b) + k is one launch of mutually independent convs.
+            kidx = {h: k for k, h in enumerate(sizes)}
+            depth = {}
+            for b in self.blocks:
+                depth[id(b)] = 0 if b.parent is None else depth[id(b.parent)] + 1
+            levels = {}
+            for b in self.blocks:
+                for i in range(b.L):
+                    levels.setdefault(depth[id(b)] + kidx[b.H[i]], []).append((b, i))
+            for d in sorted(levels):
+                members = levels[d]
+                for c0 in range(0, len(members), 4):
+                    grp = members[c0:c0 + 4]
+                    arr = (_hip.ConvFwdArgs * len(grp))()
+                    for a, (b, i) in zip(arr, grp):
+                        fwd_args(b, i, a)
+                    keep.append(arr)
+                    fwd.append(call(lib.mpnn_msconv_fwd_group, 'fwd_group', arr, len(grp),
+                                    flops=sum(fl_f(b, i) for b, i in grp),
+                                    tag=' | '.join(tag_f(b, i) for b, i in grp)))
+        else:
+            for b in self.blocks:
+                for i in range(b.L):
+                    a = _hip.ConvFwdArgs()
+                    fwd_args(b, i, a)
+                    keep.append(a)
+                    fwd.append(call(lib.mpnn_msconv_fwd, 'msconv_fwd', C.byref(a), flops=fl_f(b, i), tag=tag_f(b, i),
+                                    stream=sid[b.H[i]], waits=[F(b, i - 1)] if i > 0 else [], records=F(b, i)))
         fwd.append(marker('join'))
 
         # ---- exits ----
