@@ -118,6 +118,8 @@ int mpnn_bn_bwd_apply(float *dz_inout, const mpnn_bn_ctx *ctx, long n_pix,
  * Autodiff of layer_types.py:181-185. */
 typedef struct {
     const float *g;  int Cg;            /* [n,H,W,Cg] gradient w.r.t. pre-BN sums */
+    const mpnn_bn_ctx *g_ctx;            /* non-NULL: `g` holds dz and the BatchNorm backward
+                                            (mpnn_bn_bwd_apply) is applied while loading it */
     const float *w_pack;                 /* backward pack                          */
     const float *dy_extra;               /* [n,H,W,Cout] or NULL                   */
     const mpnn_bn_ctx *prev;             /* producer BatchNorm context or NULL     */
@@ -129,6 +131,7 @@ int mpnn_msconv_dgrad_horz(const mpnn_dgrad_horz_args *args, void *stream);
 
 typedef struct {
     const float *g;  int Cg;            /* coarse gradient [n,H,W,Cg]             */
+    const mpnn_bn_ctx *g_ctx;            /* as in mpnn_dgrad_horz_args              */
     const float *w_pack;                 /* backward pack of w_vert                */
     const mpnn_bn_ctx *fine;             /* BatchNorm context of the finer scale   */
     int fine_has_dz;                     /* 0: finer BN output has no consumer     */
@@ -152,6 +155,7 @@ typedef struct {
     mpnn_act a;
     const float *v;  int Cv;
     const float *g;                      /* [n,H,W,Cout]                           */
+    const mpnn_bn_ctx *g_ctx;            /* as in mpnn_dgrad_horz_args              */
     float *dwa;  float *dwv;  float *db; /* HWIO partial sums of split 0, [Cout]   */
     long split_stride;                   /* floats between consecutive splits      */
     int n, H, W, Cout;

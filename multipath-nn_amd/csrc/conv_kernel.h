@@ -41,6 +41,8 @@ struct ConvP {
     const float *sprev;  mpnn_act pbn;  double *red_out;    // EPI_DGH_BN / EPI_DGV
     const double *red;  int has_dz;  int red_nslot;         // EPI_DGV
     int out_nslot;                                          // slots of out_sum / red_out
+    // operand A = BatchNorm backward of dz (mpnn_bn_bwd_apply on load): A = k1*(dz - r0 - xhat*r1)
+    const float *ga_s;  mpnn_act ga_bn;  const double *ga_red;  int ga_nslot;  int ga_on;
     int n_tiles;                                            // set by the launcher
     int dbg;                                                // ablation mask (MPNN_CONV_DBG), 0 in production
 };
@@ -114,16 +116,21 @@ __device__ __forceinline__ bool x_item(int i, int n0, int y0, int x0, int np, co
 template <int GK, int MODE, int XW>
 __device__ __forceinline__ void load_x(f32x4 (*xr)[XW], const ConvP &p, int n0, int y0, int x0, int c0, int np, int tid) {
     using X = XItems<GK>;
-    static_assert(MODE == 0 || XW == 4, "pooling needs four raw registers per item");
+    static_assert(MODE != 1 || XW == 4, "pooling needs four raw registers per item");
+    static_assert(MODE != 2 || XW >= 2, "BatchNorm-backward-on-load needs two raw registers per item");
 #pragma unroll
     for (int k = 0; k < X::N; ++k) {
         int q, slot, n, y, x; bool inb;
         const bool ok = x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb);
 #pragma unroll
-        for (int w = 0; w < (MODE ? 4 : 1); ++w) xr[k][w] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < (MODE == 1 ? 4 : (MODE == 2 ? 2 : 1)); ++w) xr[k][w] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ok && inb) {
             const int c = c0 + q * 4;
-            if (MODE == 0) {
+            if (MODE == 2) {
+                const size_t off = (((size_t)n * p.H + y) * p.W + x) * p.a.C + c;
+                xr[k][0] = *(const f32x4 *)(p.a.x + off);
+                xr[k][1 % XW] = *(const f32x4 *)(p.ga_s + off);
+            } else if (MODE == 0) {
                 const int sh = p.a.shift, C = p.a.C;
                 const size_t base = (((size_t)n * (p.H << sh) + (y << sh)) * (p.W << sh) + (x << sh)) * C;
                 if ((C & 3) == 0) {
@@ -154,7 +161,15 @@ __device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], cons
         if (!x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb)) continue;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (inb) {
-            if (MODE == 0) {
+            if (MODE == 2) {                       // cA rows: m, rstd, k1, r0, r1
+                const int c = c0 + q * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float *cc = cA + (c + j) * 5;
+                    const float xh = (xr[k][1 % XW][j] - cc[0]) * cc[1];
+                    v[j] = cc[2] * (xr[k][0][j] - cc[3] - xh * cc[4]);
+                }
+            } else if (MODE == 0) {
                 v = xr[k][0];
                 if (p.a.mode != MPNN_ACT_IDENTITY) {
                     const int c = c0 + q * 4;
@@ -184,7 +199,7 @@ __device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], cons
 // LDS bytes of one workgroup (all variants of a launch share one arena).
 template <int GK, int WM, int CT>
 struct ConvSmem {
-    static constexpr int TILE = 2 * 4 * Geom<GK>::P * 16, WT = 2 * 36 * CT * 16, CA = 128 * 3 * 4, CE = CT * 5 * 4,
+    static constexpr int TILE = 2 * 4 * Geom<GK>::P * 16, WT = 2 * 36 * CT * 16, CA = 128 * 5 * 4, CE = CT * 5 * 4,
                          RED = WM * CT * 2 * 8;
     static constexpr int BYTES = TILE + WT + CA + ((CE + 15) & ~15) + RED;
 };
@@ -194,7 +209,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     using G = Geom<GK>;
     constexpr int P = G::P, R = G::R, HR = G::TH + 2;
     constexpr int CT = WN * NT * 16;
-    constexpr int XW = EPI == EPI_FWD ? 4 : 1;      // only the forward conv has a pooled operand
+    constexpr int XW = EPI == EPI_FWD ? 4 : 2;      // forward: pooled operand (4); dgrad: dz + s when BN-backward is applied on load (2)
     constexpr int XN = XItems<GK>::N;
     static_assert(WM * WN == 4 && WM * MT == 4, "4 waves, 4 M-tiles per workgroup");
 
@@ -204,7 +219,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     f32x4 (*tile)[4 * P] = (f32x4 (*)[4 * P])smem;
     f32x4 (*wtile)[BI] = (f32x4 (*)[BI])(smem + SM::TILE);
     float *cA = (float *)(smem + SM::TILE + SM::WT);
-    float *cE = cA + 128 * 3;
+    float *cE = cA + 128 * 5;
     double *redbuf = (double *)(smem + SM::TILE + SM::WT + SM::CA + ((SM::CE + 15) & ~15));
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -218,6 +233,16 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         for (int c = tid; c < p.a.C; c += 256) {
             const BnC k = bn_coef(p.a, c);
             cA[c * 3] = k.m; cA[c * 3 + 1] = k.gamma * k.rstd; cA[c * 3 + 2] = k.beta;
+        }
+    }
+    if (EPI != EPI_FWD && p.ga_on) {
+        const double inv = 1.0 / (double)p.ga_bn.cnt;
+        for (int c = tid; c < p.a.C; c += 256) {
+            const BnC k = bn_coef(p.ga_bn, c);
+            float *e = cA + c * 5;
+            e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
+            e[3] = (float)(slot_sum(p.ga_red, 2 * p.a.C, c, p.ga_nslot) * inv);
+            e[4] = (float)(slot_sum(p.ga_red, 2 * p.a.C, p.a.C + c, p.ga_nslot) * inv);
         }
     }
     if (EPI == EPI_DGH_BN || EPI == EPI_DGV) {
@@ -305,6 +330,13 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                 store_x<GK, P, 1, XW>(tile[0], xr, p, cA, n0, y0, x0, ch * 16, np, tid);
             }
         }
+        if constexpr (EPI != EPI_FWD) {
+            if (p.ga_on) {
+                pooled = true;
+                load_x<GK, 2, XW>(xr, p, n0, y0, x0, ch * 16, np, tid);
+                store_x<GK, P, 2, XW>(tile[0], xr, p, cA, n0, y0, x0, ch * 16, np, tid);
+            }
+        }
         if (!pooled) {
             load_x<GK, 0, XW>(xr, p, n0, y0, x0, ch * 16, np, tid);
             store_x<GK, P, 0, XW>(tile[0], xr, p, cA, n0, y0, x0, ch * 16, np, tid);
@@ -323,6 +355,9 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             bool pooled = false;
             if constexpr (XW == 4) {
                 if (part2) { pooled = true; load_x<GK, 1, XW>(xr, p, m0, v0, u0, ch2 * 16, np2, tid); }
+            }
+            if constexpr (EPI != EPI_FWD) {
+                if (p.ga_on) { pooled = true; load_x<GK, 2, XW>(xr, p, m0, v0, u0, ch2 * 16, np2, tid); }
             }
             if (!pooled) load_x<GK, 0, XW>(xr, p, m0, v0, u0, ch2 * 16, np2, tid);
             if (!b_once) load_b(part2, ch2);
@@ -436,6 +471,9 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             bool pooled = false;
             if constexpr (XW == 4) {
                 if (part2) { pooled = true; store_x<GK, P, 1, XW>(nxt, xr, p, cA, m0, v0, u0, ch2 * 16, np2, tid); }
+            }
+            if constexpr (EPI != EPI_FWD) {
+                if (p.ga_on) { pooled = true; store_x<GK, P, 2, XW>(nxt, xr, p, cA, m0, v0, u0, ch2 * 16, np2, tid); }
             }
             if (!pooled) store_x<GK, P, 0, XW>(nxt, xr, p, cA, m0, v0, u0, ch2 * 16, np2, tid);
             if (!b_once) store_b(wtile[(u + 1) & 1]);

@@ -26,6 +26,7 @@
 struct WgP {
     ConvP c;                 // a, v, Cv, n, H, W, Cout
     const float *g;
+    const float *g_s;  mpnn_act g_bn;  const double *g_red;  int g_nslot;  int g_on;   // g = bn_bwd_apply(dz) on load
     float *dwa, *dwv, *db;   // partial-sum destinations of split 0
     long split_stride;       // floats between consecutive splits' destinations
     int n_tiles;
@@ -37,7 +38,7 @@ template <> struct WGeom<1> { static constexpr int PS = 241; };
 template <> struct WGeom<2> { static constexpr int PS = 289; };
 
 template <int GK, int OT>
-__device__ __forceinline__ void load_g(f32x4 *gr, const WgP &p, int n0, int y0, int x0, int co0, int tid) {
+__device__ __forceinline__ void load_g(f32x4 *gr, f32x4 *gs, const WgP &p, int n0, int y0, int x0, int co0, int tid) {
 #pragma unroll
     for (int k = 0; k < OT; ++k) {
         const int i = tid + k * 256;                   // 64 * OT * 4 items
@@ -45,10 +46,13 @@ __device__ __forceinline__ void load_g(f32x4 *gr, const WgP &p, int n0, int y0, 
         int img, ty, tx;
         mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
         const int n = n0 + img;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < p.c.n)
-            v = *(const f32x4 *)(p.g + (((size_t)n * p.c.H + y0 + ty) * p.c.W + x0 + tx) * p.c.Cout + co0 + q * 4);
-        gr[k] = v;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.c.n) {
+            const size_t off = (((size_t)n * p.c.H + y0 + ty) * p.c.W + x0 + tx) * p.c.Cout + co0 + q * 4;
+            v = *(const f32x4 *)(p.g + off);
+            if (p.g_on) sv = *(const f32x4 *)(p.g_s + off);
+        }
+        gr[k] = v; gs[k] = sv;
     }
 }
 
@@ -80,6 +84,20 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         __syncthreads();
     }
 
+    float *cG = cA + 128 * 3;                        // [OT*16][5]: BatchNorm-backward coefficients of this cout group
+    if (p.g_on) {
+        const double inv = 1.0 / (double)p.g_bn.cnt;
+        for (int cc = tid; cc < OT * 16; cc += 256) {
+            const int co = co0 + cc;
+            const BnC k = bn_coef(p.g_bn, co);
+            float *e = cG + cc * 5;
+            e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
+            e[3] = (float)(slot_sum(p.g_red, 2 * c.Cout, co, p.g_nslot) * inv);
+            e[4] = (float)(slot_sum(p.g_red, 2 * c.Cout, c.Cout + co, p.g_nslot) * inv);
+        }
+        __syncthreads();
+    }
+
     f32x4 acc[3][OT];
 #pragma unroll
     for (int ti = 0; ti < 3; ++ti)
@@ -98,13 +116,13 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         tap_off[ti] = (tap / 3) * R + (tap % 3);
     }
 
-    f32x4 xr[XN][PART ? 4 : 1], gr[OT];
+    f32x4 xr[XN][PART ? 4 : 1], gr[OT], gs[OT];
     int t = bx;
     int n0, y0, x0, cn0 = 0, cy0 = 0, cx0 = 0;
     if (t < p.n_tiles) {
         tile_origin<GK>(c, t, n0, y0, x0);
         load_x<GK, PART, (PART ? 4 : 1)>(xr, c, n0, y0, x0, ch * 16, np, tid);
-        load_g<GK, OT>(gr, p, n0, y0, x0, co0, tid);
+        load_g<GK, OT>(gr, gs, p, n0, y0, x0, co0, tid);
         cn0 = n0; cy0 = y0; cx0 = x0;
     }
     for (; t < p.n_tiles; t += gx) {
@@ -113,14 +131,28 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
 #pragma unroll
         for (int k = 0; k < OT; ++k) {
             const int i = tid + k * 256;
-            *(f32x4 *)(gt + (i / (OT * 4)) * GS + (i % (OT * 4)) * 4) = gr[k];
+            f32x4 v = gr[k];
+            if (p.g_on) {
+                const int q = i % (OT * 4), pi = i / (OT * 4);
+                int img, ty, tx;
+                mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
+                if (cn0 + img < c.n) {                 // (out-of-range images stay exactly zero)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float *e = cG + (q * 4 + j) * 5;
+                        const float xh = (gs[k][j] - e[0]) * e[1];
+                        v[j] = e[2] * (v[j] - e[3] - xh * e[4]);
+                    }
+                }
+            }
+            *(f32x4 *)(gt + (i / (OT * 4)) * GS + (i % (OT * 4)) * 4) = v;
         }
         __syncthreads();
         const int tn = t + gx;
         if (tn < p.n_tiles) {                          // next tile's loads fly under the MFMAs
             tile_origin<GK>(c, tn, n0, y0, x0);
             load_x<GK, PART, (PART ? 4 : 1)>(xr, c, n0, y0, x0, ch * 16, np, tid);
-            load_g<GK, OT>(gr, p, n0, y0, x0, co0, tid);
+            load_g<GK, OT>(gr, gs, p, n0, y0, x0, co0, tid);
             cn0 = n0; cy0 = y0; cx0 = x0;
         }
 #pragma unroll
@@ -174,7 +206,7 @@ __global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
     constexpr int PS = WGeom<GK>::PS, GS = OT * 16 + 4;
     __shared__ f32x4 tile[4 * PS];
     __shared__ float gt[64 * GS];
-    __shared__ float cA[128 * 3];
+    __shared__ float cA[128 * 3 + OT * 16 * 5];
     if ((int)blockIdx.y >= ((p.c.a.C + 15) >> 4)) wgrad_body<GK, OT, 1>(p, tile, gt, cA, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
     else                                           wgrad_body<GK, OT, 0>(p, tile, gt, cA, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
@@ -197,7 +229,7 @@ template <int GK, int OT>
 __global__ __launch_bounds__(256) void bwd_scale_k(const BwdScaleP q) {
     constexpr int CB = ConvSmem<GK, 4, 16>::BYTES;
     constexpr int GS = OT * 16 + 4;
-    constexpr int WB = 4 * WGeom<GK>::PS * 16 + 64 * GS * 4 + 128 * 3 * 4;
+    constexpr int WB = 4 * WGeom<GK>::PS * 16 + 64 * GS * 4 + (128 * 3 + OT * 16 * 5) * 4;
     __shared__ __attribute__((aligned(16))) char smem[CB > WB ? CB : WB];
     const int by = blockIdx.y, bx = blockIdx.x;
     if (by < q.gyh) {
@@ -239,21 +271,14 @@ extern "C" int mpnn_wgrad_tiles(int n, int H, int W) {
     return MPNN_E_SHAPE;
 }
 
+static int fill_wgrad(const mpnn_wgrad_args *a, WgP &p, int &split);
+
 extern "C" int mpnn_msconv_wgrad(const mpnn_wgrad_args *a, void *stream) {
-    if (!a || !a->a.x || !a->g || !a->dwa || !a->db) return MPNN_E_ARG;
-    if (a->v && !a->dwv) return MPNN_E_ARG;
-    if (a->n <= 0) return 0;
-    if (a->a.C > 128 || a->Cv > 128 || (a->Cv & 3)) return MPNN_E_SHAPE;
-    if (a->a.C > 4 && (a->a.C & 3)) return MPNN_E_SHAPE;
-    const int tiles = mpnn_wgrad_tiles(a->n, a->H, a->W);
-    if (tiles < 0) return tiles;
-    const int split = a->n_split < 1 ? 1 : (a->n_split > tiles ? tiles : a->n_split);
-    if (split > 1 && a->split_stride <= 0) return MPNN_E_ARG;
+    if (a && a->n <= 0) return 0;
     WgP p = {};
-    p.c.a = a->a;  p.c.v = a->v;  p.c.Cv = a->v ? a->Cv : 0;
-    p.c.n = a->n;  p.c.H = a->H;  p.c.W = a->W;  p.c.Cout = a->Cout;
-    p.g = a->g;  p.dwa = a->dwa;  p.dwv = a->dwv;  p.db = a->db;
-    p.split_stride = a->split_stride;  p.n_tiles = tiles;
+    int split = 1;
+    const int rc = fill_wgrad(a, p, split);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (a->W >= 16) return wgrad_launch<0>(p, split, st);
     if (a->W == 8) return wgrad_launch<1>(p, split, st);
@@ -273,6 +298,11 @@ static int fill_wgrad(const mpnn_wgrad_args *a, WgP &p, int &split) {
     p.c.n = a->n;  p.c.H = a->H;  p.c.W = a->W;  p.c.Cout = a->Cout;
     p.g = a->g;  p.dwa = a->dwa;  p.dwv = a->dwv;  p.db = a->db;
     p.split_stride = a->split_stride;  p.n_tiles = tiles;
+    if (a->g_ctx) {
+        if (!a->g_ctx->s || !a->g_ctx->red) return MPNN_E_ARG;
+        p.g_on = 1;  p.g_s = a->g_ctx->s;  p.g_bn = a->g_ctx->bn;  p.g_red = a->g_ctx->red;
+        p.g_nslot = a->g_ctx->red_nslot < 1 ? 1 : a->g_ctx->red_nslot;
+    }
     return 0;
 }
 

@@ -35,17 +35,20 @@ class BnCtx(C.Structure):
 
 
 class DgradHorzArgs(C.Structure):
-    _fields_ = [('g', P), ('Cg', C.c_int), ('w_pack', P), ('dy_extra', P), ('prev', C.POINTER(BnCtx)),
+    _fields_ = [('g', P), ('Cg', C.c_int), ('g_ctx', C.POINTER(BnCtx)), ('w_pack', P), ('dy_extra', P),
+                ('prev', C.POINTER(BnCtx)),
                 ('out', P), ('red_out', P), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int)]
 
 
 class DgradVertArgs(C.Structure):
-    _fields_ = [('g', P), ('Cg', C.c_int), ('w_pack', P), ('fine', C.POINTER(BnCtx)), ('fine_has_dz', C.c_int),
+    _fields_ = [('g', P), ('Cg', C.c_int), ('g_ctx', C.POINTER(BnCtx)), ('w_pack', P), ('fine', C.POINTER(BnCtx)),
+                ('fine_has_dz', C.c_int),
                 ('dz_g_fine', P), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int)]
 
 
 class WgradArgs(C.Structure):
-    _fields_ = [('a', Act), ('v', P), ('Cv', C.c_int), ('g', P), ('dwa', P), ('dwv', P), ('db', P),
+    _fields_ = [('a', Act), ('v', P), ('Cv', C.c_int), ('g', P), ('g_ctx', C.POINTER(BnCtx)), ('dwa', P), ('dwv', P),
+                ('db', P),
                 ('split_stride', C.c_long), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int), ('n_split', C.c_int)]
 
 

@@ -588,14 +588,22 @@ class Engine:
                 bwd.append(call(lib.mpnn_bn_bwd_reduce, 'bn_bwd_reduce', b.dx.data_ptr(), C.byref(ctx),
                                 b.dzg[L1].data_ptr(), self.dred[b.sum_off[L1]:].data_ptr(),
                                 n * b.H[L1] * b.W[L1], stream=sid[b.H[L1]]))
-            ctx = self._bn_ctx(b, L1, n)
-            bwd.append(call(lib.mpnn_bn_bwd_apply, 'bn_bwd_apply', b.dzg[L1].data_ptr(), C.byref(ctx),
-                            n * b.H[L1] * b.W[L1], stream=sid[b.H[L1]], records=Gn(b, L1)))
+            # g of the coarsest scale = BatchNorm backward of dz: its own launch in the multi-stream
+            # schedule, applied while loading by the three consumers in the fused schedule.
+            g_ctx = None
+            if self.multi_stream:
+                ctx = self._bn_ctx(b, L1, n)
+                bwd.append(call(lib.mpnn_bn_bwd_apply, 'bn_bwd_apply', b.dzg[L1].data_ptr(), C.byref(ctx),
+                                n * b.H[L1] * b.W[L1], stream=sid[b.H[L1]], records=Gn(b, L1)))
+            else:
+                g_ctx = C.pointer(self._bn_ctx(b, L1, n))
 
             def vert_args(i):
                 a = _hip.DgradVertArgs()
                 fine = self._bn_ctx(b, i - 1, n)
                 a.g, a.Cg = b.dzg[i].data_ptr(), b.C[i]
+                if i == L1 and g_ctx is not None:
+                    a.g_ctx = g_ctx
                 a.w_pack = self.packs[b.pack['w_vert_%i' % (i - 1)][1]:].data_ptr()
                 a.fine = C.pointer(fine)
                 a.fine_has_dz = 1 if b.has_dz[i - 1] else 0
@@ -608,6 +616,8 @@ class Engine:
                 pb, j = b.parent, b.in_map[i]
                 a = _hip.DgradHorzArgs()
                 a.g, a.Cg = b.dzg[i].data_ptr(), b.C[i]
+                if i == L1 and g_ctx is not None:
+                    a.g_ctx = g_ctx
                 a.w_pack = self.packs[b.pack['w_horz_%i' % i][1]:].data_ptr()
                 a.dy_extra = pb.dx.data_ptr() if (pb.has_exit and j == pb.L - 1) else None
                 prev = self._bn_ctx(pb, j, n, with_red=False)
@@ -629,6 +639,8 @@ class Engine:
                 if i > 0:
                     a.v, a.Cv = b.s[i - 1].data_ptr(), b.C[i - 1]
                 a.g = b.dzg[i].data_ptr()
+                if i == L1 and g_ctx is not None:
+                    a.g_ctx = g_ctx
                 a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
                 split = self._wsplit(b, i, n, fused=not self.multi_stream)
                 a.n_split = split
