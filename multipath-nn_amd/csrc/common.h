@@ -5,6 +5,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Minimum waves per SIMD requested from the register allocator for the grouped (latency-bound)
+// kernels: 4 workgroups of 256 threads per CU.
+#ifndef MPNN_OCC
+#define MPNN_OCC 4
+#endif
+
 #define MPNN_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) return (int)e_; } while (0)
 

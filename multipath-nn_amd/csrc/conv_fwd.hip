@@ -22,7 +22,7 @@ extern "C" int mpnn_msconv_fwd(const mpnn_conv_fwd_args *a, void *stream) {
 // ---------------------------------------------------------------------------
 struct FwdGroupP { ConvP p[4]; int gk[4], small[4], gy[4], gx[4], y0[4]; int n; };
 
-__global__ __launch_bounds__(256) void fwd_group_k(const FwdGroupP q) {
+__global__ __launch_bounds__(256, MPNN_OCC) void fwd_group_k(const FwdGroupP q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // sized by the host for the members present
     const int by = blockIdx.y, bx = blockIdx.x;
     int m = 0;

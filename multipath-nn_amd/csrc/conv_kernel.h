@@ -49,10 +49,14 @@ struct ConvP {
 
 // Geometry kinds.  TH x TW output pixels per image x IMG images = 64 pixels;
 // an M-tile is 16 of them.  R = LDS row stride (slots), P = plane stride.
+// The small-map geometries use DENSE halo rows (R = halo width): two of the 16
+// lanes of a ds_read_b128 group then share a bank (one extra LDS cycle per read),
+// in exchange for half the LDS footprint -> 4 instead of 2 workgroups per CU for
+// kernels that are bound by latency, not by LDS bandwidth.
 template <int GK> struct Geom;
 template <> struct Geom<0> { static constexpr int TH = 4, TW = 16, IMG = 1, R = 18, P = 112; };  // W % 16 == 0
-template <> struct Geom<1> { static constexpr int TH = 8, TW = 8,  IMG = 1, R = 24, P = 240; };  // 8 x 8 maps
-template <> struct Geom<2> { static constexpr int TH = 4, TW = 4,  IMG = 4, R = 12, P = 288; };  // 4 x 4 maps
+template <> struct Geom<1> { static constexpr int TH = 8, TW = 8,  IMG = 1, R = 10, P = 112; };  // 8 x 8 maps
+template <> struct Geom<2> { static constexpr int TH = 4, TW = 4,  IMG = 4, R = 6,  P = 144; };  // 4 x 4 maps
 
 template <int GK>
 __device__ __forceinline__ void mtile_pix(int m, int i, int &img, int &ty, int &tx) {

@@ -34,8 +34,8 @@ struct WgP {
 
 template <int GK> struct WGeom;
 template <> struct WGeom<0> { static constexpr int PS = 113; };
-template <> struct WGeom<1> { static constexpr int PS = 241; };
-template <> struct WGeom<2> { static constexpr int PS = 289; };
+template <> struct WGeom<1> { static constexpr int PS = 113; };
+template <> struct WGeom<2> { static constexpr int PS = 145; };
 
 template <int GK, int OT>
 __device__ __forceinline__ void load_g(f32x4 *gr, f32x4 *gs, const WgP &p, int n0, int y0, int x0, int co0, int tid) {
@@ -226,7 +226,7 @@ struct BwdScaleP {
 };
 
 template <int GK, int OT>
-__global__ __launch_bounds__(256) void bwd_scale_k(const BwdScaleP q) {
+__global__ __launch_bounds__(256, (OT == 1 ? MPNN_OCC : 2)) void bwd_scale_k(const BwdScaleP q) {
     constexpr int CB = ConvSmem<GK, 4, 16>::BYTES;
     constexpr int GS = OT * 16 + 4;
     constexpr int WB = 4 * WGeom<GK>::PS * 16 + 64 * GS * 4 + (128 * 3 + OT * 16 * 5) * 4;
