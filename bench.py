@@ -35,7 +35,7 @@ def synthetic(n, seed, device):
     return x0.to(device), y.to(device)
 
 
-def cpu_baseline(batch, seconds=15.0):
+def cpu_baseline(batch, seconds=24.0):
     """The oracle (oracle/ref_net.py, torch-CPU fp32, all host cores) on the same step."""
     import arch_and_hypers as A
     from oracle.ref_net import RefNet
@@ -50,19 +50,30 @@ def cpu_baseline(batch, seconds=15.0):
     ref.load_params(vals)
     x0, y = synthetic(batch, 0, 'cpu')
     x0, y = x0.numpy(), y.numpy()
-    times = []
-    t_end = time.time() + seconds
-    for i in range(1000):
-        t0 = time.time()
-        ref.train_step(x0, y, 0.1, τ=1.0)
-        if i >= 2:
-            times.append(time.time() - t0)
-        if time.time() > t_end and len(times) >= 3:
-            break
-    med = float(np.median(times))
-    return dict(value=batch / med, unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d timed steps of batch %d (median %.1f ms/step), oracle/ref_net.py torch-CPU fp32'
-                       % (len(times), batch, med * 1e3))
+    all_cores = torch.get_num_threads()
+    best = None
+    # torch-CPU oversubscribes on many-core hosts for this small problem: time it with all host
+    # threads and with 32 / 16, and report the fastest (cores = threads actually used).
+    tries = sorted({all_cores, min(all_cores, 32), min(all_cores, 16)}, reverse=True)
+    for threads in tries:
+        torch.set_num_threads(threads)
+        times = []
+        t_end = time.time() + seconds / len(tries)
+        for i in range(1000):
+            t0 = time.time()
+            ref.train_step(x0, y, 0.1, τ=1.0)
+            if i >= 1:
+                times.append(time.time() - t0)
+            if time.time() > t_end and len(times) >= 3:
+                break
+        med = float(np.median(times))
+        if best is None or med < best[0]:
+            best = (med, threads, len(times))
+    torch.set_num_threads(all_cores)
+    med, threads, cnt = best
+    return dict(value=batch / med, unit='images/s', cores=threads, kind='port',
+                sample='%d timed steps of batch %d (median %.1f ms/step) with %d of %d host threads (fastest of %s), '
+                       'oracle/ref_net.py torch-CPU fp32' % (cnt, batch, med * 1e3, threads, all_cores, tries))
 
 
 def main():

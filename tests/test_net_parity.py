@@ -201,6 +201,38 @@ def test_mnist_sr():
     run_case(A.sr_chain(2), 8, lambda net, t: {}, steps=2, c0=1)
 
 
+def test_ragged_batch_37():
+    """37 = two 16-row tiles + 5, three 4-image tiles + 1, more than one 32-row group in lin_bwd."""
+    import arch_and_hypers as A
+    run_case(A.ac_chain(k_cpt=8e-9), 37, lambda net, t: {net.τ: 0.9}, steps=1)
+
+
+def test_full_batch_128():
+    """The benchmark's batch size (arch_and_hypers.py:35)."""
+    import arch_and_hypers as A
+    run_case(A.cr_chain(k_cpt=1e-9), 128, lambda net, t: {net.τ: 0.1}, steps=1)
+
+
+def test_batch_of_one_eval():
+    """A single image through the evaluation path (BatchNorm moving averages; batch statistics of
+    one sample would be degenerate in 'tr')."""
+    import arch_and_hypers as A
+    from oracle.ref_net import RefNet
+    net = A.ac_chain(k_cpt=0.0)((32, 32, 3), (10,))
+    eng = net.engine()
+    eng.init_params(11)
+    perturb_routers(net)
+    ref = RefNet(net)
+    ref.load_params()
+    x0, y = batch(1, seed=4)
+    net.eval({net.x0: x0, net.y: y})
+    res = ref.forward(x0, y, 'ev')
+    for ℓ in net.leaves:
+        ce = res['out'][id(ℓ)]['c_err'].detach().numpy()
+        assert np.abs(ℓ.c_err.cpu().numpy() - ce).max() < 2e-4 * (1 + np.abs(ce).max())
+        assert np.array_equal(ℓ.p_ev.cpu().numpy(), res['out'][id(ℓ)]['p_ev'].numpy())
+
+
 def test_known_answers_at_init():
     """KA3/KA4: at initialisation every router output is exactly 0, so the test-time
     routing histogram is [1,0,...,0], moc = 1 368 608, leaf p_tr ~ 2^-(j+1)."""
