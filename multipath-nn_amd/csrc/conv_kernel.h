@@ -201,14 +201,17 @@ __device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], cons
 // other buffer before the single barrier that ends the unit.
 // ---------------------------------------------------------------------------
 // LDS bytes of one workgroup (all variants of a launch share one arena).
-template <int GK, int WM, int CT>
+template <int GK, int WM, int CT, int NCH = 1>
 struct ConvSmem {
-    static constexpr int TILE = 2 * 4 * Geom<GK>::P * 16, WT = 2 * 36 * CT * 16, CA = 128 * 5 * 4, CE = CT * 5 * 4,
+    static constexpr int TILE = NCH * 2 * 4 * Geom<GK>::P * 16, WT = NCH * 2 * 36 * CT * 16, CA = 128 * 5 * 4, CE = CT * 5 * 4,
                          RED = WM * CT * 2 * 8;
     static constexpr int BYTES = TILE + WT + CA + ((CE + 15) & ~15) + RED;
 };
 
-template <int GK, int MT, int NT, int WM, int WN, bool SMALL_A, int EPI>
+// NCH = 16-channel chunks per unit (1 or 2).  With 2 a unit spans 32 input channels: half as many
+// barriers and load round trips on the deep-K, small-M layers whose per-unit MFMA time (~0.5 us)
+// cannot cover a load latency (~2 us).  Requires every operand's channel count % 32 == 0.
+template <int GK, int MT, int NT, int WM, int WN, bool SMALL_A, int EPI, int NCH = 1>
 __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const int by, const int gx, char *smem) {
     using G = Geom<GK>;
     constexpr int P = G::P, R = G::R, HR = G::TH + 2;
@@ -219,9 +222,9 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
 
     constexpr int BI = 36 * CT;                     // float4 items of one weight chunk: [9 taps][4 g][CT]
     constexpr int BN = (BI + 255) / 256;
-    using SM = ConvSmem<GK, WM, CT>;
-    f32x4 (*tile)[4 * P] = (f32x4 (*)[4 * P])smem;
-    f32x4 (*wtile)[BI] = (f32x4 (*)[BI])(smem + SM::TILE);
+    using SM = ConvSmem<GK, WM, CT, NCH>;
+    f32x4 (*tile)[NCH * 4 * P] = (f32x4 (*)[NCH * 4 * P])smem;
+    f32x4 (*wtile)[NCH * BI] = (f32x4 (*)[NCH * BI])(smem + SM::TILE);
     float *cA = (float *)(smem + SM::TILE + SM::WT);
     float *cE = cA + 128 * 5;
     double *redbuf = (double *)(smem + SM::TILE + SM::WT + SM::CA + ((SM::CE + 15) & ~15));
@@ -274,7 +277,8 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         mtile_pix<GK>(wm * MT + mt, li, img, ty, tx);
         slot0[mt] = (img * HR + ty) * R + tx;
     }
-    const int nchA = (p.a.C + 15) >> 4, nchV = p.v ? ((p.Cv + 15) >> 4) : 0, upt = nchA + nchV;
+    const int nchA = (p.a.C + 15) >> 4, nchV = p.v ? ((p.Cv + 15) >> 4) : 0;
+    const int upt = (nchA + nchV) / NCH;            // NCH == 2: both counts are even (host-checked)
 
     const int my_tiles = (bx < p.n_tiles) ? (p.n_tiles - 1 - bx) / gx + 1 : 0;
     const int n_units = my_tiles * upt;
@@ -283,35 +287,39 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     auto decode = [&](int u, int &t, int &part, int &ch, int &np) {
         const int ti = u / upt, q = u - ti * upt;
         t = bx + ti * gx;
-        part = q >= nchA ? 1 : 0;
-        ch = part ? q - nchA : q;
+        part = q * NCH >= nchA ? 1 : 0;
+        ch = part ? q * NCH - nchA : q * NCH;          // first 16-channel chunk of the unit
         const int C = part ? p.Cv : p.a.C;
         np = (C - ch * 16 + 3) >> 2;
         np = np > 4 ? 4 : np;
     };
 
     // Weight chunk (part, ch) of the k-interleaved pack -> registers -> LDS [tap][g][CT] float4.
-    f32x4 br[BN];
+    f32x4 br[NCH * BN];
     auto load_b = [&](int part_, int ch_) {
         const float *wp = part_ ? p.wv : p.wa;
         const int nch = part_ ? nchV : nchA;
 #pragma unroll
-        for (int k = 0; k < BN; ++k) {
-            const int i = tid + k * 256;
-            br[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < BI) {
-                const int c4 = i % CT, tg = i / CT, gg = tg & 3, tap = tg >> 2;
-                br[k] = *(const f32x4 *)(wp + ((size_t)((tap * nch + ch_) * 4 + gg) * p.Cout + co0 + c4) * 4);
+        for (int sc = 0; sc < NCH; ++sc)
+#pragma unroll
+            for (int k = 0; k < BN; ++k) {
+                const int i = tid + k * 256;
+                br[sc * BN + k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (i < BI) {
+                    const int c4 = i % CT, tg = i / CT, gg = tg & 3, tap = tg >> 2;
+                    br[sc * BN + k] = *(const f32x4 *)(wp + ((size_t)((tap * nch + ch_ + sc) * 4 + gg) * p.Cout + co0 + c4) * 4);
+                }
             }
-        }
     };
     auto store_b = [&](f32x4 *dst) {
 #pragma unroll
-        for (int k = 0; k < BN; ++k) { const int i = tid + k * 256; if (i < BI) dst[i] = br[k]; }
+        for (int sc = 0; sc < NCH; ++sc)
+#pragma unroll
+            for (int k = 0; k < BN; ++k) { const int i = tid + k * 256; if (i < BI) dst[sc * BI + i] = br[sc * BN + k]; }
     };
     const bool b_once = upt == 1;                    // one unit per tile: the weights never change
 
-    f32x4 xr[XN][XW];
+    f32x4 xr[NCH * XN][XW];
     f32x4 acc[MT][NT];
     float s1[NT], s2[NT];
 #pragma unroll
@@ -326,24 +334,30 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     if (n_units > 0) {
         decode(0, t, part, ch, np);
         tile_origin<GK>(p, t, n0, y0, x0);
-        bool pooled = false;
-        if constexpr (XW == 4) {
-            if (part) {
-                pooled = true;
-                load_x<GK, 1, XW>(xr, p, n0, y0, x0, ch * 16, np, tid);
-                store_x<GK, P, 1, XW>(tile[0], xr, p, cA, n0, y0, x0, ch * 16, np, tid);
+#pragma unroll
+        for (int sc = 0; sc < NCH; ++sc) {
+            bool pooled = false;
+            f32x4 (*xs)[XW] = xr + sc * XN;
+            f32x4 *td = tile[0] + sc * 4 * P;
+            const int c0 = (ch + sc) * 16;
+            if constexpr (XW == 4) {
+                if (part) {
+                    pooled = true;
+                    load_x<GK, 1, XW>(xs, p, n0, y0, x0, c0, np, tid);
+                    store_x<GK, P, 1, XW>(td, xs, p, cA, n0, y0, x0, c0, np, tid);
+                }
             }
-        }
-        if constexpr (EPI != EPI_FWD) {
-            if (p.ga_on) {
-                pooled = true;
-                load_x<GK, 2, XW>(xr, p, n0, y0, x0, ch * 16, np, tid);
-                store_x<GK, P, 2, XW>(tile[0], xr, p, cA, n0, y0, x0, ch * 16, np, tid);
+            if constexpr (EPI != EPI_FWD) {
+                if (p.ga_on) {
+                    pooled = true;
+                    load_x<GK, 2, XW>(xs, p, n0, y0, x0, c0, np, tid);
+                    store_x<GK, P, 2, XW>(td, xs, p, cA, n0, y0, x0, c0, np, tid);
+                }
             }
-        }
-        if (!pooled) {
-            load_x<GK, 0, XW>(xr, p, n0, y0, x0, ch * 16, np, tid);
-            store_x<GK, P, 0, XW>(tile[0], xr, p, cA, n0, y0, x0, ch * 16, np, tid);
+            if (!pooled) {
+                load_x<GK, 0, XW>(xs, p, n0, y0, x0, c0, np, tid);
+                store_x<GK, P, 0, XW>(td, xs, p, cA, n0, y0, x0, c0, np, tid);
+            }
         }
         load_b(part, ch);
         store_b(wtile[0]);
@@ -356,14 +370,19 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         if (more && !(p.dbg & 2)) {
             decode(u + 1, t2, part2, ch2, np2);
             tile_origin<GK>(p, t2, m0, v0, u0);
-            bool pooled = false;
-            if constexpr (XW == 4) {
-                if (part2) { pooled = true; load_x<GK, 1, XW>(xr, p, m0, v0, u0, ch2 * 16, np2, tid); }
+#pragma unroll
+            for (int sc = 0; sc < NCH; ++sc) {
+                bool pooled = false;
+                f32x4 (*xs)[XW] = xr + sc * XN;
+                const int c0 = (ch2 + sc) * 16;
+                if constexpr (XW == 4) {
+                    if (part2) { pooled = true; load_x<GK, 1, XW>(xs, p, m0, v0, u0, c0, np2, tid); }
+                }
+                if constexpr (EPI != EPI_FWD) {
+                    if (p.ga_on) { pooled = true; load_x<GK, 2, XW>(xs, p, m0, v0, u0, c0, np2, tid); }
+                }
+                if (!pooled) load_x<GK, 0, XW>(xs, p, m0, v0, u0, c0, np2, tid);
             }
-            if constexpr (EPI != EPI_FWD) {
-                if (p.ga_on) { pooled = true; load_x<GK, 2, XW>(xr, p, m0, v0, u0, ch2 * 16, np2, tid); }
-            }
-            if (!pooled) load_x<GK, 0, XW>(xr, p, m0, v0, u0, ch2 * 16, np2, tid);
             if (!b_once) load_b(part2, ch2);
         }
         // ----------------------------- MFMAs of unit u -----------------------------
@@ -389,13 +408,15 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                 }
             } else {
 #pragma unroll
+              for (int sc = 0; sc < NCH; ++sc)
+#pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int dy = tap / 3, dx = tap - dy * 3;
                     f32x4 a[MT], bq[NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bq[nt] = wl[(tap * 4 + g) * CT + wcol + nt * 16];
+                    for (int nt = 0; nt < NT; ++nt) bq[nt] = wl[sc * BI + (tap * 4 + g) * CT + wcol + nt * 16];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a[mt] = cur[g * P + slot0[mt] + dy * R + dx];
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = cur[sc * 4 * P + g * P + slot0[mt] + dy * R + dx];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -471,15 +492,20 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         }
         // ----------------------------- stage unit u+1, advance ----------------------
         if (more && !(p.dbg & 2)) {
-            f32x4 *nxt = tile[(u + 1) & 1];
-            bool pooled = false;
-            if constexpr (XW == 4) {
-                if (part2) { pooled = true; store_x<GK, P, 1, XW>(nxt, xr, p, cA, m0, v0, u0, ch2 * 16, np2, tid); }
+#pragma unroll
+            for (int sc = 0; sc < NCH; ++sc) {
+                f32x4 *nxt = tile[(u + 1) & 1] + sc * 4 * P;
+                f32x4 (*xs)[XW] = xr + sc * XN;
+                const int c0 = (ch2 + sc) * 16;
+                bool pooled = false;
+                if constexpr (XW == 4) {
+                    if (part2) { pooled = true; store_x<GK, P, 1, XW>(nxt, xs, p, cA, m0, v0, u0, c0, np2, tid); }
+                }
+                if constexpr (EPI != EPI_FWD) {
+                    if (p.ga_on) { pooled = true; store_x<GK, P, 2, XW>(nxt, xs, p, cA, m0, v0, u0, c0, np2, tid); }
+                }
+                if (!pooled) store_x<GK, P, 0, XW>(nxt, xs, p, cA, m0, v0, u0, c0, np2, tid);
             }
-            if constexpr (EPI != EPI_FWD) {
-                if (p.ga_on) { pooled = true; store_x<GK, P, 2, XW>(nxt, xr, p, cA, m0, v0, u0, ch2 * 16, np2, tid); }
-            }
-            if (!pooled) store_x<GK, P, 0, XW>(nxt, xr, p, cA, m0, v0, u0, ch2 * 16, np2, tid);
             if (!b_once) store_b(wtile[(u + 1) & 1]);
             t = t2; part = part2; ch = ch2; np = np2; n0 = m0; y0 = v0; x0 = u0;
         }

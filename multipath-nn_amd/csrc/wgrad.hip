@@ -225,17 +225,17 @@ struct BwdScaleP {
     int gyh, gyv, gxh, gxv, gxw, nchw;           // nchw = channel chunks (A + V) of the wgrad
 };
 
-template <int GK, int OT>
-__global__ __launch_bounds__(256, (OT == 1 ? MPNN_OCC : 2)) void bwd_scale_k(const BwdScaleP q) {
-    constexpr int CB = ConvSmem<GK, 4, 16>::BYTES;
+template <int GK, int OT, int NCH>
+__global__ __launch_bounds__(256, (OT == 1 && NCH == 1 ? MPNN_OCC : 2)) void bwd_scale_k(const BwdScaleP q) {
+    constexpr int CB = ConvSmem<GK, 4, 16, NCH>::BYTES;
     constexpr int GS = OT * 16 + 4;
     constexpr int WB = 4 * WGeom<GK>::PS * 16 + 64 * GS * 4 + (128 * 3 + OT * 16 * 5) * 4;
     __shared__ __attribute__((aligned(16))) char smem[CB > WB ? CB : WB];
     const int by = blockIdx.y, bx = blockIdx.x;
     if (by < q.gyh) {
-        if (bx < q.gxh) conv_body<GK, 1, 1, 4, 1, false, EPI_DGH_BN>(q.h, bx, by, q.gxh, smem);
+        if (bx < q.gxh) conv_body<GK, 1, 1, 4, 1, false, EPI_DGH_BN, NCH>(q.h, bx, by, q.gxh, smem);
     } else if (by < q.gyh + q.gyv) {
-        if (bx < q.gxv) conv_body<GK, 1, 1, 4, 1, false, EPI_DGV>(q.v, bx, by - q.gyh, q.gxv, smem);
+        if (bx < q.gxv) conv_body<GK, 1, 1, 4, 1, false, EPI_DGV, NCH>(q.v, bx, by - q.gyh, q.gxv, smem);
     } else if (bx < q.gxw) {
         const int r = by - q.gyh - q.gyv;
         const int chunk = r % q.nchw, bz = r / q.nchw;
@@ -325,8 +325,17 @@ static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hip
     if (q.gxh > gx) gx = q.gxh;
     if (q.gxv > gx) gx = q.gxv;
     const dim3 grid(gx, q.gyh + q.gyv + gyw);
-    if (wide) hipLaunchKernelGGL((bwd_scale_k<GK, 4>), grid, dim3(256), 0, st, q);
-    else      hipLaunchKernelGGL((bwd_scale_k<GK, 1>), grid, dim3(256), 0, st, q);
+    // 32-channel units for the dgrad bodies when g has a multiple of 32 channels on a small map
+    static const int nch_env = [] { const char *e = getenv("MPNN_CONV_NCH"); return e ? atoi(e) : 0; }();
+    bool deep = GK != 0 && (q.w.c.Cout % 32) == 0 && (has_h || has_v);
+    if (nch_env == 1) deep = false;
+    if (deep) {
+        if (wide) hipLaunchKernelGGL((bwd_scale_k<GK, 4, 2>), grid, dim3(256), 0, st, q);
+        else      hipLaunchKernelGGL((bwd_scale_k<GK, 1, 2>), grid, dim3(256), 0, st, q);
+    } else {
+        if (wide) hipLaunchKernelGGL((bwd_scale_k<GK, 4, 1>), grid, dim3(256), 0, st, q);
+        else      hipLaunchKernelGGL((bwd_scale_k<GK, 1, 1>), grid, dim3(256), 0, st, q);
+    }
     MPNN_LAUNCH_CHECK();
     return 0;
 }
