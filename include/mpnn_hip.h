@@ -69,16 +69,20 @@ int mpnn_pack_weights(const float *params, float *packs, const int *desc,
 
 /* ---- multiscale conv block, forward --------------------------------------
  * One scale of MultiscaleConvMax.link (layer_types.py:181-185):
- *   out = bias + conv3x3_same(act(a)) [+ conv3x3_same(maxpool2x2(v))]
+ *   out = bias + conv3x3_same(act(a)) [+ conv3x3_same(v)]
  * and, fused, the per-channel sum / sum-of-squares that BatchNorm's
- * tf.nn.moments needs (layer_types.py:232).  `v` is the PRE-BN output of the
- * next finer scale, [n, 2H, 2W, Cv] (NULL for the first scale). */
+ * tf.nn.moments needs (layer_types.py:232) and, if `pool_out` is given, the
+ * 2x2/2 max-pool of `out` (the `pool(self.x[i-1])` of layer_types.py:185 that
+ * the next coarser scale consumes: pooled ONCE, by the producer).  `v` is that
+ * pooled PRE-BN map of the next finer scale, [n, H, W, Cv] (NULL for the first
+ * scale). */
 typedef struct {
     mpnn_act a;
     const float *v;  int Cv;
     const float *wa_pack;  const float *wv_pack;   /* forward packs           */
     const float *bias;                              /* [Cout]                  */
     float  *out;                                    /* [n, H, W, Cout]         */
+    float  *pool_out;                               /* [n, H/2, W/2, Cout] or NULL */
     double *out_sum;                                /* [SLOTS][2*Cout], accumulated */
     int out_nslot;                                  /* slots of out_sum to spread over */
     int n, H, W, Cout;
@@ -144,7 +148,8 @@ int mpnn_msconv_dgrad_pair(const mpnn_dgrad_horz_args *horz, const mpnn_dgrad_ve
                            void *stream);
 
 /* ---- multiscale conv block, weight gradients -------------------------------
- * dW_horz = act(a)^T (*) g, dW_vert = maxpool2x2(v)^T (*) g, db = sum g.
+ * dW_horz = act(a)^T (*) g, dW_vert = v^T (*) g (v = the pooled finer map, as in
+ * mpnn_conv_fwd_args), db = sum g.
  * The pixel range is divided over `n_split` workgroup rows; split s WRITES its
  * partial sums (plain stores, every element exactly once) to dwa/dwv/db +
  * s*split_stride.  With n_split == 1 those may be the gradient tensors

@@ -9,8 +9,9 @@ extern "C" int mpnn_msconv_fwd(const mpnn_conv_fwd_args *a, void *stream) {
     p.v = a->v;  p.Cv = a->v ? a->Cv : 0;
     p.wa = a->wa_pack;  p.wv = a->wv_pack;
     p.n = a->n;  p.H = a->H;  p.W = a->W;  p.Cout = a->Cout;
-    p.bias = a->bias;  p.out = a->out;  p.out_sum = a->out_sum;
+    p.bias = a->bias;  p.out = a->out;  p.out_sum = a->out_sum;  p.pool_out = a->pool_out;
     p.out_nslot = a->out_nslot < 1 ? 1 : (a->out_nslot > MPNN_BN_SLOTS ? MPNN_BN_SLOTS : a->out_nslot);
+    if (a->pool_out && (a->H < 8 || (a->H & 1) || (a->W & 1))) return MPNN_E_SHAPE;
     return conv_launch<EPI_FWD>(p, (hipStream_t)stream);
 }
 
@@ -48,8 +49,9 @@ static int fill_fwd(const mpnn_conv_fwd_args *a, ConvP &p) {
     p.v = a->v;  p.Cv = a->v ? a->Cv : 0;
     p.wa = a->wa_pack;  p.wv = a->wv_pack;
     p.n = a->n;  p.H = a->H;  p.W = a->W;  p.Cout = a->Cout;
-    p.bias = a->bias;  p.out = a->out;  p.out_sum = a->out_sum;
+    p.bias = a->bias;  p.out = a->out;  p.out_sum = a->out_sum;  p.pool_out = a->pool_out;
     p.out_nslot = a->out_nslot < 1 ? 1 : (a->out_nslot > MPNN_BN_SLOTS ? MPNN_BN_SLOTS : a->out_nslot);
+    if (a->pool_out && (a->H < 8 || (a->H & 1) || (a->W & 1))) return MPNN_E_SHAPE;
     return 0;
 }
 

@@ -33,10 +33,11 @@ enum { EPI_FWD = 0, EPI_DGH_BN = 1, EPI_DGH_RAW = 2, EPI_DGV = 3 };
 
 struct ConvP {
     mpnn_act a;                 // operand A (identity transform for dgrad)
-    const float *v;  int Cv;    // operand V: finer pre-BN map, pooled on load
+    const float *v;  int Cv;    // operand V: the finer scale's pre-BN map, ALREADY 2x2-max-pooled by its producer
     const float *wa, *wv;       // weight packs
     int n, H, W, Cout;
     const float *bias;  float *out;  double *out_sum;      // EPI_FWD
+    float *pool_out;                                        // EPI_FWD: 2x2 max-pool of `out` (NULL: none)
     const float *extra;                                     // EPI_DGH_*
     const float *sprev;  mpnn_act pbn;  double *red_out;    // EPI_DGH_BN / EPI_DGV
     const double *red;  int has_dz;  int red_nslot;         // EPI_DGV
@@ -91,8 +92,9 @@ static inline int conv_grid_x(int n, int H, int W) {
 // thread block maps to (plane q, halo pixel hp) with 8 consecutive pixels of
 // one plane in 8 consecutive lanes (conflict-free ds_write_b128 groups, 512-B
 // contiguous global segments).
-// MODE 0: operand A (optional BN+ReLU, optional pyramid subsampling), one
-// float4 per item; MODE 1: 2x2 max-pool of the finer map, four float4 per item.
+// MODE 0: operand A (optional BN+ReLU, optional pyramid subsampling); MODE 1:
+// operand V (the finer scale's map, max-pooled once by its producer's epilogue);
+// MODE 2: BatchNorm backward of dz (two float4 per item: dz and s).
 // ---------------------------------------------------------------------------
 template <int GK> struct XItems {
     using G = Geom<GK>;
@@ -120,14 +122,13 @@ __device__ __forceinline__ bool x_item(int i, int n0, int y0, int x0, int np, co
 template <int GK, int MODE, int XW>
 __device__ __forceinline__ void load_x(f32x4 (*xr)[XW], const ConvP &p, int n0, int y0, int x0, int c0, int np, int tid) {
     using X = XItems<GK>;
-    static_assert(MODE != 1 || XW == 4, "pooling needs four raw registers per item");
     static_assert(MODE != 2 || XW >= 2, "BatchNorm-backward-on-load needs two raw registers per item");
 #pragma unroll
     for (int k = 0; k < X::N; ++k) {
         int q, slot, n, y, x; bool inb;
         const bool ok = x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb);
 #pragma unroll
-        for (int w = 0; w < (MODE == 1 ? 4 : (MODE == 2 ? 2 : 1)); ++w) xr[k][w] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < (MODE == 2 ? 2 : 1); ++w) xr[k][w] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ok && inb) {
             const int c = c0 + q * 4;
             if (MODE == 2) {
@@ -143,13 +144,8 @@ __device__ __forceinline__ void load_x(f32x4 (*xr)[XW], const ConvP &p, int n0, 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xr[k][0][j] = (c + j < C) ? p.a.x[base + c + j] : 0.f;
                 }
-            } else {
-                const int W2 = p.W * 2;
-                const float *s = p.v + (((size_t)n * (p.H * 2) + 2 * y) * W2 + 2 * x) * p.Cv + c;
-                xr[k][0] = *(const f32x4 *)s;
-                xr[k][1 % XW] = *(const f32x4 *)(s + p.Cv);
-                xr[k][2 % XW] = *(const f32x4 *)(s + (size_t)W2 * p.Cv);
-                xr[k][3 % XW] = *(const f32x4 *)(s + (size_t)W2 * p.Cv + p.Cv);
+            } else {                               // pooled map of the finer scale: a plain operand
+                xr[k][0] = *(const f32x4 *)(p.v + (((size_t)n * p.H + y) * p.W + x) * p.Cv + c);
             }
         }
     }
@@ -184,9 +180,7 @@ __device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], cons
                     }
                 }
             } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    v[j] = fmaxf(fmaxf(xr[k][0][j], xr[k][1 % XW][j]), fmaxf(xr[k][2 % XW][j], xr[k][3 % XW][j]));
+                v = xr[k][0];
             }
         }
         tile[q * PS + slot] = v;
@@ -204,8 +198,8 @@ __device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], cons
 template <int GK, int WM, int CT, int NCH = 1>
 struct ConvSmem {
     static constexpr int TILE = NCH * 2 * 4 * Geom<GK>::P * 16, WT = NCH * 2 * 36 * CT * 16, CA = 128 * 5 * 4, CE = CT * 5 * 4,
-                         RED = WM * CT * 2 * 8;
-    static constexpr int BYTES = TILE + WT + CA + ((CE + 15) & ~15) + RED;
+                         RED = WM * CT * 2 * 8, POOL = 64 * CT * 4;
+    static constexpr int BYTES = TILE + WT + CA + ((CE + 15) & ~15) + RED + POOL;
 };
 
 // NCH = 16-channel chunks per unit (1 or 2).  With 2 a unit spans 32 input channels: half as many
@@ -216,7 +210,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     using G = Geom<GK>;
     constexpr int P = G::P, R = G::R, HR = G::TH + 2;
     constexpr int CT = WN * NT * 16;
-    constexpr int XW = EPI == EPI_FWD ? 4 : 2;      // forward: pooled operand (4); dgrad: dz + s when BN-backward is applied on load (2)
+    constexpr int XW = EPI == EPI_FWD ? 1 : 2;      // dgrad: dz + s when BatchNorm-backward is applied on load
     constexpr int XN = XItems<GK>::N;
     static_assert(WM * WN == 4 && WM * MT == 4, "4 waves, 4 M-tiles per workgroup");
 
@@ -228,6 +222,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     float *cA = (float *)(smem + SM::TILE + SM::WT);
     float *cE = cA + 128 * 5;
     double *redbuf = (double *)(smem + SM::TILE + SM::WT + SM::CA + ((SM::CE + 15) & ~15));
+    float *pool_lds = (float *)(smem + SM::TILE + SM::WT + SM::CA + ((SM::CE + 15) & ~15) + SM::RED);   // [64 px][CT]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -340,7 +335,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             f32x4 (*xs)[XW] = xr + sc * XN;
             f32x4 *td = tile[0] + sc * 4 * P;
             const int c0 = (ch + sc) * 16;
-            if constexpr (XW == 4) {
+            if constexpr (EPI == EPI_FWD) {
                 if (part) {
                     pooled = true;
                     load_x<GK, 1, XW>(xs, p, n0, y0, x0, c0, np, tid);
@@ -375,7 +370,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                 bool pooled = false;
                 f32x4 (*xs)[XW] = xr + sc * XN;
                 const int c0 = (ch2 + sc) * 16;
-                if constexpr (XW == 4) {
+                if constexpr (EPI == EPI_FWD) {
                     if (part2) { pooled = true; load_x<GK, 1, XW>(xs, p, m0, v0, u0, c0, np2, tid); }
                 }
                 if constexpr (EPI != EPI_FWD) {
@@ -448,6 +443,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                             val += bias_r[nt];
                             p.out[idx] = val;
                             s1[nt] += val; s2[nt] += val * val;
+                            if (GK != 2 && p.pool_out) pool_lds[((wm * MT + mt) * 16 + g * 4 + r) * CT + cl] = val;
                         } else if (EPI == EPI_DGH_RAW) {
                             const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
                             if (p.extra) val += p.extra[idx];
@@ -485,6 +481,21 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                     }
                 }
             }
+            // 2x2 max-pool of the finished tile for the next coarser scale's vert conv
+            // (layer_types.py:185): the tile's 64 pixels meet in LDS, each thread pools one value.
+            if (EPI == EPI_FWD && GK != 2 && p.pool_out) {        // uniform across the workgroup
+                __syncthreads();
+                if (n0 < p.n) {
+                    constexpr int TWp = GK == 0 ? 8 : 4, ROW = GK == 0 ? 16 : 8;   // pooled tile width, tile row length
+                    const int H2 = p.H >> 1, W2 = p.W >> 1;
+                    for (int e = tid; e < 16 * CT; e += 256) {
+                        const int c = e % CT, pp = e / CT, py = pp / TWp, px = pp - py * TWp;
+                        const float *q0 = pool_lds + ((2 * py) * ROW + 2 * px) * CT + c;
+                        const float m4 = fmaxf(fmaxf(q0[0], q0[CT]), fmaxf(q0[ROW * CT], q0[ROW * CT + CT]));
+                        p.pool_out[(((size_t)n0 * H2 + (y0 >> 1) + py) * W2 + (x0 >> 1) + px) * p.Cout + co0 + c] = m4;
+                    }
+                }
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -498,7 +509,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                 f32x4 (*xs)[XW] = xr + sc * XN;
                 const int c0 = (ch2 + sc) * 16;
                 bool pooled = false;
-                if constexpr (XW == 4) {
+                if constexpr (EPI == EPI_FWD) {
                     if (part2) { pooled = true; store_x<GK, P, 1, XW>(nxt, xs, p, cA, m0, v0, u0, c0, np2, tid); }
                 }
                 if constexpr (EPI != EPI_FWD) {

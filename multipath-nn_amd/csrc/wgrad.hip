@@ -3,7 +3,7 @@
 // per-workgroup partial gradients.
 //
 //   dW_horz[t][c][co] = sum_pix act(a)[pix + t][c]      * g[pix][co]
-//   dW_vert[t][c][co] = sum_pix maxpool2(v)[pix + t][c] * g[pix][co]
+//   dW_vert[t][c][co] = sum_pix v[pix + t][c] * g[pix][co]      (v = the pooled finer map)
 //   db[co]            = sum_pix g[pix][co]
 //
 // GEMM view per tap: M = 16 input channels (one chunk), N = output channels,
@@ -116,18 +116,18 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         tap_off[ti] = (tap / 3) * R + (tap % 3);
     }
 
-    f32x4 xr[XN][PART ? 4 : 1], gr[OT], gs[OT];
+    f32x4 xr[XN][1], gr[OT], gs[OT];
     int t = bx;
     int n0, y0, x0, cn0 = 0, cy0 = 0, cx0 = 0;
     if (t < p.n_tiles) {
         tile_origin<GK>(c, t, n0, y0, x0);
-        load_x<GK, PART, (PART ? 4 : 1)>(xr, c, n0, y0, x0, ch * 16, np, tid);
+        load_x<GK, PART, 1>(xr, c, n0, y0, x0, ch * 16, np, tid);
         load_g<GK, OT>(gr, gs, p, n0, y0, x0, co0, tid);
         cn0 = n0; cy0 = y0; cx0 = x0;
     }
     for (; t < p.n_tiles; t += gx) {
         __syncthreads();                               // previous tile's LDS reads are done
-        store_x<GK, PS, PART, (PART ? 4 : 1)>(tile, xr, c, cA, cn0, cy0, cx0, ch * 16, np, tid);
+        store_x<GK, PS, PART, 1>(tile, xr, c, cA, cn0, cy0, cx0, ch * 16, np, tid);
 #pragma unroll
         for (int k = 0; k < OT; ++k) {
             const int i = tid + k * 256;
@@ -151,7 +151,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         const int tn = t + gx;
         if (tn < p.n_tiles) {                          // next tile's loads fly under the MFMAs
             tile_origin<GK>(c, tn, n0, y0, x0);
-            load_x<GK, PART, (PART ? 4 : 1)>(xr, c, n0, y0, x0, ch * 16, np, tid);
+            load_x<GK, PART, 1>(xr, c, n0, y0, x0, ch * 16, np, tid);
             load_g<GK, OT>(gr, gs, p, n0, y0, x0, co0, tid);
             cn0 = n0; cy0 = y0; cx0 = x0;
         }

@@ -26,7 +26,7 @@ class Act(C.Structure):
 
 class ConvFwdArgs(C.Structure):
     _fields_ = [('a', Act), ('v', P), ('Cv', C.c_int), ('wa_pack', P), ('wv_pack', P), ('bias', P),
-                ('out', P), ('out_sum', P), ('out_nslot', C.c_int), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int),
+                ('out', P), ('pool_out', P), ('out_sum', P), ('out_nslot', C.c_int), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int),
                 ('Cout', C.c_int)]
 
 

@@ -337,6 +337,7 @@ class Engine:
         for b in self.blocks:
             b.s = [z(n, b.H[i], b.W[i], b.C[i]) for i in range(b.L)]
             b.dzg = [z(n, b.H[i], b.W[i], b.C[i]) for i in range(b.L)]
+            b.sp = [z(n, b.H[i] // 2, b.W[i] // 2, b.C[i]) for i in range(b.L - 1)]     # 2x2-max-pooled s
             if b.has_exit:
                 K = b.H[-1] * b.W[-1] * b.C[-1]
                 b.dx = z(n, K)
@@ -437,8 +438,10 @@ class Engine:
             cp = b.conv.params
             a.a = self._act_of_input(b, i, n, act_mode)
             if i > 0:
-                a.v, a.Cv = b.s[i - 1].data_ptr(), b.C[i - 1]
+                a.v, a.Cv = b.sp[i - 1].data_ptr(), b.C[i - 1]
                 a.wv_pack = self.packs[b.pack['w_vert_%i' % (i - 1)][0]:].data_ptr()
+            if i < b.L - 1:
+                a.pool_out = b.sp[i].data_ptr()
             a.wa_pack = self.packs[b.pack['w_horz_%i' % i][0]:].data_ptr()
             a.bias = getattr(cp, 'b_%i' % i).data.data_ptr()
             a.out = b.s[i].data_ptr()
@@ -637,7 +640,7 @@ class Engine:
                 pv = getattr(cp, 'w_vert_%i' % (i - 1)) if i > 0 else None
                 pb = getattr(cp, 'b_%i' % i)
                 if i > 0:
-                    a.v, a.Cv = b.s[i - 1].data_ptr(), b.C[i - 1]
+                    a.v, a.Cv = b.sp[i - 1].data_ptr(), b.C[i - 1]
                 a.g = b.dzg[i].data_ptr()
                 if i == L1 and g_ctx is not None:
                     a.g_ctx = g_ctx

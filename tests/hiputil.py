@@ -67,8 +67,16 @@ def bn_dict(x, gamma, beta, m_avg=None, v_avg=None, eps=1e-6):
     return d, x64.shape[0]
 
 
-def conv_fwd(x, wh, b, v=None, wv=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0, bn_cnt=1):
-    """x: [n, H<<shift, W<<shift, Ca]; returns (out, out_sum)."""
+def pool2_np(v):
+    n, h, w, c = v.shape
+    return np.ascontiguousarray(v.reshape(n, h // 2, 2, w // 2, 2, c).max(axis=(2, 4)))
+
+
+def conv_fwd(x, wh, b, v=None, wv=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0, bn_cnt=1, want_pool=False):
+    """x: [n, H<<shift, W<<shift, Ca]; v: the UNPOOLED finer map [n, 2H, 2W, Cv] (pooled here, as its
+    producer would).  Returns (out, out_sum[, pooled out])."""
+    if v is not None:
+        v = pool2_np(np.asarray(v, np.float32))
     lib = _hip.load()
     n = x.shape[0]
     H, W = x.shape[1] >> shift, x.shape[2] >> shift
@@ -82,9 +90,13 @@ def conv_fwd(x, wh, b, v=None, wv=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0
     a.v = _hip.ptr(vd); a.Cv = v.shape[3] if v is not None else 0
     a.wa_pack = fw[0].data_ptr(); a.wv_pack = fw[1].data_ptr() if wv is not None else None
     a.bias = bd.data_ptr(); a.out = out.data_ptr(); a.out_sum = osum.data_ptr(); a.out_nslot = _hip.BN_SLOTS
+    pool = torch.full((n, H // 2, W // 2, co), 9.0, device=DEV) if want_pool else None
+    a.pool_out = _hip.ptr(pool)
     a.n, a.H, a.W, a.Cout = n, H, W, co
     _hip.check(lib.mpnn_msconv_fwd(C.byref(a), stream()), 'msconv_fwd')
     torch.cuda.synchronize()
+    if want_pool:
+        return out.cpu().numpy(), unslot(osum, 2 * co), pool.cpu().numpy()
     return out.cpu().numpy(), unslot(osum, 2 * co)
 
 
@@ -143,6 +155,8 @@ def dgrad_vert(g, w, s_fine, bn, cnt, dz_fine=None, red=None):
 def wgrad(x, g, v=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0, bn_cnt=1, n_split=7):
     """Partial sums into a slab + mpnn_slab_reduce (n_split > 1) or straight into the gradients."""
     lib = _hip.load()
+    if v is not None:
+        v = pool2_np(np.asarray(v, np.float32))          # the producer's pooled map
     n = x.shape[0]
     H, W = x.shape[1] >> shift, x.shape[2] >> shift
     ca, co = x.shape[3], g.shape[3]

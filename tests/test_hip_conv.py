@@ -62,8 +62,12 @@ def test_conv_fwd_raw_and_bn(shape):
     rng = np.random.default_rng(hash(shape) % 2 ** 31)
     n = 5 if H == 4 else 2
     x, v, wh, wv, b = make(shape, rng, n)
-    # identity input (pyramid)
-    out, osum = U.conv_fwd(x, wh, b, v, wv, shift=shift)
+    # identity input (pyramid); the epilogue also max-pools the output for the next coarser scale
+    if H >= 8:
+        out, osum, pooled = U.conv_fwd(x, wh, b, v, wv, shift=shift, want_pool=True)
+        assert np.array_equal(pooled, U.pool2_np(out))
+    else:
+        out, osum = U.conv_fwd(x, wh, b, v, wv, shift=shift)
     ref, _ = ref_fwd(x, v, wh, wv, b, shift)
     close(out, ref, 2e-5)
     close(osum[:co], ref.sum((0, 1, 2)), 1e-5)
