@@ -89,8 +89,10 @@ typedef struct {
 } mpnn_conv_fwd_args;
 int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
 /* Up to four mutually independent forward convs (one wavefront level of the block x scale grid)
- * as ONE launch; `args` is a HOST array of `count` records. */
-int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, int count, void *stream);
+ * as ONE launch; `args` is a HOST array of `count` records (sizes the grid) and `dev_args` a
+ * DEVICE copy of it (read by the kernel; uploaded once per plan). */
+int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
+                          void *stream);
 
 /* ---- BatchNorm(+ReLU) backward pieces ------------------------------------
  * Backward of `y = relu(gamma * (s - m) / sqrt(v + eps) + beta)` THROUGH the

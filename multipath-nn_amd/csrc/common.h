@@ -47,6 +47,36 @@ __device__ __forceinline__ BnC bn_coef(const mpnn_act &b, int c) {
     return k;
 }
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations
+// (lgkmcnt(0)), NOT for its global loads.  __syncthreads() also drains vmcnt, which would wait for
+// the prefetch loads that are deliberately left in flight across pipeline steps.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef MPNN_SAFE_BARRIER
+    __syncthreads();
+    return;
+#endif
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0) only
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Drain the MFMA pipe before the accumulators are read by VALU code.  hipcc covers the
+// MFMA-write -> VALU-read hazard by counting the instructions in between as wait states; when
+// those are mostly SALU instructions (branch conditions of the persistent loop) the last
+// accumulator register written by the last MFMA was observed to be read STALE on gfx950
+// (fwd_group_k: rows 4g+3 of a tile missed the final MFMA, run-to-run nondeterministic).
+// One s_nop 15 (16 wait states) after every unit's MFMA block, against >1000 cycles of MFMAs per unit.
+__device__ __forceinline__ void mfma_drain() {
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef MPNN_DRAIN_NOPS
+#define MPNN_DRAIN_NOPS 1
+#endif
+#pragma unroll
+    for (int k = 0; k < MPNN_DRAIN_NOPS; ++k) asm volatile("s_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // fp64 butterfly over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48).
 __device__ __forceinline__ double reduce_g4(double v) {
     v += __shfl_xor(v, 16);

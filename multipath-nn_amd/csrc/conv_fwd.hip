@@ -1,17 +1,12 @@
 // mpnn_msconv_fwd: one scale of MultiscaleConvMax forward (see conv_kernel.h).
 #include "conv_kernel.h"
 
+__host__ __device__ static inline int fill_fwd(const mpnn_conv_fwd_args *a, ConvP &p);
+
 extern "C" int mpnn_msconv_fwd(const mpnn_conv_fwd_args *a, void *stream) {
-    if (!a || !a->a.x || !a->wa_pack || !a->out || !a->bias) return MPNN_E_ARG;
-    if (a->v && !a->wv_pack) return MPNN_E_ARG;
     ConvP p = {};
-    p.a = a->a;
-    p.v = a->v;  p.Cv = a->v ? a->Cv : 0;
-    p.wa = a->wa_pack;  p.wv = a->wv_pack;
-    p.n = a->n;  p.H = a->H;  p.W = a->W;  p.Cout = a->Cout;
-    p.bias = a->bias;  p.out = a->out;  p.out_sum = a->out_sum;  p.pool_out = a->pool_out;
-    p.out_nslot = a->out_nslot < 1 ? 1 : (a->out_nslot > MPNN_BN_SLOTS ? MPNN_BN_SLOTS : a->out_nslot);
-    if (a->pool_out && (a->H < 8 || (a->H & 1) || (a->W & 1))) return MPNN_E_SHAPE;
+    const int rc = fill_fwd(a, p);
+    if (rc) return rc;
     return conv_launch<EPI_FWD>(p, (hipStream_t)stream);
 }
 
@@ -21,28 +16,9 @@ extern "C" int mpnn_msconv_fwd(const mpnn_conv_fwd_args *a, void *stream) {
 // Rows of the grid are dealt to the members; each member runs the body of its own geometry.
 // The members' serial latency chains overlap instead of queueing as separate launches.
 // ---------------------------------------------------------------------------
-struct FwdGroupP { ConvP p[4]; int gk[4], small[4], gy[4], gx[4], y0[4]; int n; };
+struct FwdGroupP { int gk[4], small[4], gy[4], gx[4], y0[4]; int n; };
 
-__global__ __launch_bounds__(256, MPNN_OCC) void fwd_group_k(const FwdGroupP q) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // sized by the host for the members present
-    const int by = blockIdx.y, bx = blockIdx.x;
-    int m = 0;
-#pragma unroll
-    for (int k = 1; k < 4; ++k) if (k < q.n && by >= q.y0[k]) m = k;
-    if (bx >= q.gx[m]) return;
-    const ConvP &p = q.p[m];
-    const int yy = by - q.y0[m], gx = q.gx[m];
-    switch (q.gk[m] * 2 + q.small[m]) {
-        case 0: conv_body<0, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
-        case 1: conv_body<0, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
-        case 2: conv_body<1, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
-        case 3: conv_body<1, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
-        case 4: conv_body<2, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
-        default: conv_body<2, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
-    }
-}
-
-static int fill_fwd(const mpnn_conv_fwd_args *a, ConvP &p) {
+__host__ __device__ static inline int fill_fwd(const mpnn_conv_fwd_args *a, ConvP &p) {
     if (!a || !a->a.x || !a->wa_pack || !a->out || !a->bias) return MPNN_E_ARG;
     if (a->v && !a->wv_pack) return MPNN_E_ARG;
     p.a = a->a;
@@ -55,13 +31,38 @@ static int fill_fwd(const mpnn_conv_fwd_args *a, ConvP &p) {
     return 0;
 }
 
-extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, int count, void *stream) {
+// The member records live in DEVICE memory (uploaded once per plan): indexing a by-value kernel
+// argument array with a runtime member index makes hipcc copy the whole argument block to scratch.
+__global__ __launch_bounds__(256) void fwd_group_k(const mpnn_conv_fwd_args *__restrict__ tab, const FwdGroupP q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // sized by the host for the members present
+    const int by = blockIdx.y, bx = blockIdx.x;
+    int m = 0, y0 = 0, gx = q.gx[0], kind = q.gk[0] * 2 + q.small[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < q.n && by >= q.y0[k]) { m = k; y0 = q.y0[k]; gx = q.gx[k]; kind = q.gk[k] * 2 + q.small[k]; }
+    if (bx >= gx) return;
+    ConvP p = {};
+    fill_fwd(tab + m, p);
+    const int yy = by - y0;
+    switch (kind) {
+        case 0: p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
+        case 1: p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
+        case 2: p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
+        case 3: p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
+        case 4: p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
+        default: p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
+    }
+}
+
+extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
+                                     void *stream) {
     if (count <= 0) return 0;
-    if (!args || count > 4) return MPNN_E_ARG;
+    if (!args || !dev_args || count > 4) return MPNN_E_ARG;
     FwdGroupP q = {};
+    ConvP hp[4] = {};
     int rows = 0, gxm = 0;
     for (int k = 0; k < count; ++k) {
-        ConvP &p = q.p[k];
+        ConvP &p = hp[k];
         int rc = fill_fwd(&args[k], p);
         if (rc) return rc;
         if (p.n <= 0 || (p.Cout % 16) || p.a.C > 128 || p.Cv > 128 || (p.Cv & 3)) return MPNN_E_SHAPE;
@@ -76,14 +77,13 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, int count, 
         rows += q.gy[k];
     }
     // Share the ~1024 resident workgroup slots (256 CUs x 4) between the members in proportion to
-    // their tile-rows, so that every member is resident from the start (a member that fills all
-    // slots by itself makes the others queue behind it and the launch takes the SUM of its members).
+    // their tile-rows, so that every member is resident from the start.
     long total = 0;
-    for (int k = 0; k < count; ++k) total += (long)q.p[k].n_tiles * q.gy[k];
+    for (int k = 0; k < count; ++k) total += (long)hp[k].n_tiles * q.gy[k];
     for (int k = 0; k < count; ++k) {
-        long g = count == 1 ? conv_cap_gx(q.p[k].n_tiles, q.gy[k]) : (1024L * q.p[k].n_tiles) / (total > 0 ? total : 1);
+        long g = count == 1 ? conv_cap_gx(hp[k].n_tiles, q.gy[k]) : (1024L * hp[k].n_tiles) / (total > 0 ? total : 1);
         if (g < 16) g = 16;
-        if (g > q.p[k].n_tiles) g = q.p[k].n_tiles;
+        if (g > hp[k].n_tiles) g = hp[k].n_tiles;
         q.gx[k] = (int)g;
         if (q.gx[k] > gxm) gxm = q.gx[k];
     }
@@ -91,7 +91,7 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, int count, 
     const int bytes[3] = {ConvSmem<0, 4, 16>::BYTES, ConvSmem<1, 4, 16>::BYTES, ConvSmem<2, 4, 16>::BYTES};
     int lds = 0;
     for (int k = 0; k < count; ++k) if (bytes[q.gk[k]] > lds) lds = bytes[q.gk[k]];
-    hipLaunchKernelGGL(fwd_group_k, dim3(gxm, rows), dim3(256), lds, (hipStream_t)stream, q);
+    hipLaunchKernelGGL(fwd_group_k, dim3(gxm, rows), dim3(256), lds, (hipStream_t)stream, dev_args, q);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

@@ -79,7 +79,7 @@ __device__ __forceinline__ void tile_origin(const ConvP &p, int bid, int &n0, in
 }
 
 template <int GK>
-static inline int conv_grid_x(int n, int H, int W) {
+__host__ __device__ static inline int conv_grid_x(int n, int H, int W) {
     if (GK == 0) return n * (W >> 4) * (H >> 2);
     if (GK == 1) return n;
     return (n + 3) >> 2;
@@ -119,6 +119,10 @@ __device__ __forceinline__ bool x_item(int i, int n0, int y0, int x0, int np, co
     return true;
 }
 
+// BRANCH-FREE: every item issues its load unconditionally from a clamped (always valid) address;
+// out-of-range items are zeroed by store_x.  With a branch around each load hipcc waits
+// vmcnt(0) between items and a thread's loads serialise (one full latency each: measured
+// 1.5 us per unit, more than the unit's MFMAs).
 template <int GK, int MODE, int XW>
 __device__ __forceinline__ void load_x(f32x4 (*xr)[XW], const ConvP &p, int n0, int y0, int x0, int c0, int np, int tid) {
     using X = XItems<GK>;
@@ -127,26 +131,24 @@ __device__ __forceinline__ void load_x(f32x4 (*xr)[XW], const ConvP &p, int n0, 
     for (int k = 0; k < X::N; ++k) {
         int q, slot, n, y, x; bool inb;
         const bool ok = x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb);
+        const bool live = ok && inb;
+        const int c = c0 + q * 4;
+        if (MODE == 2) {
+            const size_t off = live ? (((size_t)n * p.H + y) * p.W + x) * p.a.C + c : 0;
+            xr[k][0] = *(const f32x4 *)(p.a.x + off);
+            xr[k][1 % XW] = *(const f32x4 *)(p.ga_s + off);
+        } else if (MODE == 0) {
+            const int sh = p.a.shift, C = p.a.C;
+            const size_t base = live ? (((size_t)n * (p.H << sh) + (y << sh)) * (p.W << sh) + (x << sh)) * C : 0;
+            if ((C & 3) == 0) {                    // uniform
+                xr[k][0] = *(const f32x4 *)(p.a.x + base + (live ? c : 0));
+            } else {                               // raw image with 1 or 3 channels: clamped scalar loads
 #pragma unroll
-        for (int w = 0; w < (MODE == 2 ? 2 : 1); ++w) xr[k][w] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok && inb) {
-            const int c = c0 + q * 4;
-            if (MODE == 2) {
-                const size_t off = (((size_t)n * p.H + y) * p.W + x) * p.a.C + c;
-                xr[k][0] = *(const f32x4 *)(p.a.x + off);
-                xr[k][1 % XW] = *(const f32x4 *)(p.ga_s + off);
-            } else if (MODE == 0) {
-                const int sh = p.a.shift, C = p.a.C;
-                const size_t base = (((size_t)n * (p.H << sh) + (y << sh)) * (p.W << sh) + (x << sh)) * C;
-                if ((C & 3) == 0) {
-                    xr[k][0] = *(const f32x4 *)(p.a.x + base + c);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xr[k][0][j] = (c + j < C) ? p.a.x[base + c + j] : 0.f;
-                }
-            } else {                               // pooled map of the finer scale: a plain operand
-                xr[k][0] = *(const f32x4 *)(p.v + (((size_t)n * p.H + y) * p.W + x) * p.Cv + c);
+                for (int j = 0; j < 4; ++j) xr[k][0][j] = p.a.x[base + (live && c + j < C ? c + j : 0)];
             }
+        } else {                                   // pooled map of the finer scale: a plain operand
+            const size_t off = live ? (((size_t)n * p.H + y) * p.W + x) * p.Cv + c : 0;
+            xr[k][0] = *(const f32x4 *)(p.v + off);
         }
     }
 }
@@ -171,13 +173,16 @@ __device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], cons
                 }
             } else if (MODE == 0) {
                 v = xr[k][0];
+                const int c = c0 + q * 4;
                 if (p.a.mode != MPNN_ACT_IDENTITY) {
-                    const int c = c0 + q * 4;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float *cc = cA + (c + j) * 3;
                         v[j] = (c + j < p.a.C) ? fmaxf((v[j] - cc[0]) * cc[1] + cc[2], 0.f) : 0.f;
                     }
+                } else if (p.a.C & 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (c + j < p.a.C) ? v[j] : 0.f;
                 }
             } else {
                 v = xr[k][0];
@@ -290,31 +295,71 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     };
 
     // Weight chunk (part, ch) of the k-interleaved pack -> registers -> LDS [tap][g][CT] float4.
-    f32x4 br[NCH * BN];
-    auto load_b = [&](int part_, int ch_) {
-        const float *wp = part_ ? p.wv : p.wa;
-        const int nch = part_ ? nchV : nchA;
-#pragma unroll
-        for (int sc = 0; sc < NCH; ++sc)
-#pragma unroll
-            for (int k = 0; k < BN; ++k) {
-                const int i = tid + k * 256;
-                br[sc * BN + k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (i < BI) {
-                    const int c4 = i % CT, tg = i / CT, gg = tg & 3, tap = tg >> 2;
-                    br[sc * BN + k] = *(const f32x4 *)(wp + ((size_t)((tap * nch + ch_ + sc) * 4 + gg) * p.Cout + co0 + c4) * 4);
-                }
-            }
-    };
-    auto store_b = [&](f32x4 *dst) {
-#pragma unroll
-        for (int sc = 0; sc < NCH; ++sc)
-#pragma unroll
-            for (int k = 0; k < BN; ++k) { const int i = tid + k * 256; if (i < BI) dst[sc * BI + i] = br[sc * BN + k]; }
+    // ---- staging helpers: one unit = NCH 16-channel chunks of operand A/V plus its weight chunk ----
+    struct UI { int t, part, ch, np, n0, y0, x0; };
+    auto mk = [&](int u) {
+        UI r;
+        decode(u, r.t, r.part, r.ch, r.np);
+        tile_origin<GK>(p, r.t, r.n0, r.y0, r.x0);
+        return r;
     };
     const bool b_once = upt == 1;                    // one unit per tile: the weights never change
+    auto unit_load = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq, bool with_b) {
+#pragma unroll
+        for (int sc = 0; sc < NCH; ++sc) {
+            bool done = false;
+            f32x4 (*xs)[XW] = xq + sc * XN;
+            const int c0 = (q.ch + sc) * 16;
+            if constexpr (EPI == EPI_FWD) {
+                if (q.part) { done = true; load_x<GK, 1, XW>(xs, p, q.n0, q.y0, q.x0, c0, q.np, tid); }
+            }
+            if constexpr (EPI != EPI_FWD) {
+                if (p.ga_on) { done = true; load_x<GK, 2, XW>(xs, p, q.n0, q.y0, q.x0, c0, q.np, tid); }
+            }
+            if (!done) load_x<GK, 0, XW>(xs, p, q.n0, q.y0, q.x0, c0, q.np, tid);
+        }
+        if (with_b) {
+            const float *wp = q.part ? p.wv : p.wa;
+            const int nch = q.part ? nchV : nchA;
+#pragma unroll
+            for (int sc = 0; sc < NCH; ++sc)
+#pragma unroll
+                for (int k = 0; k < BN; ++k) {
+                    const int i0 = tid + k * 256, i = i0 < BI ? i0 : 0;          // clamped: the load is unconditional
+                    const int c4 = i % CT, tg = i / CT, gg = tg & 3, tap = tg >> 2;
+                    bq[sc * BN + k] = *(const f32x4 *)(wp + ((size_t)((tap * nch + q.ch + sc) * 4 + gg) * p.Cout + co0 + c4) * 4);
+                }
+        }
+    };
+    auto unit_store = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq, int buf, bool with_b) {
+#pragma unroll
+        for (int sc = 0; sc < NCH; ++sc) {
+            f32x4 *td = tile[buf] + sc * 4 * P;
+            f32x4 (*xs)[XW] = xq + sc * XN;
+            const int c0 = (q.ch + sc) * 16;
+            bool done = false;
+            if constexpr (EPI == EPI_FWD) {
+                if (q.part) { done = true; store_x<GK, P, 1, XW>(td, xs, p, cA, q.n0, q.y0, q.x0, c0, q.np, tid); }
+            }
+            if constexpr (EPI != EPI_FWD) {
+                if (p.ga_on) { done = true; store_x<GK, P, 2, XW>(td, xs, p, cA, q.n0, q.y0, q.x0, c0, q.np, tid); }
+            }
+            if (!done) store_x<GK, P, 0, XW>(td, xs, p, cA, q.n0, q.y0, q.x0, c0, q.np, tid);
+        }
+        if (with_b) {
+            f32x4 *dst = wtile[b_once ? 0 : buf];
+#pragma unroll
+            for (int sc = 0; sc < NCH; ++sc)
+#pragma unroll
+                for (int k = 0; k < BN; ++k) { const int i = tid + k * 256; if (i < BI) dst[sc * BI + i] = bq[sc * BN + k]; }
+        }
+    };
 
-    f32x4 xr[NCH * XN][XW];
+    // Two register sets: while unit u computes, unit u+1 is landed/landing in one set (written to LDS
+    // at the end of the step) and unit u+2 is being loaded into the other: the prefetch distance is
+    // two units, enough to cover a load round trip with ~0.5 us of MFMAs per unit.
+    f32x4 xrA[NCH * XN][XW], xrB[NCH * XN][XW];
+    f32x4 brA[NCH * BN], brB[NCH * BN];
     f32x4 acc[MT][NT];
     float s1[NT], s2[NT];
 #pragma unroll
@@ -324,61 +369,27 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int t, part, ch, np, n0, y0, x0;               // current unit
-    int t2, part2, ch2, np2, m0, v0, u0;           // next unit (origin m0, v0, u0)
+    UI cu = {}, n1 = {}, n2 = {};
     if (n_units > 0) {
-        decode(0, t, part, ch, np);
-        tile_origin<GK>(p, t, n0, y0, x0);
-#pragma unroll
-        for (int sc = 0; sc < NCH; ++sc) {
-            bool pooled = false;
-            f32x4 (*xs)[XW] = xr + sc * XN;
-            f32x4 *td = tile[0] + sc * 4 * P;
-            const int c0 = (ch + sc) * 16;
-            if constexpr (EPI == EPI_FWD) {
-                if (part) {
-                    pooled = true;
-                    load_x<GK, 1, XW>(xs, p, n0, y0, x0, c0, np, tid);
-                    store_x<GK, P, 1, XW>(td, xs, p, cA, n0, y0, x0, c0, np, tid);
-                }
-            }
-            if constexpr (EPI != EPI_FWD) {
-                if (p.ga_on) {
-                    pooled = true;
-                    load_x<GK, 2, XW>(xs, p, n0, y0, x0, c0, np, tid);
-                    store_x<GK, P, 2, XW>(td, xs, p, cA, n0, y0, x0, c0, np, tid);
-                }
-            }
-            if (!pooled) {
-                load_x<GK, 0, XW>(xs, p, n0, y0, x0, c0, np, tid);
-                store_x<GK, P, 0, XW>(td, xs, p, cA, n0, y0, x0, c0, np, tid);
-            }
-        }
-        load_b(part, ch);
-        store_b(wtile[0]);
+        cu = mk(0);
+        unit_load(cu, xrA, brA, true);
+        unit_store(cu, xrA, brA, 0, true);
+    }
+    if (n_units > 1) {
+        n1 = mk(1);
+        unit_load(n1, xrA, brA, !b_once);
     }
     __syncthreads();
 
-    for (int u = 0; u < n_units; ++u) {
+    // One step: compute unit u (LDS buffer u&1); RN1 holds unit u+1, RN2 receives unit u+2.
+    auto step = [&](const int u, f32x4 (*xn1)[XW], f32x4 *bn1, f32x4 (*xn2)[XW], f32x4 *bn2) {
         const f32x4 *cur = tile[u & 1];
-        const bool more = u + 1 < n_units;
-        if (more && !(p.dbg & 2)) {
-            decode(u + 1, t2, part2, ch2, np2);
-            tile_origin<GK>(p, t2, m0, v0, u0);
-#pragma unroll
-            for (int sc = 0; sc < NCH; ++sc) {
-                bool pooled = false;
-                f32x4 (*xs)[XW] = xr + sc * XN;
-                const int c0 = (ch2 + sc) * 16;
-                if constexpr (EPI == EPI_FWD) {
-                    if (part2) { pooled = true; load_x<GK, 1, XW>(xs, p, m0, v0, u0, c0, np2, tid); }
-                }
-                if constexpr (EPI != EPI_FWD) {
-                    if (p.ga_on) { pooled = true; load_x<GK, 2, XW>(xs, p, m0, v0, u0, c0, np2, tid); }
-                }
-                if (!pooled) load_x<GK, 0, XW>(xs, p, m0, v0, u0, c0, np2, tid);
-            }
-            if (!b_once) load_b(part2, ch2);
+        const bool more = u + 1 < n_units, more2 = u + 2 < n_units;
+        const int part = cu.part, t = cu.t, n0 = cu.n0, y0 = cu.y0, x0 = cu.x0;
+        const int t2 = n1.t;
+        if (more2 && !(p.dbg & 2)) {
+            n2 = mk(u + 2);
+            unit_load(n2, xn2, bn2, !b_once);
         }
         // ----------------------------- MFMAs of unit u -----------------------------
         if (!(p.dbg & 1)) {
@@ -422,6 +433,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                 }
             }
         }
+        mfma_drain();
         // ----------------------------- epilogue of a finished tile -----------------
         // D layout: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel of the M-tile).
         if ((!more || t2 != t) && !(p.dbg & 4)) {
@@ -502,25 +514,13 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // ----------------------------- stage unit u+1, advance ----------------------
-        if (more && !(p.dbg & 2)) {
-#pragma unroll
-            for (int sc = 0; sc < NCH; ++sc) {
-                f32x4 *nxt = tile[(u + 1) & 1] + sc * 4 * P;
-                f32x4 (*xs)[XW] = xr + sc * XN;
-                const int c0 = (ch2 + sc) * 16;
-                bool pooled = false;
-                if constexpr (EPI == EPI_FWD) {
-                    if (part2) { pooled = true; store_x<GK, P, 1, XW>(nxt, xs, p, cA, m0, v0, u0, c0, np2, tid); }
-                }
-                if constexpr (EPI != EPI_FWD) {
-                    if (p.ga_on) { pooled = true; store_x<GK, P, 2, XW>(nxt, xs, p, cA, m0, v0, u0, c0, np2, tid); }
-                }
-                if (!pooled) store_x<GK, P, 0, XW>(nxt, xs, p, cA, m0, v0, u0, c0, np2, tid);
-            }
-            if (!b_once) store_b(wtile[(u + 1) & 1]);
-            t = t2; part = part2; ch = ch2; np = np2; n0 = m0; y0 = v0; x0 = u0;
-        }
-        __syncthreads();
+        if (more && !(p.dbg & 2)) unit_store(n1, xn1, bn1, (u + 1) & 1, !b_once);
+        cu = n1; n1 = n2;
+        lds_barrier();              // LDS-only: the prefetch loads of unit u+2 stay in flight
+    };
+    for (int u = 0; u < n_units; u += 2) {
+        step(u, xrA, brA, xrB, brB);
+        if (u + 1 < n_units) step(u + 1, xrB, brB, xrA, brA);
     }
 
     if (EPI == EPI_FWD || EPI == EPI_DGH_BN) {

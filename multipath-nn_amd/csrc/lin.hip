@@ -57,6 +57,7 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], b1[j], acc1, 0, 0, 0);
         }
     }
+    mfma_drain();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         red[(wid * 2 + 0) * 256 + lane * 4 + r] = acc0[r];

@@ -46,12 +46,12 @@ __device__ __forceinline__ void load_g(f32x4 *gr, f32x4 *gs, const WgP &p, int n
         int img, ty, tx;
         mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
         const int n = n0 + img;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
-        if (n < p.c.n) {
-            const size_t off = (((size_t)n * p.c.H + y0 + ty) * p.c.W + x0 + tx) * p.c.Cout + co0 + q * 4;
-            v = *(const f32x4 *)(p.g + off);
-            if (p.g_on) sv = *(const f32x4 *)(p.g_s + off);
-        }
+        // unconditional loads from a clamped address (no branch -> no vmcnt wait between items)
+        const bool live = n < p.c.n;
+        const size_t off = live ? (((size_t)n * p.c.H + y0 + ty) * p.c.W + x0 + tx) * p.c.Cout + co0 + q * 4 : 0;
+        f32x4 v = *(const f32x4 *)(p.g + off);
+        f32x4 sv = p.g_on ? *(const f32x4 *)(p.g_s + off) : v;
+        if (!live) { v = f32x4{0.f, 0.f, 0.f, 0.f}; sv = v; }
         gr[k] = v; gs[k] = sv;
     }
 }
@@ -126,7 +126,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         cn0 = n0; cy0 = y0; cx0 = x0;
     }
     for (; t < p.n_tiles; t += gx) {
-        __syncthreads();                               // previous tile's LDS reads are done
+        lds_barrier();                                 // previous tile's LDS reads are done
         store_x<GK, PS, PART, 1>(tile, xr, c, cA, cn0, cy0, cx0, ch * 16, np, tid);
 #pragma unroll
         for (int k = 0; k < OT; ++k) {
@@ -147,7 +147,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
             }
             *(f32x4 *)(gt + (i / (OT * 4)) * GS + (i % (OT * 4)) * 4) = v;
         }
-        __syncthreads();
+        lds_barrier();
         const int tn = t + gx;
         if (tn < p.n_tiles) {                          // next tile's loads fly under the MFMAs
             tile_origin<GK>(c, tn, n0, y0, x0);
@@ -179,6 +179,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         }
     }
 
+    mfma_drain();
     // D layout: col = li (cout), row = g*4 + r (input channel of the chunk).
     const size_t soff = (size_t)bx * p.split_stride;
     float *dw = (part ? p.dwv : p.dwa) + soff;

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libmpnn_hip.so')
+LIB_PATH = os.environ.get('MPNN_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'libmpnn_hip.so')
 
 ACT_IDENTITY, ACT_BN_BATCH, ACT_BN_MOVING = 0, 1, 2
 NET_SR, NET_ACTOR, NET_CRITIC = 0, 1, 2
@@ -89,7 +89,7 @@ class RouteArgs(C.Structure):
 _SIGS = {
     'mpnn_pack_weights': [P, P, P, C.c_int, P],
     'mpnn_msconv_fwd': [C.POINTER(ConvFwdArgs), P],
-    'mpnn_msconv_fwd_group': [C.POINTER(ConvFwdArgs), C.c_int, P],
+    'mpnn_msconv_fwd_group': [C.POINTER(ConvFwdArgs), P, C.c_int, P],
     'mpnn_bn_bwd_reduce': [P, C.POINTER(BnCtx), P, P, C.c_long, P],
     'mpnn_bn_bwd_apply': [P, C.POINTER(BnCtx), C.c_long, P],
     'mpnn_msconv_dgrad_horz': [C.POINTER(DgradHorzArgs), P],

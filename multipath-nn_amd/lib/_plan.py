@@ -83,6 +83,7 @@ class Engine:
         self.n_max = 0
         self.use_graph = bool(int(os.environ.get('MPNN_GRAPH', '0')))
         self.multi_stream = bool(int(os.environ.get('MPNN_STREAMS', '0')))
+        self.group_fwd = bool(int(os.environ.get('MPNN_FWD_GROUP', '1')))   # wavefront-grouped forward launches
         self._streams = []
         self._event_keep = []
         self.n_streams = 1
@@ -396,7 +397,7 @@ class Engine:
         return max(1, min(tiles, want))
 
     def program(self, mode, n):
-        key = (mode, n, self.multi_stream)
+        key = (mode, n, self.multi_stream, self.group_fwd)
         if key in self._progs:
             return self._progs[key]
         self._ensure_capacity(n)
@@ -411,6 +412,7 @@ class Engine:
                 _hip.check(fn(*args, st), what)
             launch.what, launch.flops, launch.tag = what, float(flops), tag
             launch.stream, launch.waits, launch.records = stream, tuple(waits), records
+            launch.args = args
             return launch
 
         def marker(kind):                     # 'fork' / 'join' of the side streams
@@ -453,7 +455,7 @@ class Engine:
         tag_f = lambda b, i: 'h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])
         groupable = all(b.parent is not None or b.in_map is None for b in self.blocks) and \
             all(c % 16 == 0 and not (c % 64 == 0 and h >= 16) for b in self.blocks for c, h in zip(b.C, b.H))
-        if not self.multi_stream and groupable and all(len(self.nodes[b.node.parent].layer.sinks) >= 1 for b in self.blocks):
+        if self.group_fwd and not self.multi_stream and groupable and all(len(self.nodes[b.node.parent].layer.sinks) >= 1 for b in self.blocks):
             # Wavefront over the block x scale grid: F(b, k) needs only F(b-1, k) and F(b, k-1), so level
             # d = depth(b) + k is one launch of mutually independent convs.
             kidx = {h: k for k, h in enumerate(sizes)}
@@ -471,8 +473,9 @@ class Engine:
                     arr = (_hip.ConvFwdArgs * len(grp))()
                     for a, (b, i) in zip(arr, grp):
                         fwd_args(b, i, a)
-                    keep.append(arr)
-                    fwd.append(call(lib.mpnn_msconv_fwd_group, 'fwd_group', arr, len(grp),
+                    dev_arr = _hip.to_device_table(list(arr), self.dev)
+                    keep += [arr, dev_arr]
+                    fwd.append(call(lib.mpnn_msconv_fwd_group, 'fwd_group', arr, dev_arr.data_ptr(), len(grp),
                                     flops=sum(fl_f(b, i) for b, i in grp),
                                     tag=' | '.join(tag_f(b, i) for b, i in grp)))
         else:

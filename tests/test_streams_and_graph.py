@@ -27,3 +27,61 @@ def test_multi_stream_and_graph_match_sequential():
         p1, s1 = run(multi, graph)
         assert np.abs(p1 - p0).max() <= 1e-4 * np.abs(p0).max(), (multi, graph)
         assert np.abs(s1 - s0).max() <= 1e-4 * np.abs(s0).max(), (multi, graph)
+
+
+def _net128(seed=5):
+    import arch_and_hypers as A
+    net = A.ac_chain(k_cpt=1.6e-8, seed=seed)((32, 32, 3), (10,))
+    rng = np.random.default_rng(0)
+    x0 = rng.random((128, 32, 32, 3)).astype(np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 128)]
+    return net, {net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.05, net.τ: 1.0}
+
+
+def test_training_step_is_repeatable():
+    """The same step from the same state gives the same gradients and parameters, run to run
+    (only the fp32 atomics of the exit-path dW may reorder: ~1e-8).  This caught a stale
+    MFMA-accumulator read on gfx950 (common.h: mfma_drain) that made whole tile rows of a conv
+    differ by O(1) between launches."""
+    net, feed = _net128()
+    eng = net.engine()
+    for _ in range(2):
+        net.train.run(feed)
+    torch.cuda.synchronize()
+    P0, A0, S0 = eng.P.clone(), eng.A.clone(), eng.S.clone()
+    outs = []
+    for rep in range(4):
+        eng.P.copy_(P0); eng.A.copy_(A0); eng.S.copy_(S0)
+        net.train.run(feed)
+        torch.cuda.synchronize()
+        outs.append((eng.G.clone(), eng.P.clone(), [s.clone() for b in eng.blocks for s in b.s]))
+    g0, p0, s0 = outs[0]
+    for g, p, s in outs[1:]:
+        for a, b in zip(s, s0):
+            assert torch.equal(a, b), 'forward conv sums differ between identical launches'
+        assert (g - g0).abs().max().item() <= 1e-6 * g0.abs().max().item()
+        assert (p - p0).abs().max().item() <= 1e-6 * p0.abs().max().item()
+
+
+def test_wavefront_groups_equal_single_launches():
+    """mpnn_msconv_fwd_group (one launch per wavefront level) computes what one mpnn_msconv_fwd
+    launch per conv computes.  Block 0 (no BatchNorm on its input) is bit-identical; deeper blocks
+    see the fp64 statistics slots filled in a different workgroup order, i.e. fp32 coefficients
+    that may differ in the last bit."""
+    net, feed = _net128(seed=11)
+    eng = net.engine()
+    eng.use_graph = False
+    res = {}
+    for group in (True, False):
+        eng.group_fwd = group
+        eng.init_params(11)
+        net.train.run(feed)
+        torch.cuda.synchronize()
+        res[group] = [s.clone() for b in eng.blocks for s in b.s] + [s.clone() for b in eng.blocks for s in b.sp]
+    kinds = {op.what for op in eng.program('tr', 128)['fwd']}
+    assert 'msconv_fwd' in kinds and 'fwd_group' not in kinds
+    n0 = eng.blocks[0].L
+    for k, (a, b) in enumerate(zip(res[True], res[False])):
+        if k < n0:
+            assert torch.equal(a, b), k
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item(), k

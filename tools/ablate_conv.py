@@ -7,6 +7,7 @@ eng = net.engine(); n = 128
 eng.x0[:n].uniform_(); eng.y[:n].zero_(); eng.y[:n, 0] = 1
 feed = {net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr', net.λ_lrn: 0.0, net.τ: 1.0}
 net.train.run(feed)
+eng.multi_stream = True     # separate launches (they honour MPNN_CONV_DBG)
 want = {'h4 128+0->128', 'h8 64+0->64', 'h32 16+0->16', 'h4 64+64->64', 'h16 32+0->32'}
 for dbg in (0, 1, 2, 4, 3, 7):
     os.environ['MPNN_CONV_DBG'] = str(dbg)
