@@ -176,8 +176,9 @@ int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *horz, const mpnn_dgrad_ver
 /* Number of 64-pixel tiles (upper bound of n_split) for a map, or MPNN_E_SHAPE. */
 int mpnn_wgrad_tiles(int n, int H, int W);
 /* dst[i] = sum_{s<n_split} src[s*stride + i].  table: 6 ints per work item:
- * src_off (floats in `slabs`), dst_off (floats in `grads`), count (<= 1024),
- * n_split, stride, reserved. */
+ * src_off (floats in `slabs`), dst_off (floats in `grads`), count (<= 256),
+ * n_split, stride, reserved.  One workgroup per item; a count above 256 is MPNN_E_ARG-free
+ * undefined behaviour, so split larger tensors into several items. */
 int mpnn_slab_reduce(const float *slabs, float *grads, const int *table, int n_items,
                      void *stream);
 
@@ -317,6 +318,19 @@ int mpnn_talr_momentum_step(float *params, float *accum, const float *grads,
                             const int *seg, int n_seg, const float *node_stat,
                             const float *hyp, int talr, float inv_n, float grad_scale,
                             void *stream);
+
+/* Workgroups of the mpnn_msconv_bwd_scale kernel for an H x W x Cout scale that are resident on the
+ * device at once (occupancy x compute units; needs a GPU).  The caller gives the weight-gradient
+ * split (n_split x channel chunks x cout groups workgroups) about half of them, so that the dgrad
+ * and wgrad workgroups of the launch all start together.  Negative = MPNN_E_*. */
+int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad);
+
+/* Profiling aid (no reference counterpart).  Installs (or, with NULL, removes) a device buffer of
+ * MPNN_TRACE_SLOTS (8) uint64 per workgroup of the largest grid to be traced: thread 0 of every
+ * workgroup of the conv / dgrad / wgrad kernels stamps the 100 MHz device clock at its phase
+ * boundaries (entry, tables ready, first tile staged, first unit done, loop done, exit; slot 6 = body
+ * kind, slot 7 = units).  tools/trace_phases.py prints the timeline.  Synchronises the device. */
+int mpnn_debug_set_trace(unsigned long long *buf);
 
 const char *mpnn_version(void);
 

@@ -14,6 +14,56 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MPNN_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) return (int)e_; } while (0)
 
+// Workgroups of `kernel` (256 threads, `dyn_lds` bytes of dynamic LDS) that are resident on the
+// device at once (occupancy x compute units), cached per kernel instantiation.  The persistent grids
+// are sized to this: workgroups beyond it only start when earlier ones exit, which serialises the
+// bodies of a fused launch (measured: the weight-gradient workgroups of bwd_scale started 8-13 us late).
+static int resident_slots(const void *kernel, int dyn_lds) {
+    struct Entry { const void *fn; int lds, slots; };
+    static Entry cache[64];
+    static int n_cached = 0;
+    for (int i = 0; i < n_cached; ++i)
+        if (cache[i].fn == kernel && cache[i].lds == dyn_lds) return cache[i].slots;
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, (size_t)dyn_lds) != hipSuccess || per_cu < 1)
+        per_cu = 2;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int slots = per_cu * cus;
+    if (n_cached < 64) cache[n_cached++] = Entry{kernel, dyn_lds, slots};
+    return slots;
+}
+
+// ---------------------------------------------------------------------------
+// Phase trace (profiling aid; off unless mpnn_debug_set_trace() installed a buffer).  Thread 0 of a
+// workgroup stamps the 100 MHz constant clock into buf[wg * MPNN_TRACE_SLOTS + k]; the host tool
+// (tools/trace_phases.py) turns the stamps into a per-workgroup timeline of a single launch.
+// Every translation unit has its own copy of the pointer (no relocatable device code).
+// ---------------------------------------------------------------------------
+// Compiled in only with -DMPNN_TRACE (make trace -> libmpnn_hip_trace.so): the stamps cost registers.
+#define MPNN_TRACE_SLOTS 8
+#ifdef MPNN_TRACE
+static __device__ unsigned long long *mpnn_trace_buf_ = nullptr;
+__device__ __forceinline__ void trace_stamp(int k) {
+    unsigned long long *b = mpnn_trace_buf_;
+    if (b && threadIdx.x == 0)
+        b[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * MPNN_TRACE_SLOTS + k] = __builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void trace_note(int k, unsigned long long v) {
+    unsigned long long *b = mpnn_trace_buf_;
+    if (b && threadIdx.x == 0) b[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * MPNN_TRACE_SLOTS + k] = v;
+}
+static inline int mpnn_trace_install(void *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(mpnn_trace_buf_), &buf, sizeof(buf));
+}
+#else
+__device__ __forceinline__ void trace_stamp(int) {}
+__device__ __forceinline__ void trace_note(int, unsigned long long) {}
+static inline int mpnn_trace_install(void *) { return MPNN_E_ARG; }
+#endif
+
 // ---------------------------------------------------------------------------
 // BatchNorm coefficients for one channel (reference: layer_types.py:231-238).
 // Batch mode: mean/biased variance from the fp64 sums the producing conv
@@ -21,10 +71,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------
 struct BnC { float m, rstd, gamma, beta; };
 
-// Sum of one statistic over the replicated slots.
+// Sums of TWO statistics over the replicated slots in one loop: the loads of both are in flight
+// together, 8 slots per round trip (16 slots = 2 dependent round trips instead of 8).
+__device__ __forceinline__ void slot_sum2(const double *base, int C2, int i0, int i1, int nslot, double &a, double &b) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll 8
+    for (int s = 0; s < nslot; ++s) { t0 += base[s * C2 + i0]; t1 += base[s * C2 + i1]; }
+    a = t0; b = t1;
+}
 __device__ __forceinline__ double slot_sum(const double *base, int C2, int idx, int nslot) {
     double t = 0.0;
-#pragma unroll 4
+#pragma unroll 8
     for (int s = 0; s < nslot; ++s) t += base[s * C2 + idx];
     return t;
 }
@@ -35,8 +92,10 @@ __device__ __forceinline__ BnC bn_coef(const mpnn_act &b, int c) {
     k.beta = b.beta[c];
     if (b.mode == MPNN_ACT_BN_BATCH) {
         const double inv = 1.0 / (double)b.cnt;
-        const double mean = slot_sum(b.sum, 2 * b.C, c, b.nslot) * inv;
-        double var = slot_sum(b.sum, 2 * b.C, b.C + c, b.nslot) * inv - mean * mean;
+        double s1, s2;
+        slot_sum2(b.sum, 2 * b.C, c, b.C + c, b.nslot, s1, s2);
+        const double mean = s1 * inv;
+        double var = s2 * inv - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         k.m = (float)mean;
         k.rstd = rsqrtf((float)var + b.eps);

@@ -36,6 +36,8 @@ int mpnn_fill_dgrad_vert(const mpnn_dgrad_vert_args *a, ConvP &p) {
 }
 
 // Both input gradients of one scale (they read the same g) in ONE launch.
+int mpnn_trace_install_dgrad(void *buf) { return mpnn_trace_install(buf); }
+
 extern "C" int mpnn_msconv_dgrad_pair(const mpnn_dgrad_horz_args *h, const mpnn_dgrad_vert_args *v, void *stream) {
     ConvP ph = {}, pv = {};
     int rc = mpnn_fill_dgrad_horz(h, ph);

@@ -3,6 +3,8 @@
 
 __host__ __device__ static inline int fill_fwd(const mpnn_conv_fwd_args *a, ConvP &p);
 
+int mpnn_trace_install_fwd(void *buf) { return mpnn_trace_install(buf); }
+
 extern "C" int mpnn_msconv_fwd(const mpnn_conv_fwd_args *a, void *stream) {
     ConvP p = {};
     const int rc = fill_fwd(a, p);
@@ -76,21 +78,27 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         q.y0[k] = rows;
         rows += q.gy[k];
     }
-    // Share the ~1024 resident workgroup slots (256 CUs x 4) between the members in proportion to
-    // their tile-rows, so that every member is resident from the start.
-    long total = 0;
-    for (int k = 0; k < count; ++k) total += (long)hp[k].n_tiles * q.gy[k];
+    // Share the resident workgroup slots between the members in proportion to their work, so that
+    // every member is resident from the start.
+    const int bytes[3] = {ConvSmem<0, 4, 16>::BYTES, ConvSmem<1, 4, 16>::BYTES, ConvSmem<2, 4, 16>::BYTES};
+    int lds = 0;
+    for (int k = 0; k < count; ++k) if (bytes[q.gk[k]] > lds) lds = bytes[q.gk[k]];
+    const long slots = resident_slots((const void *)fwd_group_k, lds);
+    // work of a member = tile-rows x units per tile (16-channel chunks of both operands)
+    long total = 0, work[4];
     for (int k = 0; k < count; ++k) {
-        long g = count == 1 ? conv_cap_gx(hp[k].n_tiles, q.gy[k]) : (1024L * hp[k].n_tiles) / (total > 0 ? total : 1);
-        if (g < 16) g = 16;
+        const long units = ((hp[k].a.C + 15) >> 4) + (hp[k].v ? ((hp[k].Cv + 15) >> 4) : 0);
+        work[k] = (long)hp[k].n_tiles * q.gy[k] * units;
+        total += work[k];
+    }
+    for (int k = 0; k < count; ++k) {
+        long g = (slots * work[k]) / (total > 0 ? total : 1) / q.gy[k];      // workgroups per tile-row
+        if (g < 1) g = 1;
         if (g > hp[k].n_tiles) g = hp[k].n_tiles;
         q.gx[k] = (int)g;
         if (q.gx[k] > gxm) gxm = q.gx[k];
     }
     q.n = count;
-    const int bytes[3] = {ConvSmem<0, 4, 16>::BYTES, ConvSmem<1, 4, 16>::BYTES, ConvSmem<2, 4, 16>::BYTES};
-    int lds = 0;
-    for (int k = 0; k < count; ++k) if (bytes[q.gk[k]] > lds) lds = bytes[q.gk[k]];
     hipLaunchKernelGGL(fwd_group_k, dim3(gxm, rows), dim3(256), lds, (hipStream_t)stream, dev_args, q);
     MPNN_LAUNCH_CHECK();
     return 0;

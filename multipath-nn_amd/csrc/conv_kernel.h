@@ -229,6 +229,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     double *redbuf = (double *)(smem + SM::TILE + SM::WT + SM::CA + ((SM::CE + 15) & ~15));
     float *pool_lds = (float *)(smem + SM::TILE + SM::WT + SM::CA + ((SM::CE + 15) & ~15) + SM::RED);   // [64 px][CT]
 
+    trace_stamp(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
@@ -236,36 +237,6 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     const int co0 = by * CT;
     const int cw = co0 + wn * NT * 16 + li;          // this lane's first output channel
 
-    if (EPI == EPI_FWD && p.a.mode != MPNN_ACT_IDENTITY) {
-        for (int c = tid; c < p.a.C; c += 256) {
-            const BnC k = bn_coef(p.a, c);
-            cA[c * 3] = k.m; cA[c * 3 + 1] = k.gamma * k.rstd; cA[c * 3 + 2] = k.beta;
-        }
-    }
-    if (EPI != EPI_FWD && p.ga_on) {
-        const double inv = 1.0 / (double)p.ga_bn.cnt;
-        for (int c = tid; c < p.a.C; c += 256) {
-            const BnC k = bn_coef(p.ga_bn, c);
-            float *e = cA + c * 5;
-            e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
-            e[3] = (float)(slot_sum(p.ga_red, 2 * p.a.C, c, p.ga_nslot) * inv);
-            e[4] = (float)(slot_sum(p.ga_red, 2 * p.a.C, p.a.C + c, p.ga_nslot) * inv);
-        }
-    }
-    if (EPI == EPI_DGH_BN || EPI == EPI_DGV) {
-        for (int c = tid; c < CT; c += 256) {
-            const BnC k = bn_coef(p.pbn, co0 + c);
-            float *e = cE + c * 5;
-            e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
-            if (EPI == EPI_DGH_BN) { e[3] = k.beta; e[4] = 0.f; }
-            else {
-                const double inv = 1.0 / (double)p.pbn.cnt;
-                e[3] = p.red ? (float)(slot_sum(p.red, 2 * p.pbn.C, co0 + c, p.red_nslot) * inv) : 0.f;             // dbeta / cnt
-                e[4] = p.red ? (float)(slot_sum(p.red, 2 * p.pbn.C, p.pbn.C + co0 + c, p.red_nslot) * inv) : 0.f;   // dgamma / cnt
-            }
-        }
-    }
-    __syncthreads();
 
     float bias_r[NT];
 #pragma unroll
@@ -355,8 +326,9 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         }
     };
 
-    // Two register sets: while unit u computes, unit u+1 is landed/landing in one set (written to LDS
-    // at the end of the step) and unit u+2 is being loaded into the other: the prefetch distance is
+    // Two register sets (unit 0 -> A, unit 1 -> B in the prologue): while unit u computes, unit u+1 is
+    // landed/landing in one set (written to LDS at the end of the step) and unit u+2 is being loaded
+    // into the other: the prefetch distance is
     // two units, enough to cover a load round trip with ~0.5 us of MFMAs per unit.
     f32x4 xrA[NCH * XN][XW], xrB[NCH * XN][XW];
     f32x4 brA[NCH * BN], brB[NCH * BN];
@@ -369,17 +341,54 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Prologue: coefficient tables first, then units 0 and 1 requested together.  (Requesting unit 0
+    // before the tables was measured slower: memory returns in order, so the table loads queue behind
+    // the tile loads and nothing is saved, while the registers stay live across the table code.)
     UI cu = {}, n1 = {}, n2 = {};
+    if (EPI == EPI_FWD && p.a.mode != MPNN_ACT_IDENTITY) {
+        for (int c = tid; c < p.a.C; c += 256) {
+            const BnC k = bn_coef(p.a, c);
+            cA[c * 3] = k.m; cA[c * 3 + 1] = k.gamma * k.rstd; cA[c * 3 + 2] = k.beta;
+        }
+    }
+    if (EPI != EPI_FWD && p.ga_on) {
+        const double inv = 1.0 / (double)p.ga_bn.cnt;
+        for (int c = tid; c < p.a.C; c += 256) {
+            const BnC k = bn_coef(p.ga_bn, c);
+            float *e = cA + c * 5;
+            e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
+            double r0, r1;
+            slot_sum2(p.ga_red, 2 * p.a.C, c, p.a.C + c, p.ga_nslot, r0, r1);
+            e[3] = (float)(r0 * inv); e[4] = (float)(r1 * inv);
+        }
+    }
+    if (EPI == EPI_DGH_BN || EPI == EPI_DGV) {
+        for (int c = tid - 128; c >= 0 && c < CT; c += 256) {     // waves 2-3: beside the table above
+            const BnC k = bn_coef(p.pbn, co0 + c);
+            float *e = cE + c * 5;
+            e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
+            if (EPI == EPI_DGH_BN) { e[3] = k.beta; e[4] = 0.f; }
+            else {
+                const double inv = 1.0 / (double)p.pbn.cnt;
+                double r0 = 0.0, r1 = 0.0;                         // dbeta, dgamma
+                if (p.red) slot_sum2(p.red, 2 * p.pbn.C, co0 + c, p.pbn.C + co0 + c, p.red_nslot, r0, r1);
+                e[3] = (float)(r0 * inv); e[4] = (float)(r1 * inv);
+            }
+        }
+    }
+    __syncthreads();
+    trace_stamp(1);
     if (n_units > 0) {
         cu = mk(0);
         unit_load(cu, xrA, brA, true);
-        unit_store(cu, xrA, brA, 0, true);
     }
     if (n_units > 1) {
         n1 = mk(1);
-        unit_load(n1, xrA, brA, !b_once);
+        unit_load(n1, xrB, brB, !b_once);
     }
+    if (n_units > 0) unit_store(cu, xrA, brA, 0, true);
     __syncthreads();
+    trace_stamp(2);
 
     // One step: compute unit u (LDS buffer u&1); RN1 holds unit u+1, RN2 receives unit u+2.
     auto step = [&](const int u, f32x4 (*xn1)[XW], f32x4 *bn1, f32x4 (*xn2)[XW], f32x4 *bn2) {
@@ -519,9 +528,11 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         lds_barrier();              // LDS-only: the prefetch loads of unit u+2 stay in flight
     };
     for (int u = 0; u < n_units; u += 2) {
-        step(u, xrA, brA, xrB, brB);
-        if (u + 1 < n_units) step(u + 1, xrB, brB, xrA, brA);
+        step(u, xrB, brB, xrA, brA);
+        if (u == 0) trace_stamp(3);
+        if (u + 1 < n_units) step(u + 1, xrA, brA, xrB, brB);
     }
+    trace_stamp(4);
 
     if (EPI == EPI_FWD || EPI == EPI_DGH_BN) {
         double *dst = EPI == EPI_FWD ? p.out_sum : p.red_out;
@@ -547,6 +558,8 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             }
         }
     }
+    trace_stamp(5);
+    trace_note(6, EPI + 1); trace_note(7, n_units);
 }
 
 template <int GK, int MT, int NT, int WM, int WN, bool SMALL_A, int EPI>

@@ -258,4 +258,15 @@ extern "C" int mpnn_compact_by_branch(const float *p_ev, int n, int *idx_out, in
     return 0;
 }
 
+int mpnn_trace_install_fwd(void *buf);
+int mpnn_trace_install_dgrad(void *buf);
+int mpnn_trace_install_wgrad(void *buf);
+
+extern "C" int mpnn_debug_set_trace(unsigned long long *buf) {
+    int rc = mpnn_trace_install_fwd(buf);
+    if (!rc) rc = mpnn_trace_install_dgrad(buf);
+    if (!rc) rc = mpnn_trace_install_wgrad(buf);
+    return rc;
+}
+
 extern "C" const char *mpnn_version(void) { return "mpnn_hip 0.1 (gfx950)"; }

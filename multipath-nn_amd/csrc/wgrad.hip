@@ -75,28 +75,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     int np = (C - ch * 16 + 3) >> 2;
     np = np > 4 ? 4 : np;
     const bool bias_wave = wid == 1 && by == 0;           // slot ti = 2 of wave 1 is tap 9: unused
-
-    if (part == 0 && c.a.mode != MPNN_ACT_IDENTITY) {
-        for (int cc = tid; cc < c.a.C; cc += 256) {
-            const BnC k = bn_coef(c.a, cc);
-            cA[cc * 3] = k.m; cA[cc * 3 + 1] = k.gamma * k.rstd; cA[cc * 3 + 2] = k.beta;
-        }
-        __syncthreads();
-    }
-
-    float *cG = cA + 128 * 3;                        // [OT*16][5]: BatchNorm-backward coefficients of this cout group
-    if (p.g_on) {
-        const double inv = 1.0 / (double)p.g_bn.cnt;
-        for (int cc = tid; cc < OT * 16; cc += 256) {
-            const int co = co0 + cc;
-            const BnC k = bn_coef(p.g_bn, co);
-            float *e = cG + cc * 5;
-            e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
-            e[3] = (float)(slot_sum(p.g_red, 2 * c.Cout, co, p.g_nslot) * inv);
-            e[4] = (float)(slot_sum(p.g_red, 2 * c.Cout, c.Cout + co, p.g_nslot) * inv);
-        }
-        __syncthreads();
-    }
+    trace_stamp(0);
 
     f32x4 acc[3][OT];
 #pragma unroll
@@ -116,6 +95,29 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         tap_off[ti] = (tap / 3) * R + (tap % 3);
     }
 
+    if (part == 0 && c.a.mode != MPNN_ACT_IDENTITY) {
+        for (int cc = tid; cc < c.a.C; cc += 256) {
+            const BnC k = bn_coef(c.a, cc);
+            cA[cc * 3] = k.m; cA[cc * 3 + 1] = k.gamma * k.rstd; cA[cc * 3 + 2] = k.beta;
+        }
+    }
+
+    float *cG = cA + 128 * 3;                        // [OT*16][5]: BatchNorm-backward coefficients of this cout group
+    if (p.g_on) {
+        const double inv = 1.0 / (double)p.g_bn.cnt;
+        for (int cc = tid - 128; cc >= 0 && cc < OT * 16; cc += 256) {     // waves 2-3: beside the table above
+            const int co = co0 + cc;
+            const BnC k = bn_coef(p.g_bn, co);
+            float *e = cG + cc * 5;
+            e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
+            double r0, r1;
+            slot_sum2(p.g_red, 2 * c.Cout, co, c.Cout + co, p.g_nslot, r0, r1);
+            e[3] = (float)(r0 * inv); e[4] = (float)(r1 * inv);
+        }
+    }
+
+    __syncthreads();
+    trace_stamp(1);
     f32x4 xr[XN][1], gr[OT], gs[OT];
     int t = bx;
     int n0, y0, x0, cn0 = 0, cy0 = 0, cx0 = 0;
@@ -148,6 +150,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
             *(f32x4 *)(gt + (i / (OT * 4)) * GS + (i % (OT * 4)) * 4) = v;
         }
         lds_barrier();
+        if (t == bx) trace_stamp(2);
         const int tn = t + gx;
         if (tn < p.n_tiles) {                          // next tile's loads fly under the MFMAs
             tile_origin<GK>(c, tn, n0, y0, x0);
@@ -179,6 +182,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         }
     }
 
+    trace_stamp(4);
     mfma_drain();
     // D layout: col = li (cout), row = g*4 + r (input channel of the chunk).
     const size_t soff = (size_t)bx * p.split_stride;
@@ -200,6 +204,8 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
 #pragma unroll
         for (int nt = 0; nt < OT; ++nt) p.db[soff + co0 + nt * 16 + li] = acc[2][nt][0];
     }
+    trace_stamp(5);
+    trace_note(6, 8); trace_note(7, bx < p.n_tiles ? (p.n_tiles - 1 - bx) / gx + 1 : 0);
 }
 
 template <int GK, int OT>
@@ -265,6 +271,8 @@ static int wgrad_launch(const WgP &p, int split, hipStream_t st) {
     return 0;
 }
 
+int mpnn_trace_install_wgrad(void *buf) { return mpnn_trace_install(buf); }
+
 extern "C" int mpnn_wgrad_tiles(int n, int H, int W) {
     if (W >= 16 && (W % 16) == 0 && (H % 4) == 0) return conv_grid_x<0>(n, H, W);
     if (W == 8 && H == 8) return conv_grid_x<1>(n, 8, 8);
@@ -311,32 +319,61 @@ int mpnn_fill_dgrad_horz(const mpnn_dgrad_horz_args *a, ConvP &p);     // conv_d
 int mpnn_fill_dgrad_vert(const mpnn_dgrad_vert_args *a, ConvP &p);
 
 template <int GK>
+static auto bwd_scale_kernel(bool wide, bool deep) -> void (*)(const BwdScaleP) {
+    return deep ? (wide ? bwd_scale_k<GK, 4, 2> : bwd_scale_k<GK, 1, 2>)
+                : (wide ? bwd_scale_k<GK, 4, 1> : bwd_scale_k<GK, 1, 1>);
+}
+
+// Resident workgroups of the kernel mpnn_msconv_bwd_scale runs for this shape (the caller sizes
+// the weight-gradient split, and with it the slabs, to a share of them).
+extern "C" int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad) {
+    static const int nch_env = [] { const char *e = getenv("MPNN_CONV_NCH"); return e ? atoi(e) : 0; }();
+    const bool wide = (Cout % 64) == 0;
+    const int gk = (W >= 16 && (W % 16) == 0 && (H % 4) == 0) ? 0 : (W == 8 && H == 8) ? 1 : (W == 4 && H == 4) ? 2 : -1;
+    if (gk < 0 || (Cout % 16)) return MPNN_E_SHAPE;
+    bool deep = gk != 0 && (Cout % 32) == 0 && has_dgrad;
+    if (nch_env == 1) deep = false;
+    const void *k = gk == 0 ? (const void *)bwd_scale_kernel<0>(wide, deep)
+                  : gk == 1 ? (const void *)bwd_scale_kernel<1>(wide, deep) : (const void *)bwd_scale_kernel<2>(wide, deep);
+    return resident_slots(k, 0);
+}
+
+template <int GK>
 static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hipStream_t st) {
     const int tiles = conv_grid_x<GK>(q.w.c.n, q.w.c.H, q.w.c.W);
     q.gyh = has_h ? q.h.Cout / 16 : 0;
     q.gyv = has_v ? q.v.Cout / 16 : 0;
     q.h.n_tiles = q.v.n_tiles = tiles;
-    q.gxh = has_h ? conv_cap_gx(tiles, q.gyh) : 0;
-    q.gxv = has_v ? conv_cap_gx(tiles, q.gyv) : 0;
     q.gxw = split;
     q.nchw = ((q.w.c.a.C + 15) >> 4) + (q.w.c.v ? ((q.w.c.Cv + 15) >> 4) : 0);
     const bool wide = (q.w.c.Cout % 64) == 0;           // 64-channel weight-gradient groups for wide layers
     const int gyw = q.nchw * (q.w.c.Cout / (wide ? 64 : 16));
-    int gx = q.gxw;
-    if (q.gxh > gx) gx = q.gxh;
-    if (q.gxv > gx) gx = q.gxv;
-    const dim3 grid(gx, q.gyh + q.gyv + gyw);
     // 32-channel units for the dgrad bodies when g has a multiple of 32 channels on a small map
     static const int nch_env = [] { const char *e = getenv("MPNN_CONV_NCH"); return e ? atoi(e) : 0; }();
     bool deep = GK != 0 && (q.w.c.Cout % 32) == 0 && (has_h || has_v);
     if (nch_env == 1) deep = false;
-    if (deep) {
-        if (wide) hipLaunchKernelGGL((bwd_scale_k<GK, 4, 2>), grid, dim3(256), 0, st, q);
-        else      hipLaunchKernelGGL((bwd_scale_k<GK, 1, 2>), grid, dim3(256), 0, st, q);
-    } else {
-        if (wide) hipLaunchKernelGGL((bwd_scale_k<GK, 4, 1>), grid, dim3(256), 0, st, q);
-        else      hipLaunchKernelGGL((bwd_scale_k<GK, 1, 1>), grid, dim3(256), 0, st, q);
-    }
+    void (*kern)(const BwdScaleP) = bwd_scale_kernel<GK>(wide, deep);
+    // Fit the grid to what is resident at once: the weight-gradient rows keep their split x rows
+    // workgroups (the slabs are sized for them), the two dgrad bodies share the rest by work.
+    const long slots = resident_slots((const void *)kern, 0);
+    long avail = slots - (long)split * gyw;
+    if (avail < slots / 4) avail = slots / 4;
+    const long units = (q.w.c.Cout + 15) >> 4;          // g's 16-channel chunks: units per dgrad tile
+    const long wh = has_h ? (long)q.gyh * units : 0, wv = has_v ? (long)q.gyv * units : 0;
+    auto share = [&](long w, int gy) {
+        if (!w) return 0;
+        long g = avail * w / (wh + wv) / gy;
+        if (g < 1) g = 1;
+        if (g > tiles) g = tiles;
+        return (int)g;
+    };
+    q.gxh = share(wh, q.gyh);
+    q.gxv = share(wv, q.gyv);
+    int gx = q.gxw;
+    if (q.gxh > gx) gx = q.gxh;
+    if (q.gxv > gx) gx = q.gxv;
+    const dim3 grid(gx, q.gyh + q.gyv + gyw);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, q);
     MPNN_LAUNCH_CHECK();
     return 0;
 }
@@ -366,33 +403,49 @@ extern "C" int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *h, const mpnn_d
 }
 
 // ---------------------------------------------------------------------------
-// mpnn_slab_reduce: dst[i] = sum_{s < n_split} src[s * stride + i], fixed order.
-// table: 6 ints per work item: src_off, dst_off, count (<= 1024), n_split, stride, -.
+// mpnn_slab_reduce: dst[i] = sum_{s < n_split} src[s * stride + i], in a fixed order.
+// table: 6 ints per work item: src_off, dst_off, count (<= 256), n_split, stride, -.
+// One workgroup per item: lane l of every wave owns elements [4l, 4l+4); the four waves each sum a
+// contiguous quarter of the slabs (8 loads in flight), and the quarters are combined through LDS in
+// wave order -- the serial chain is n_split / 32 round trips instead of n_split / 8.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void slab_reduce_k(const float *__restrict__ slabs, float *__restrict__ grads,
                                                      const int *__restrict__ table) {
     const int *t = table + blockIdx.x * 6;
     const int src = t[0], dst = t[1], cnt = t[2], ns = t[3], stride = t[4];
-    const int i = threadIdx.x * 4;
-    if (i >= cnt) return;
-    if (i + 4 <= cnt && ((src + i) & 3) == 0 && (stride & 3) == 0 && ((dst + i) & 3) == 0) {
-        const float *base = slabs + src + i;
-        f32x4 a[8];
+    __shared__ f32x4 part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane * 4;
+    const int per = (ns + 3) >> 2, s0 = w * per, s1 = min(ns, s0 + per);
+    const bool vec = ((src | stride | dst) & 3) == 0;          // uniform
+    f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+    if (i < cnt) {
+        if (vec && i + 4 <= cnt) {
+            const float *base = slabs + src + i;
+            f32x4 a[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int s = 0;
-        for (; s + 8 <= ns; s += 8) {
+            for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int sl = s0;
+            for (; sl + 8 <= s1; sl += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += *(const f32x4 *)(base + (size_t)(s + u) * stride);
+                for (int u = 0; u < 8; ++u) a[u] += *(const f32x4 *)(base + (size_t)(sl + u) * stride);
+            }
+            for (; sl < s1; ++sl) a[0] += *(const f32x4 *)(base + (size_t)sl * stride);
+            tot = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        } else {
+            for (int j = 0; j < 4 && i + j < cnt; ++j) {
+                float acc = 0.f;
+                for (int sl = s0; sl < s1; ++sl) acc += slabs[src + (size_t)sl * stride + i + j];
+                tot[j] = acc;
+            }
         }
-        for (; s < ns; ++s) a[0] += *(const f32x4 *)(base + (size_t)s * stride);
-        *(f32x4 *)(grads + dst + i) = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    } else {
-        for (int j = i; j < min(i + 4, cnt); ++j) {
-            float acc = 0.f;
-            for (int s = 0; s < ns; ++s) acc += slabs[src + (size_t)s * stride + j];
-            grads[dst + j] = acc;
-        }
+    }
+    part[w][lane] = tot;
+    __syncthreads();
+    if (w == 0 && i < cnt) {
+        const f32x4 r = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (vec && i + 4 <= cnt) *(f32x4 *)(grads + dst + i) = r;
+        else for (int j = 0; j < 4 && i + j < cnt; ++j) grads[dst + i + j] = r[j];
     }
 }
 

@@ -391,7 +391,15 @@ class Engine:
         groups = max(1, b.C[i] // 64) if b.C[i] % 64 == 0 else (b.C[i] // 32 if b.C[i] % 32 == 0 else b.C[i] // 16)
         if fused:
             groups = b.C[i] // 64 if b.C[i] % 64 == 0 else b.C[i] // 16    # as mpnn_msconv_bwd_scale
-        want = max(1, 512 // (nch * groups))
+        budget = 512
+        if fused:
+            # about half of the workgroups that are resident at once: the dgrad bodies of the same
+            # launch take the rest, and everything starts together
+            has_dgrad = 1 if (b.in_map is not None or i > 0) else 0
+            slots = self.lib.mpnn_msconv_bwd_scale_slots(b.H[i], b.W[i], b.C[i], has_dgrad)
+            if slots > 0:
+                budget = min(512, slots // 2 if has_dgrad else slots)
+        want = max(1, budget // (nch * groups))
         w_bytes = 4 * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
         want = min(want, max(1, (12 << 20) // w_bytes))         # keep a layer's slab under ~12 MB
         return max(1, min(tiles, want))
@@ -663,8 +671,8 @@ class Engine:
                     for prm, sz in zip((pa, pv, pb), sizes):
                         if prm is None:
                             continue
-                        for k in range(0, sz, 1024):
-                            slab_plan['table'] += [off + k, prm.offset + k, min(1024, sz - k), split, stride, 0]
+                        for k in range(0, sz, 256):
+                            slab_plan['table'] += [off + k, prm.offset + k, min(256, sz - k), split, stride, 0]
                         slab_plan['ptrs'].append((a, {id(pa): 'dwa', id(pb): 'db'}.get(id(prm), 'dwv'), off))
                         off += sz
                     a.split_stride = stride

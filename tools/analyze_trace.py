@@ -21,3 +21,10 @@ if len(idx) > 6:
     union += cur_e - cur_s
     print('per step: wall %.1f us, sum of kernel durations %.1f us, GPU busy (union) %.1f us, idle %.1f us, kernels %d'
           % (wall, busy, union / steps / 1e3, wall - union / steps / 1e3, len(seg) // steps))
+    # per-kernel mean duration and mean gap to the previous kernel's end, one steady-state step
+    one = seg[-(len(seg) // steps):]
+    print('%-58s %8s %8s' % ('kernel (last step, in order)', 'dur us', 'gap us'))
+    prev_e = None
+    for s, e, name in one:
+        print('%-58s %8.1f %8.1f' % (name[:58], (e - s) / 1e3, 0.0 if prev_e is None else (s - prev_e) / 1e3))
+        prev_e = e

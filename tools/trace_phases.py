@@ -1,0 +1,62 @@
+"""Per-workgroup phase timeline of every conv / backward launch of one training step.
+
+Needs the trace build of the library (make -C multipath-nn_amd/csrc trace) and selects it through
+MPNN_HIP_LIB.  For each launch: when workgroups start (dispatch ramp), and when they pass the phase
+stamps (tables ready, first tile staged, first unit done, loop done, exit), relative to the first
+workgroup's start; clock = 100 MHz (10 ns ticks).
+
+    python tools/trace_phases.py [substring of the launch tag]
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault('MPNN_HIP_LIB', os.path.join(ROOT, 'multipath-nn_amd', 'libmpnn_hip_trace.so'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'multipath-nn_amd'))
+import numpy as np, torch, arch_and_hypers as A
+from lib import _hip
+
+want = sys.argv[1] if len(sys.argv) > 1 else ''
+net = A.ac_chain(k_cpt=0.0, seed=1234)((32, 32, 3), (10,))
+eng = net.engine()
+n = 128
+eng.x0[:n].uniform_(); eng.y[:n].zero_(); eng.y[:n, 0] = 1
+feed = {net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr', net.λ_lrn: 0.1, net.τ: 1.0}
+for _ in range(3): net.train.run(feed)
+torch.cuda.synchronize()
+prog = eng.program('tr', n)
+ops = [o for o in list(prog['fwd']) + list(prog['bwd']) if o.what not in ('fork', 'join')]
+st = torch.cuda.current_stream()
+eng._zero(True); eng._pack()
+for op in ops: op(st.cuda_stream)
+torch.cuda.synchronize()
+NWG = 1 << 16
+buf = torch.zeros(NWG * 8, dtype=torch.int64, device=eng.dev)
+KIND = {1: 'fwd', 2: 'dgh_bn', 3: 'dgh_raw', 4: 'dgv', 8: 'wgrad'}
+NAMES = ['start', 'tables', 'staged', 'unit0', 'loop', 'exit']
+for op in ops:
+    if op.what not in ('fwd_group', 'msconv_fwd', 'bwd_scale') or (want not in op.tag and want != op.what):
+        continue
+    for _ in range(2): op(st.cuda_stream)            # warm caches
+    torch.cuda.synchronize()
+    buf.zero_(); torch.cuda.synchronize()
+    _hip.check(eng.lib.mpnn_debug_set_trace(buf.data_ptr()), 'set_trace')
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st); op(st.cuda_stream); e1.record(st); e1.synchronize()
+    _hip.check(eng.lib.mpnn_debug_set_trace(None), 'set_trace')
+    t = buf.cpu().numpy().reshape(NWG, 8)
+    rows = t[t[:, 0] != 0]
+    if not len(rows):
+        continue
+    t0 = rows[:, 0].min()
+    span = (rows[:, 5].max() - t0) / 100.0
+    print('\n%s [%s]  event %.1f us, first start -> last exit %.1f us, %d workgroups' % (op.what, op.tag, e0.elapsed_time(e1) * 1e3, span, len(rows)))
+    for kind in sorted(set(rows[:, 6])):
+        r = rows[rows[:, 6] == kind]
+        rel = (r[:, :6] - t0) / 100.0
+        units = r[:, 7]
+        print('  %-7s %4d wgs, units/wg %d..%d' % (KIND.get(int(kind), str(kind)), len(r), units.min(), units.max()))
+        for k in range(6):
+            col = rel[:, k][r[:, k] != 0]
+            if len(col):
+                print('     %-7s min %6.2f  med %6.2f  max %6.2f us' % (NAMES[k], col.min(), np.median(col), col.max()))
+        d = (r[:, 5] - r[:, 0]) / 100.0
+        print('     in-wg time (start->exit): min %.2f med %.2f max %.2f us' % (d.min(), np.median(d), d.max()))
