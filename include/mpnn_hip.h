@@ -67,6 +67,12 @@ typedef struct {
 int mpnn_pack_weights(const float *params, float *packs, const int *desc,
                       int n_desc, void *stream);
 
+/* First launch of a training step: mpnn_pack_weights plus clearing `zero_bytes` bytes at `zero`
+ * (both multiples of 16; the step's accumulators: BatchNorm statistic slots, loss sums, gradient
+ * tensor) in the same kernel -- one launch instead of a pack and two memsets. */
+int mpnn_step_begin(const float *params, float *packs, const int *desc, int n_desc,
+                    void *zero, long zero_bytes, void *stream);
+
 /* ---- multiscale conv block, forward --------------------------------------
  * One scale of MultiscaleConvMax.link (layer_types.py:181-185):
  *   out = bias + conv3x3_same(act(a)) [+ conv3x3_same(v)]

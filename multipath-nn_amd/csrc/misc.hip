@@ -8,7 +8,13 @@
 // bwd pack [9][nchB][4][Cin ][4]:  (tap, ch, gb, ci, j) <- W[8-tap][ci][ch*16+4gb+j]
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_k(const float *__restrict__ params, float *__restrict__ packs,
-                                              const int *__restrict__ desc) {
+                                              const int *__restrict__ desc, f32x4 *__restrict__ zero, long zero_vec) {
+    // mpnn_step_begin: the same launch clears the step's accumulators (statistics slots, loss, gradients)
+    if (zero) {
+        const long nb = (long)gridDim.x * gridDim.y * gridDim.z;
+        const long b = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        for (long i = b * 256 + threadIdx.x; i < zero_vec; i += nb * 256) zero[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int *d = desc + blockIdx.x * 6;
     const int src = d[0], fwd = d[1], bwd = d[2], Cin = d[3], Cout = d[4];
     const int tap = blockIdx.y;
@@ -36,7 +42,18 @@ __global__ __launch_bounds__(256) void pack_k(const float *__restrict__ params, 
 
 extern "C" int mpnn_pack_weights(const float *params, float *packs, const int *desc, int n_desc, void *stream) {
     if (n_desc <= 0) return 0;
-    hipLaunchKernelGGL(pack_k, dim3(n_desc, 9, 8), dim3(256), 0, (hipStream_t)stream, params, packs, desc);
+    hipLaunchKernelGGL(pack_k, dim3(n_desc, 9, 8), dim3(256), 0, (hipStream_t)stream, params, packs, desc,
+                       (f32x4 *)nullptr, 0L);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mpnn_step_begin(const float *params, float *packs, const int *desc, int n_desc,
+                               void *zero, long zero_bytes, void *stream) {
+    if (n_desc <= 0) return MPNN_E_ARG;
+    if (zero && (((size_t)zero & 15) || (zero_bytes & 15) || zero_bytes < 0)) return MPNN_E_ARG;
+    hipLaunchKernelGGL(pack_k, dim3(n_desc, 9, 8), dim3(256), 0, (hipStream_t)stream, params, packs, desc,
+                       (f32x4 *)zero, zero ? zero_bytes / 16 : 0L);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

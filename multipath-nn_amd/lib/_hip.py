@@ -88,6 +88,7 @@ class RouteArgs(C.Structure):
 
 _SIGS = {
     'mpnn_pack_weights': [P, P, P, C.c_int, P],
+    'mpnn_step_begin': [P, P, P, C.c_int, P, C.c_long, P],
     'mpnn_msconv_fwd': [C.POINTER(ConvFwdArgs), P],
     'mpnn_msconv_fwd_group': [C.POINTER(ConvFwdArgs), P, C.c_int, P],
     'mpnn_debug_set_trace': [P],

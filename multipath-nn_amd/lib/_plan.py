@@ -277,9 +277,18 @@ class Engine:
                 doff += 2 * b.C[i] * _hip.BN_SLOTS
         # dsum | dred | loss live in ONE byte arena so a step zeroes them with a single memset
         nd = max(doff, 1)
-        self._zarena = torch.zeros((2 * nd + 4) * 8, dtype=torch.uint8, device=dev)
-        z64 = self._zarena.view(torch.float64)
+        # ... together with the gradient tensor (and its node-statistics tail): mpnn_step_begin clears
+        # the whole arena in the launch that packs the weights.
+        zb = (2 * nd + 4) * 8
+        gb = (self.G.numel() * 4 + 15) // 16 * 16
+        self._zarena = torch.zeros(zb + gb, dtype=torch.uint8, device=dev)
+        z64 = self._zarena[:zb].view(torch.float64)
         self.dsum, self.dred, self.loss = z64[:nd], z64[nd:2 * nd], z64[2 * nd:2 * nd + 4]
+        n_g = self.G.numel()
+        self.G = self._zarena[zb:zb + n_g * 4].view(torch.float32)
+        self.node_stat = self.G[n_g - self.node_stat.numel():]
+        for p in self.trainable:
+            p.grad = self.G[p.offset:p.offset + p.size]
         self.n_bn = len(tab) // 8
         self.bn_table = torch.tensor(tab, dtype=torch.int32, device=dev)
         self.bn_decay = float(self.blocks[0].bns[0].hypers.d) if self.blocks else 0.9
@@ -300,6 +309,7 @@ class Engine:
         self.node_ops_host = ops
         self.hyp = torch.zeros(_hip.HYP_N, device=dev)
         self.hyp_host = torch.zeros(_hip.HYP_N).pin_memory()
+        self._hyp_sent = None
 
     def init_params(self, seed=None):
         """Draw every parameter from the reference's initialisation law
@@ -753,7 +763,9 @@ class Engine:
             h[_hip.HYP_KCPT] = 0.0
         else:
             h[_hip.HYP_KCPT] = float(getattr(ϕ, 'k_cpt', 0.0))
-        self.hyp.copy_(h, non_blocking=True)
+        if self._hyp_sent is None or not torch.equal(h, self._hyp_sent):
+            self.hyp.copy_(h, non_blocking=True)          # (skipped while the schedule holds them constant)
+            self._hyp_sent = h.clone()
         return n, feed.get(net.mode, net.mode.default)
 
     def _launch(self, ops, sec=0):
@@ -808,8 +820,7 @@ class Engine:
         assert not forked, 'program section ended with side streams still forked'
     def _zero(self, train):
         if train:
-            self._zarena.zero_()
-            self.G.zero_()
+            self._zarena.zero_()           # (G lives in the same arena)
         else:
             self.loss.zero_()
 
@@ -824,9 +835,15 @@ class Engine:
             self.node_stat.data_ptr(), self.hyp.data_ptr(), talr, 1.0 / (n * self.world), 1.0 / self.world,
             torch.cuda.current_stream().cuda_stream), 'talr_momentum_step')
 
+    def _begin(self, train):
+        """mpnn_step_begin: pack the weights and clear the step's accumulators in one launch."""
+        z = self._zarena if train else self.loss
+        _hip.check(self.lib.mpnn_step_begin(self.P.data_ptr(), self.packs.data_ptr(), self.pack_desc.data_ptr(),
+                                            self.n_pack, z.data_ptr(), z.numel() * z.element_size(),
+                                            torch.cuda.current_stream().cuda_stream), 'step_begin')
+
     def _phase_a(self, prog, train):
-        self._zero(train)
-        self._pack()
+        self._begin(train)
         self._launch(prog['fwd'], 0)
         if train:
             self._launch(prog['bwd'], 1)
