@@ -422,23 +422,31 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
                 }
             } else {
-#pragma unroll
-              for (int sc = 0; sc < NCH; ++sc)
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int dy = tap / 3, dx = tap - dy * 3;
-                    f32x4 a[MT], bq[NT];
+                // Software-pipelined over the NCH * 9 (chunk, tap) fragments: the LDS reads of fragment
+                // t + 1 are issued before the MFMAs of fragment t, so their latency hides under 4 * MT * NT
+                // MFMAs instead of stalling the wave once per tap.
+                f32x4 fa[2][MT], fb[2][NT];
+                auto frag = [&](int it, f32x4 *a, f32x4 *bq) {
+                    const int sc = it / 9, tap = it - sc * 9, dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bq[nt] = wl[sc * BI + (tap * 4 + g) * CT + wcol + nt * 16];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) a[mt] = cur[sc * 4 * P + g * P + slot0[mt] + dy * R + dx];
+                };
+                frag(0, fa[0], fb[0]);
+#pragma unroll
+                for (int it = 0; it < NCH * 9; ++it) {
+                    if (it + 1 < NCH * 9) frag(it + 1, fa[(it + 1) & 1], fb[(it + 1) & 1]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], bq[nt][j], acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[it & 1][mt][j], fb[it & 1][nt][j], acc[mt][nt], 0, 0, 0);
+                    // pin the order for the machine scheduler (it otherwise sinks the reads to their use)
+                    if (it + 1 < NCH * 9) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);   // DS reads of t+1
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);                        // MFMAs of t
                 }
             }
         }
