@@ -135,13 +135,30 @@ def main():
         # routed FLOPs/s = images/s x 2 x moc (scripts/train-nets:120), moc from an 'ev' pass
         net.eval({net.x0: eng.x0[:n], net.y: eng.y[:n]})
         moc = float(net.state()[(net, 'moc')].mean())
-        # dominant kernel: per-launch HIP-event timing on the launch stream
-        ops = eng.time_ops('tr', n, reps=20)
+        # dominant kernel FAMILY (one kernel symbol, or the instantiations of one template): in-situ
+        # per-launch HIP-event timing on the launch stream, whole steps run eagerly
+        ops = eng.time_step_ops('tr', n, reps=20)
+        fam = {}
+        for what, tag, fl, t in ops:
+            f = fam.setdefault(what, [0, 0.0, 0.0]); f[0] += 1; f[1] += fl; f[2] += t
         conv = [o for o in ops if o[2] > 0]
-        dom = max(conv, key=lambda o: o[3])
-        ach = dom[2] / (dom[3] * 1e-3) / 1e12
+        dom_name = max((k for k in fam if fam[k][1] > 0), key=lambda k: fam[k][2])
+        cnt, fl, t_ms = fam[dom_name]
+        ach = fl / (t_ms * 1e-3) / 1e12
+        symbol = {'fwd_group': 'fwd_group_k', 'bwd_scale': 'bwd_scale_k<GK,OT,NCH> (all instantiations)',
+                  'msconv_fwd': 'conv_k<...,EPI_FWD>'}.get(dom_name, dom_name)
         total_ms = sum(o[3] for o in ops)
         conv_fl, conv_ms = sum(o[2] for o in conv), sum(o[3] for o in conv)
+        # HBM-side traffic of the same kernel family per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # passes of THIS command, summarised by tools/summarize_pmc.py into profiles/ (bench.py cannot run
+        # the profiler around itself); null when no summary is committed.
+        traffic, traffic_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary.json')))
+            if pm.get('family') == dom_name:
+                traffic, traffic_src = pm['traffic_bytes_per_launch'], pm.get('source')
+        except Exception:
+            pass
         out = {
             'metric': 'images/sec training CIFAR-10 actor-net', 'value': value, 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
@@ -151,9 +168,9 @@ def main():
                        'global_batch': n * world, 'per_gpu_batch': n, 'parallelism': 'dp%d' % world,
                        'hip_graph': bool(eng.use_graph), 'streams': eng.n_streams if eng.multi_stream else 1},
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
-                         'frac': ach / PEAK_F32_MFMA, 'traffic': None,
-                         'kernel': '%s [%s]' % (dom[0], dom[1]), 'kernel_ms': dom[3],
-                         'kernel_flops': dom[2]},
+                         'frac': ach / PEAK_F32_MFMA, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel': symbol, 'launches_per_step': cnt,
+                         'kernel_ms': t_ms / cnt, 'kernel_flops': fl / cnt},
             'step_frac_of_mfma_roofline': value / world * F_TRAIN / 1e12 / PEAK_F32_MFMA,
             'conv_kernels': {'tflops': conv_fl / (conv_ms * 1e-3) / 1e12, 'sum_ms': conv_ms,
                              'all_launches_sum_ms': total_ms, 'n_launches': len(ops)},

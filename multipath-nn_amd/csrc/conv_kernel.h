@@ -193,6 +193,136 @@ __device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], cons
 }
 
 // ---------------------------------------------------------------------------
+// Lean staging for conv_body.  Everything about an item that does not depend on the tile (its LDS
+// slot, its halo pixel) is computed ONCE per kernel (ItemK); everything that depends on the tile
+// but not on the channel chunk (pixel index, in-bounds bit) once per TILE (TileGeo); a unit then
+// costs one multiply-add per item for its address.  (x_item recomputed all of it for every item
+// of every unit, twice: ~40% of a unit's instructions on the deep 4x4 layers.)
+// ---------------------------------------------------------------------------
+template <int GK> struct ItemK {
+    static constexpr int N = XItems<GK>::N;
+    int slot[N];            // float4 index in the LDS tile (plane included)
+    int geo[N];             // img << 16 | hy << 8 | hx  of the halo pixel
+    unsigned ok;            // bit k: item k exists
+    int q;                  // channel quad (LDS plane) of all items of this thread
+};
+template <int GK, int PS>
+__device__ __forceinline__ void item_consts(ItemK<GK> &ik, int tid) {
+    using X = XItems<GK>;
+    using G = Geom<GK>;
+    ik.ok = 0;
+    ik.q = (tid >> 3) & 3;                         // (256 k >> 3) & 3 == 0: the same for every k
+#pragma unroll
+    for (int k = 0; k < X::N; ++k) {
+        const int i = tid + k * 256;
+        const int hp = ((i >> 5) << 3) + (i & 7);
+        const bool ok = hp < X::NHP;
+        const int hq = ok ? hp : 0;
+        const int img = hq / (X::HR * X::HC);
+        const int rem = hq - img * (X::HR * X::HC);
+        const int hy = rem / X::HC, hx = rem - hy * X::HC;
+        ik.slot[k] = ik.q * PS + (img * X::HR + hy) * G::R + hx;
+        ik.geo[k] = (img << 16) | (hy << 8) | hx;
+        ik.ok |= (ok ? 1u : 0u) << k;
+    }
+}
+template <int GK, bool SHIFTED> struct TileGeo {
+    static constexpr int N = XItems<GK>::N;
+    int pix[N];                       // (n*H + y)*W + x of the halo pixel (0 when out of range)
+    int pixs[SHIFTED ? N : 1];        // the same in the un-subsampled pyramid input (ToPyramid's pick)
+    unsigned inb;                     // bit k: pixel inside the image and the batch
+};
+template <int GK, bool SHIFTED>
+__device__ __forceinline__ void tile_geo(TileGeo<GK, SHIFTED> &tg, const ItemK<GK> &ik, const ConvP &p, int n0, int y0, int x0) {
+    tg.inb = 0;
+#pragma unroll
+    for (int k = 0; k < ItemK<GK>::N; ++k) {
+        const int n = n0 + (ik.geo[k] >> 16), y = y0 + ((ik.geo[k] >> 8) & 255) - 1, x = x0 + (ik.geo[k] & 255) - 1;
+        const bool ok = ((ik.ok >> k) & 1) && n < p.n && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        tg.pix[k] = ok ? (n * p.H + y) * p.W + x : 0;
+        if (SHIFTED) {
+            const int sh = p.a.shift;
+            tg.pixs[k] = ok ? (n * (p.H << sh) + (y << sh)) * (p.W << sh) + (x << sh) : 0;
+        }
+        tg.inb |= (ok ? 1u : 0u) << k;
+    }
+}
+// raw loads of one 16-channel chunk (branch-free, clamped addresses; see load_x)
+template <int GK, int MODE, int XW, bool SHIFTED>
+__device__ __forceinline__ void ld_items(f32x4 (*xr)[XW], const ConvP &p, const TileGeo<GK, SHIFTED> &tg, const ItemK<GK> &ik, int c0, int np) {
+    static_assert(MODE != 2 || XW >= 2, "BatchNorm-backward-on-load needs two raw registers per item");
+    const int c = c0 + ik.q * 4;
+    const bool qin = ik.q < np;
+#pragma unroll
+    for (int k = 0; k < ItemK<GK>::N; ++k) {
+        const bool live = qin && ((tg.inb >> k) & 1);
+        if (MODE == 2) {
+            const int off = live ? tg.pix[k] * p.a.C + c : 0;
+            xr[k][0] = *(const f32x4 *)(p.a.x + off);
+            xr[k][1 % XW] = *(const f32x4 *)(p.ga_s + off);
+        } else if (MODE == 0) {
+            const int C = p.a.C;
+            const int base = live ? (SHIFTED ? tg.pixs[k] : tg.pix[k]) * C : 0;
+            if ((C & 3) == 0) {                    // uniform
+                xr[k][0] = *(const f32x4 *)(p.a.x + base + (live ? c : 0));
+            } else {                               // raw image with 1 or 3 channels: clamped scalar loads
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xr[k][0][j] = p.a.x[base + (live && c + j < C ? c + j : 0)];
+            }
+        } else {
+            const int off = live ? tg.pix[k] * p.Cv + c : 0;
+            xr[k][0] = *(const f32x4 *)(p.v + off);
+        }
+    }
+}
+// transform + LDS store of one chunk; `inb` is the tile's in-bounds mask the chunk was loaded with
+template <int GK, int MODE, int XW>
+__device__ __forceinline__ void st_items(f32x4 *tile, const f32x4 (*xr)[XW], const ConvP &p, const float *cA,
+                                         unsigned inb, const ItemK<GK> &ik, int c0, int np) {
+    const int c = c0 + ik.q * 4;
+    const bool qin = ik.q < np;
+    float cc[4][5];
+    if (MODE == 2) {                               // cA rows: m, rstd, k1, r0, r1
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 5; ++e) cc[j][e] = cA[(c + j) * 5 + e];
+    } else if (MODE == 0 && p.a.mode != MPNN_ACT_IDENTITY) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) cc[j][e] = cA[(c + j) * 3 + e];
+    }
+#pragma unroll
+    for (int k = 0; k < ItemK<GK>::N; ++k) {
+        if (!((ik.ok >> k) & 1)) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (qin && ((inb >> k) & 1)) {
+            if (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xr[k][1 % XW][j] - cc[j][0]) * cc[j][1];
+                    v[j] = cc[j][2] * (xr[k][0][j] - cc[j][3] - xh * cc[j][4]);
+                }
+            } else if (MODE == 0) {
+                v = xr[k][0];
+                if (p.a.mode != MPNN_ACT_IDENTITY) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = (c + j < p.a.C) ? fmaxf((v[j] - cc[j][0]) * cc[j][1] + cc[j][2], 0.f) : 0.f;
+                } else if (p.a.C & 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (c + j < p.a.C) ? v[j] : 0.f;
+                }
+            } else {
+                v = xr[k][0];
+            }
+        }
+        tile[ik.slot[k]] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The kernel.  A workgroup is persistent over its share of the 64-pixel tiles;
 // its work is a sequence of units (tile, operand part, 16-channel chunk).  LDS
 // is double-buffered: while the MFMAs of unit u read buffer u&1, the raw global
@@ -254,52 +384,65 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     const int my_tiles = (bx < p.n_tiles) ? (p.n_tiles - 1 - bx) / gx + 1 : 0;
     const int n_units = my_tiles * upt;
 
-    // unit decode
-    auto decode = [&](int u, int &t, int &part, int &ch, int &np) {
-        const int ti = u / upt, q = u - ti * upt;
-        t = bx + ti * gx;
-        part = q * NCH >= nchA ? 1 : 0;
-        ch = part ? q * NCH - nchA : q * NCH;          // first 16-channel chunk of the unit
-        const int C = part ? p.Cv : p.a.C;
-        np = (C - ch * 16 + 3) >> 2;
-        np = np > 4 ? 4 : np;
+    // ---- staging: one unit = NCH 16-channel chunks of operand A or V plus its weight chunk ----
+    ItemK<GK> ik;
+    item_consts<GK, P>(ik, tid);
+    int wA[BN], wB[BN];                              // weight items: tap * 16 * Cout  and  (g * Cout + co) * 4
+#pragma unroll
+    for (int k = 0; k < BN; ++k) {
+        const int i0 = tid + k * 256, i = i0 < BI ? i0 : 0;          // clamped: the load is unconditional
+        const int c4 = i % CT, tg = i / CT, gg = tg & 3, tap = tg >> 2;
+        wA[k] = tap * 16 * p.Cout;
+        wB[k] = (gg * p.Cout + co0 + c4) * 4;
+    }
+    // The unit sequence is generated incrementally (no divisions): chunk, then operand part, then tile.
+    struct UI { int t, part, ch, np, n0, y0, x0; unsigned inb; };
+    TileGeo<GK, SMALL_A> tgeo;                       // geometry of the tile the generator stands on
+    UI gen = {};
+    auto set_np = [&](UI &r) {
+        const int C = r.part ? p.Cv : p.a.C;
+        r.np = (C - r.ch * 16 + 3) >> 2;           // channel quads left from this chunk on (may exceed 4)
     };
-
-    // Weight chunk (part, ch) of the k-interleaved pack -> registers -> LDS [tap][g][CT] float4.
-    // ---- staging helpers: one unit = NCH 16-channel chunks of operand A/V plus its weight chunk ----
-    struct UI { int t, part, ch, np, n0, y0, x0; };
-    auto mk = [&](int u) {
-        UI r;
-        decode(u, r.t, r.part, r.ch, r.np);
-        tile_origin<GK>(p, r.t, r.n0, r.y0, r.x0);
-        return r;
+    auto gen_tile = [&](UI &r, int t) {
+        r.t = t; r.part = 0; r.ch = 0;
+        tile_origin<GK>(p, t, r.n0, r.y0, r.x0);
+        tile_geo<GK, SMALL_A>(tgeo, ik, p, r.n0, r.y0, r.x0);
+        r.inb = tgeo.inb;
+        set_np(r);
+    };
+    auto gen_next = [&](UI &r) {
+        r.ch += NCH;
+        if (r.ch >= (r.part ? nchV : nchA)) {
+            if (!r.part && nchV) { r.part = 1; r.ch = 0; }
+            else { gen_tile(r, r.t + gx); return; }
+        }
+        set_np(r);
     };
     const bool b_once = upt == 1;                    // one unit per tile: the weights never change
+    // loads of the unit the generator stands on (its tile geometry is in tgeo)
     auto unit_load = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq, bool with_b) {
 #pragma unroll
         for (int sc = 0; sc < NCH; ++sc) {
             bool done = false;
             f32x4 (*xs)[XW] = xq + sc * XN;
-            const int c0 = (q.ch + sc) * 16;
+            const int c0 = (q.ch + sc) * 16, np = q.np - 4 * sc;
             if constexpr (EPI == EPI_FWD) {
-                if (q.part) { done = true; load_x<GK, 1, XW>(xs, p, q.n0, q.y0, q.x0, c0, q.np, tid); }
+                if (q.part) { done = true; ld_items<GK, 1, XW, SMALL_A>(xs, p, tgeo, ik, c0, np); }
             }
             if constexpr (EPI != EPI_FWD) {
-                if (p.ga_on) { done = true; load_x<GK, 2, XW>(xs, p, q.n0, q.y0, q.x0, c0, q.np, tid); }
+                if (p.ga_on) { done = true; ld_items<GK, 2, XW, SMALL_A>(xs, p, tgeo, ik, c0, np); }
             }
-            if (!done) load_x<GK, 0, XW>(xs, p, q.n0, q.y0, q.x0, c0, q.np, tid);
+            if (!done) ld_items<GK, 0, XW, SMALL_A>(xs, p, tgeo, ik, c0, np);
         }
         if (with_b) {
             const float *wp = q.part ? p.wv : p.wa;
             const int nch = q.part ? nchV : nchA;
 #pragma unroll
-            for (int sc = 0; sc < NCH; ++sc)
+            for (int sc = 0; sc < NCH; ++sc) {
+                const int uo = (q.ch + sc) * 16 * p.Cout;
 #pragma unroll
-                for (int k = 0; k < BN; ++k) {
-                    const int i0 = tid + k * 256, i = i0 < BI ? i0 : 0;          // clamped: the load is unconditional
-                    const int c4 = i % CT, tg = i / CT, gg = tg & 3, tap = tg >> 2;
-                    bq[sc * BN + k] = *(const f32x4 *)(wp + ((size_t)((tap * nch + q.ch + sc) * 4 + gg) * p.Cout + co0 + c4) * 4);
-                }
+                for (int k = 0; k < BN; ++k) bq[sc * BN + k] = *(const f32x4 *)(wp + (wA[k] * nch + uo + wB[k]));
+            }
         }
     };
     auto unit_store = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq, int buf, bool with_b) {
@@ -307,15 +450,15 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         for (int sc = 0; sc < NCH; ++sc) {
             f32x4 *td = tile[buf] + sc * 4 * P;
             f32x4 (*xs)[XW] = xq + sc * XN;
-            const int c0 = (q.ch + sc) * 16;
+            const int c0 = (q.ch + sc) * 16, np = q.np - 4 * sc;
             bool done = false;
             if constexpr (EPI == EPI_FWD) {
-                if (q.part) { done = true; store_x<GK, P, 1, XW>(td, xs, p, cA, q.n0, q.y0, q.x0, c0, q.np, tid); }
+                if (q.part) { done = true; st_items<GK, 1, XW>(td, xs, p, cA, q.inb, ik, c0, np); }
             }
             if constexpr (EPI != EPI_FWD) {
-                if (p.ga_on) { done = true; store_x<GK, P, 2, XW>(td, xs, p, cA, q.n0, q.y0, q.x0, c0, q.np, tid); }
+                if (p.ga_on) { done = true; st_items<GK, 2, XW>(td, xs, p, cA, q.inb, ik, c0, np); }
             }
-            if (!done) store_x<GK, P, 0, XW>(td, xs, p, cA, q.n0, q.y0, q.x0, c0, q.np, tid);
+            if (!done) st_items<GK, 0, XW>(td, xs, p, cA, q.inb, ik, c0, np);
         }
         if (with_b) {
             f32x4 *dst = wtile[b_once ? 0 : buf];
@@ -379,11 +522,13 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     __syncthreads();
     trace_stamp(1);
     if (n_units > 0) {
-        cu = mk(0);
+        gen_tile(gen, bx);
+        cu = gen;
         unit_load(cu, xrA, brA, true);
     }
     if (n_units > 1) {
-        n1 = mk(1);
+        gen_next(gen);
+        n1 = gen;
         unit_load(n1, xrB, brB, !b_once);
     }
     if (n_units > 0) unit_store(cu, xrA, brA, 0, true);
@@ -397,7 +542,8 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         const int part = cu.part, t = cu.t, n0 = cu.n0, y0 = cu.y0, x0 = cu.x0;
         const int t2 = n1.t;
         if (more2 && !(p.dbg & 2)) {
-            n2 = mk(u + 2);
+            gen_next(gen);
+            n2 = gen;
             unit_load(n2, xn2, bn2, !b_once);
         }
         // ----------------------------- MFMAs of unit u -----------------------------

@@ -900,6 +900,28 @@ class Engine:
                 self.allreduce(self.G)
             gb.replay()
 
+    def time_step_ops(self, mode, n, reps=10):
+        """In-situ per-launch timing: whole steps run eagerly (no graph), every launch bracketed by
+        HIP events on the launch stream, so each kernel sees the cache state and predecessors it has in
+        a real step.  Returns [(what, tag, flops, mean_ms)] in launch order."""
+        prog = self.program(mode, n)
+        train = mode == 'tr'
+        ops = [o for o in list(prog['fwd']) + (list(prog['bwd']) if train else []) if o.what not in ('fork', 'join')]
+        st = torch.cuda.current_stream()
+        tot = [0.0] * len(ops)
+        for rep in range(reps + 1):
+            self._begin(train)
+            evs = []
+            for op in ops:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st); op(st.cuda_stream); e1.record(st)
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            if rep:                               # first pass warms code objects
+                for k, (e0, e1) in enumerate(evs):
+                    tot[k] += e0.elapsed_time(e1)
+        return [(op.what, op.tag, op.flops, t / reps) for op, t in zip(ops, tot)]
+
     def time_ops(self, mode, n, reps=20):
         """Per-launch timing with HIP events on the launch stream (torch's current
         stream is the stream every kernel of the plan is launched on).  Returns
