@@ -247,32 +247,42 @@ __device__ __forceinline__ void tile_geo(TileGeo<GK, SHIFTED> &tg, const ItemK<G
         tg.inb |= (ok ? 1u : 0u) << k;
     }
 }
-// raw loads of one 16-channel chunk (branch-free, clamped addresses; see load_x)
-template <int GK, int MODE, int XW, bool SHIFTED>
-__device__ __forceinline__ void ld_items(f32x4 (*xr)[XW], const ConvP &p, const TileGeo<GK, SHIFTED> &tg, const ItemK<GK> &ik, int c0, int np) {
-    static_assert(MODE != 2 || XW >= 2, "BatchNorm-backward-on-load needs two raw registers per item");
+// Raw loads of one 16-channel chunk.  NO control flow around the loads and the same number of loads
+// whatever the operand: the compiler can then count them and wait with vmcnt(N > 0) for an OLDER
+// unit while this one stays in flight (behind a branch it falls back to vmcnt(0), which drains the
+// prefetch that was just issued: the waves sat in s_waitcnt 60% of the time).
+//   KIND 0: forward, operand A or V selected by `part` (pointer/stride select, one load per item)
+//   KIND 1: forward, 1- or 3-channel pyramid image as operand A (scalar loads) / V (vector)
+//   KIND 2: dgrad: dz and, when BatchNorm-backward is applied on load, s
+template <int GK, int KIND, int XW, bool SHIFTED>
+__device__ __forceinline__ void ld_items(f32x4 (*xr)[XW], const ConvP &p, const TileGeo<GK, SHIFTED> &tg, const ItemK<GK> &ik,
+                                         int part, int c0, int np) {
+    static_assert(KIND != 2 || XW >= 2, "dgrad staging keeps two raw registers per item");
     const int c = c0 + ik.q * 4;
     const bool qin = ik.q < np;
+    if (KIND == 1 && part == 0) {                  // (block 0 only)
+        const int C = p.a.C;
 #pragma unroll
-    for (int k = 0; k < ItemK<GK>::N; ++k) {
-        const bool live = qin && ((tg.inb >> k) & 1);
-        if (MODE == 2) {
-            const int off = live ? tg.pix[k] * p.a.C + c : 0;
-            xr[k][0] = *(const f32x4 *)(p.a.x + off);
-            xr[k][1 % XW] = *(const f32x4 *)(p.ga_s + off);
-        } else if (MODE == 0) {
-            const int C = p.a.C;
+        for (int k = 0; k < ItemK<GK>::N; ++k) {
+            const bool live = qin && ((tg.inb >> k) & 1);
             const int base = live ? (SHIFTED ? tg.pixs[k] : tg.pix[k]) * C : 0;
-            if ((C & 3) == 0) {                    // uniform
-                xr[k][0] = *(const f32x4 *)(p.a.x + base + (live ? c : 0));
-            } else {                               // raw image with 1 or 3 channels: clamped scalar loads
+            if ((C & 3) == 0) xr[k][0] = *(const f32x4 *)(p.a.x + base + (live ? c : 0));
+            else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xr[k][0][j] = p.a.x[base + (live && c + j < C ? c + j : 0)];
             }
-        } else {
-            const int off = live ? tg.pix[k] * p.Cv + c : 0;
-            xr[k][0] = *(const f32x4 *)(p.v + off);
         }
+        return;
+    }
+    const float *src = (KIND != 2 && part) ? p.v : p.a.x;
+    const float *src2 = p.ga_s;
+    const int C = (KIND != 2 && part) ? p.Cv : p.a.C;
+#pragma unroll
+    for (int k = 0; k < ItemK<GK>::N; ++k) {
+        const bool live = qin && ((tg.inb >> k) & 1);
+        const int off = live ? tg.pix[k] * C + c : 0;
+        xr[k][0] = *(const f32x4 *)(src + off);
+        if (KIND == 2 && p.ga_on) xr[k][1 % XW] = *(const f32x4 *)(src2 + off);      // (uniform)
     }
 }
 // transform + LDS store of one chunk; `inb` is the tile's in-bounds mask the chunk was loaded with
@@ -419,30 +429,20 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         set_np(r);
     };
     const bool b_once = upt == 1;                    // one unit per tile: the weights never change
-    // loads of the unit the generator stands on (its tile geometry is in tgeo)
-    auto unit_load = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq, bool with_b) {
+    // loads of the unit the generator stands on (its tile geometry is in tgeo); unconditional: a unit
+    // past the end has every item out of range (clamped addresses) and is never stored
+    constexpr int LK = EPI != EPI_FWD ? 2 : (SMALL_A ? 1 : 0);
+    auto unit_load = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq) {
+#pragma unroll
+        for (int sc = 0; sc < NCH; ++sc)
+            ld_items<GK, LK, XW, SMALL_A>(xq + sc * XN, p, tgeo, ik, q.part, (q.ch + sc) * 16, q.np - 4 * sc);
+        const float *wp = q.part ? p.wv : p.wa;
+        const int nch = q.part ? nchV : nchA;
 #pragma unroll
         for (int sc = 0; sc < NCH; ++sc) {
-            bool done = false;
-            f32x4 (*xs)[XW] = xq + sc * XN;
-            const int c0 = (q.ch + sc) * 16, np = q.np - 4 * sc;
-            if constexpr (EPI == EPI_FWD) {
-                if (q.part) { done = true; ld_items<GK, 1, XW, SMALL_A>(xs, p, tgeo, ik, c0, np); }
-            }
-            if constexpr (EPI != EPI_FWD) {
-                if (p.ga_on) { done = true; ld_items<GK, 2, XW, SMALL_A>(xs, p, tgeo, ik, c0, np); }
-            }
-            if (!done) ld_items<GK, 0, XW, SMALL_A>(xs, p, tgeo, ik, c0, np);
-        }
-        if (with_b) {
-            const float *wp = q.part ? p.wv : p.wa;
-            const int nch = q.part ? nchV : nchA;
+            const int uo = (q.ch + sc) * 16 * p.Cout;
 #pragma unroll
-            for (int sc = 0; sc < NCH; ++sc) {
-                const int uo = (q.ch + sc) * 16 * p.Cout;
-#pragma unroll
-                for (int k = 0; k < BN; ++k) bq[sc * BN + k] = *(const f32x4 *)(wp + (wA[k] * nch + uo + wB[k]));
-            }
+            for (int k = 0; k < BN; ++k) bq[sc * BN + k] = *(const f32x4 *)(wp + (wA[k] * nch + uo + wB[k]));
         }
     };
     auto unit_store = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq, int buf, bool with_b) {
@@ -521,16 +521,12 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     }
     __syncthreads();
     trace_stamp(1);
-    if (n_units > 0) {
-        gen_tile(gen, bx);
-        cu = gen;
-        unit_load(cu, xrA, brA, true);
-    }
-    if (n_units > 1) {
-        gen_next(gen);
-        n1 = gen;
-        unit_load(n1, xrB, brB, !b_once);
-    }
+    gen_tile(gen, bx);
+    cu = gen;
+    unit_load(cu, xrA, brA);
+    gen_next(gen);
+    n1 = gen;
+    unit_load(n1, xrB, brB);
     if (n_units > 0) unit_store(cu, xrA, brA, 0, true);
     __syncthreads();
     trace_stamp(2);
@@ -541,10 +537,10 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         const bool more = u + 1 < n_units, more2 = u + 2 < n_units;
         const int part = cu.part, t = cu.t, n0 = cu.n0, y0 = cu.y0, x0 = cu.x0;
         const int t2 = n1.t;
-        if (more2 && !(p.dbg & 2)) {
+        if (more2) {       // (unconditional loads past the end were measured slower: short workgroups doubled their loads)
             gen_next(gen);
             n2 = gen;
-            unit_load(n2, xn2, bn2, !b_once);
+            unit_load(n2, xn2, bn2);
         }
         // ----------------------------- MFMAs of unit u -----------------------------
         if (!(p.dbg & 1)) {
@@ -597,6 +593,10 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             }
         }
         mfma_drain();
+        // ----------------------------- stage unit u+1 ------------------------------
+        // BEFORE the epilogue: its wait then covers exactly the loads of unit u+2 issued above
+        // (vmcnt(N)); behind the epilogue's conditional global stores the count would be unknown.
+        if (more && !(p.dbg & 2)) unit_store(n1, xn1, bn1, (u + 1) & 1, !b_once);
         // ----------------------------- epilogue of a finished tile -----------------
         // D layout: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel of the M-tile).
         if ((!more || t2 != t) && !(p.dbg & 4)) {
@@ -676,8 +676,6 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // ----------------------------- stage unit u+1, advance ----------------------
-        if (more && !(p.dbg & 2)) unit_store(n1, xn1, bn1, (u + 1) & 1, !b_once);
         cu = n1; n1 = n2;
         lds_barrier();              // LDS-only: the prefetch loads of unit u+2 stay in flight
     };
