@@ -199,6 +199,13 @@ __device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], cons
 // costs one multiply-add per item for its address.  (x_item recomputed all of it for every item
 // of every unit, twice: ~40% of a unit's instructions on the deep 4x4 layers.)
 // ---------------------------------------------------------------------------
+// Branch- and table-free selects on a 0/1 flag (hipcc turned `flag ? x : y` on loop-varying uniform
+// flags into a lookup table in SCRATCH memory, i.e. a memory load per use inside the pipeline).
+__device__ __forceinline__ int sel_i(int flag, int a, int b) { const int m = -flag; return (a & ~m) | (b & m); }
+__device__ __forceinline__ const float *sel_p(int flag, const float *a, const float *b) {
+    const unsigned long long m = 0ull - (unsigned long long)flag;
+    return (const float *)(((unsigned long long)a & ~m) | ((unsigned long long)b & m));
+}
 template <int GK> struct ItemK {
     static constexpr int N = XItems<GK>::N;
     int slot[N];            // float4 index in the LDS tile (plane included)
@@ -256,12 +263,11 @@ __device__ __forceinline__ void tile_geo(TileGeo<GK, SHIFTED> &tg, const ItemK<G
 //   KIND 2: dgrad: dz and, when BatchNorm-backward is applied on load, s
 template <int GK, int KIND, int XW, bool SHIFTED>
 __device__ __forceinline__ void ld_items(f32x4 (*xr)[XW], const ConvP &p, const TileGeo<GK, SHIFTED> &tg, const ItemK<GK> &ik,
-                                         int part, int c0, int np) {
+                                         int part, int c0, int np, const float *src, int C) {
     static_assert(KIND != 2 || XW >= 2, "dgrad staging keeps two raw registers per item");
     const int c = c0 + ik.q * 4;
     const bool qin = ik.q < np;
     if (KIND == 1 && part == 0) {                  // (block 0 only)
-        const int C = p.a.C;
 #pragma unroll
         for (int k = 0; k < ItemK<GK>::N; ++k) {
             const bool live = qin && ((tg.inb >> k) & 1);
@@ -274,9 +280,7 @@ __device__ __forceinline__ void ld_items(f32x4 (*xr)[XW], const ConvP &p, const 
         }
         return;
     }
-    const float *src = (KIND != 2 && part) ? p.v : p.a.x;
     const float *src2 = p.ga_s;
-    const int C = (KIND != 2 && part) ? p.Cv : p.a.C;
 #pragma unroll
     for (int k = 0; k < ItemK<GK>::N; ++k) {
         const bool live = qin && ((tg.inb >> k) & 1);
@@ -397,20 +401,20 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     // ---- staging: one unit = NCH 16-channel chunks of operand A or V plus its weight chunk ----
     ItemK<GK> ik;
     item_consts<GK, P>(ik, tid);
-    int wA[BN], wB[BN];                              // weight items: tap * 16 * Cout  and  (g * Cout + co) * 4
-#pragma unroll
-    for (int k = 0; k < BN; ++k) {
+    // weight item k of this thread: element offset  tap * 16 * Cout * nch + (g * Cout + co) * 4  (+ chunk)
+    auto w_off = [&](int k, int nch) {
         const int i0 = tid + k * 256, i = i0 < BI ? i0 : 0;          // clamped: the load is unconditional
         const int c4 = i % CT, tg = i / CT, gg = tg & 3, tap = tg >> 2;
-        wA[k] = tap * 16 * p.Cout;
-        wB[k] = (gg * p.Cout + co0 + c4) * 4;
-    }
+        return tap * 16 * p.Cout * nch + (gg * p.Cout + co0 + c4) * 4;
+    };
     // The unit sequence is generated incrementally (no divisions): chunk, then operand part, then tile.
     struct UI { int t, part, ch, np, n0, y0, x0; unsigned inb; };
     TileGeo<GK, SMALL_A> tgeo;                       // geometry of the tile the generator stands on
     UI gen = {};
+    const int aC = p.a.C, vC = p.Cv;
+    const float *const aX = p.a.x, *const vX = p.v, *const wAp = p.wa, *const wVp = p.wv;
     auto set_np = [&](UI &r) {
-        const int C = r.part ? p.Cv : p.a.C;
+        const int C = sel_i(r.part, aC, vC);
         r.np = (C - r.ch * 16 + 3) >> 2;           // channel quads left from this chunk on (may exceed 4)
     };
     auto gen_tile = [&](UI &r, int t) {
@@ -422,7 +426,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     };
     auto gen_next = [&](UI &r) {
         r.ch += NCH;
-        if (r.ch >= (r.part ? nchV : nchA)) {
+        if (r.ch >= sel_i(r.part, nchA, nchV)) {
             if (!r.part && nchV) { r.part = 1; r.ch = 0; }
             else { gen_tile(r, r.t + gx); return; }
         }
@@ -433,16 +437,18 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     // past the end has every item out of range (clamped addresses) and is never stored
     constexpr int LK = EPI != EPI_FWD ? 2 : (SMALL_A ? 1 : 0);
     auto unit_load = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq) {
+        // (operand selects on LOCALS: a select between two fields of the by-value kernel argument
+        // was compiled to a scratch-memory table indexed by `part`)
+        const float *src = sel_p(q.part, aX, vX), *wp = sel_p(q.part, wAp, wVp);
+        const int C = sel_i(q.part, aC, vC), nch = sel_i(q.part, nchA, nchV);
 #pragma unroll
         for (int sc = 0; sc < NCH; ++sc)
-            ld_items<GK, LK, XW, SMALL_A>(xq + sc * XN, p, tgeo, ik, q.part, (q.ch + sc) * 16, q.np - 4 * sc);
-        const float *wp = q.part ? p.wv : p.wa;
-        const int nch = q.part ? nchV : nchA;
+            ld_items<GK, LK, XW, SMALL_A>(xq + sc * XN, p, tgeo, ik, q.part, (q.ch + sc) * 16, q.np - 4 * sc, src, C);
 #pragma unroll
         for (int sc = 0; sc < NCH; ++sc) {
             const int uo = (q.ch + sc) * 16 * p.Cout;
 #pragma unroll
-            for (int k = 0; k < BN; ++k) bq[sc * BN + k] = *(const f32x4 *)(wp + (wA[k] * nch + uo + wB[k]));
+            for (int k = 0; k < BN; ++k) bq[sc * BN + k] = *(const f32x4 *)(wp + (w_off(k, nch) + uo));
         }
     };
     auto unit_store = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq, int buf, bool with_b) {

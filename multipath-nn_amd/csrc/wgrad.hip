@@ -21,6 +21,10 @@
 // forward conv but with plane stride == 1 mod 8 slots so that the 16 channels x
 // 2 pixel groups of a ds_read_b32 wave-half fall on 32 distinct banks; the g
 // tile as [64 pixels][OT*16 + 4].
+#include <type_traits>
+#ifndef MPNN_WG_SETS
+#define MPNN_WG_SETS 1
+#endif
 #include "conv_kernel.h"
 
 struct WgP {
@@ -49,10 +53,8 @@ __device__ __forceinline__ void load_g(f32x4 *gr, f32x4 *gs, const WgP &p, int n
         // unconditional loads from a clamped address (no branch -> no vmcnt wait between items)
         const bool live = n < p.c.n;
         const size_t off = live ? (((size_t)n * p.c.H + y0 + ty) * p.c.W + x0 + tx) * p.c.Cout + co0 + q * 4 : 0;
-        f32x4 v = *(const f32x4 *)(p.g + off);
-        f32x4 sv = p.g_on ? *(const f32x4 *)(p.g_s + off) : v;
-        if (!live) { v = f32x4{0.f, 0.f, 0.f, 0.f}; sv = v; }
-        gr[k] = v; gs[k] = sv;
+        gr[k] = *(const f32x4 *)(p.g + off);          // raw: out-of-range images are zeroed when stored
+        if (p.g_on) gs[k] = *(const f32x4 *)(p.g_s + off);    // (uniform)
     }
 }
 
@@ -118,27 +120,36 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
 
     __syncthreads();
     trace_stamp(1);
-    f32x4 xr[XN][1], gr[OT], gs[OT];
-    int t = bx;
-    int n0, y0, x0, cn0 = 0, cy0 = 0, cx0 = 0;
-    if (t < p.n_tiles) {
-        tile_origin<GK>(c, t, n0, y0, x0);
-        load_x<GK, PART, 1>(xr, c, n0, y0, x0, ch * 16, np, tid);
-        load_g<GK, OT>(gr, gs, p, n0, y0, x0, co0, tid);
-        cn0 = n0; cy0 = y0; cx0 = x0;
-    }
-    for (; t < p.n_tiles; t += gx) {
+    // Two register sets, prefetch distance two tiles: while tile t is in LDS under the MFMAs, tile
+    // t + gx is landed / landing in the other set and tile t + 2 gx is requested into the set that was
+    // just written to LDS.  (With one set the loop waited a full memory round trip per tile.)
+    // (64-channel groups, OT > 1, keep one set: two would not fit the register file.)
+    constexpr int NS = MPNN_WG_SETS;                 // register sets = prefetch distance in tiles
+    f32x4 xrS[NS][XN][1], grS[NS][OT], gsS[NS][OT];
+    int on0[NS], oy0[NS], ox0[NS];
+    auto request = [&](auto sel, int t) {
+        constexpr int S = decltype(sel)::value;
+        tile_origin<GK>(c, t, on0[S], oy0[S], ox0[S]);
+        load_x<GK, PART, 1>(xrS[S], c, on0[S], oy0[S], ox0[S], ch * 16, np, tid);
+        load_g<GK, OT>(grS[S], gsS[S], p, on0[S], oy0[S], ox0[S], co0, tid);
+    };
+    auto tile_step = [&](auto sel, int t) {
+        constexpr int S = decltype(sel)::value;
+        f32x4 (*xr)[1] = xrS[S];
+        f32x4 *gr = grS[S], *gs = gsS[S];
+        const int o_n0 = on0[S];
         lds_barrier();                                 // previous tile's LDS reads are done
-        store_x<GK, PS, PART, 1>(tile, xr, c, cA, cn0, cy0, cx0, ch * 16, np, tid);
+        store_x<GK, PS, PART, 1>(tile, xr, c, cA, on0[S], oy0[S], ox0[S], ch * 16, np, tid);
 #pragma unroll
         for (int k = 0; k < OT; ++k) {
             const int i = tid + k * 256;
-            f32x4 v = gr[k];
-            if (p.g_on) {
-                const int q = i % (OT * 4), pi = i / (OT * 4);
-                int img, ty, tx;
-                mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
-                if (cn0 + img < c.n) {                 // (out-of-range images stay exactly zero)
+            const int q = i % (OT * 4), pi = i / (OT * 4);
+            int img, ty, tx;
+            mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (o_n0 + img < c.n) {                    // (out-of-range images stay exactly zero)
+                v = gr[k];
+                if (p.g_on) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float *e = cG + (q * 4 + j) * 5;
@@ -147,17 +158,11 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
                     }
                 }
             }
-            *(f32x4 *)(gt + (i / (OT * 4)) * GS + (i % (OT * 4)) * 4) = v;
+            *(f32x4 *)(gt + pi * GS + q * 4) = v;
         }
         lds_barrier();
         if (t == bx) trace_stamp(2);
-        const int tn = t + gx;
-        if (tn < p.n_tiles) {                          // next tile's loads fly under the MFMAs
-            tile_origin<GK>(c, tn, n0, y0, x0);
-            load_x<GK, PART, 1>(xr, c, n0, y0, x0, ch * 16, np, tid);
-            load_g<GK, OT>(gr, gs, p, n0, y0, x0, co0, tid);
-            cn0 = n0; cy0 = y0; cx0 = x0;
-        }
+        if (t + NS * gx < p.n_tiles) request(sel, t + NS * gx);      // flies under NS tiles of MFMAs
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             float bq[4][OT], aq[4][3];
@@ -180,6 +185,14 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
                     for (int nt = 0; nt < OT; ++nt)
                         acc[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j][ti], bq[j][nt], acc[ti][nt], 0, 0, 0);
         }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, NS - 1>;
+    if (bx < p.n_tiles) request(S0{}, bx);
+    if (NS == 2 && bx + gx < p.n_tiles) request(S1{}, bx + gx);
+    for (int t = bx; t < p.n_tiles; t += NS * gx) {
+        tile_step(S0{}, t);
+        if (NS == 2 && t + gx < p.n_tiles) tile_step(S1{}, t + gx);
     }
 
     trace_stamp(4);
@@ -232,8 +245,11 @@ struct BwdScaleP {
     int gyh, gyv, gxh, gxv, gxw, nchw;           // nchw = channel chunks (A + V) of the wgrad
 };
 
+#ifndef MPNN_OCC_BWD
+#define MPNN_OCC_BWD 3       // waves per SIMD asked of the narrow backward kernel (4 = 128 VGPRs spilled 26-42 registers)
+#endif
 template <int GK, int OT, int NCH>
-__global__ __launch_bounds__(256, (OT == 1 && NCH == 1 ? MPNN_OCC : 2)) void bwd_scale_k(const BwdScaleP q) {
+__global__ __launch_bounds__(256, (OT == 1 && NCH == 1 ? MPNN_OCC_BWD : 2)) void bwd_scale_k(const BwdScaleP q) {
     constexpr int CB = ConvSmem<GK, 4, 16, NCH>::BYTES;
     constexpr int GS = OT * 16 + 4;
     constexpr int WB = 4 * WGeom<GK>::PS * 16 + 64 * GS * 4 + (128 * 3 + OT * 16 * 5) * 4;
