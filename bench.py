@@ -143,7 +143,8 @@ def main():
             f = fam.setdefault(what, [0, 0.0, 0.0]); f[0] += 1; f[1] += fl; f[2] += t
         conv = [o for o in ops if o[2] > 0]
         dom_name = max((k for k in fam if fam[k][1] > 0), key=lambda k: fam[k][2])
-        cnt, fl, t_ms = fam[dom_name]
+        # the family's mean launch duration: one event pair around its run of consecutive launches
+        cnt, fl, t_ms = eng.time_family_blocks('tr', n, reps=20)[dom_name]
         ach = fl / (t_ms * 1e-3) / 1e12
         symbol = {'fwd_group': 'fwd_group_k', 'bwd_scale': 'bwd_scale_k<GK,OT,NCH> (all instantiations)',
                   'msconv_fwd': 'conv_k<...,EPI_FWD>'}.get(dom_name, dom_name)

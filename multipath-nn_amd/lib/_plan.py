@@ -922,6 +922,40 @@ class Engine:
                     tot[k] += e0.elapsed_time(e1)
         return [(op.what, op.tag, op.flops, t / reps) for op, t in zip(ops, tot)]
 
+    def time_family_blocks(self, mode, n, reps=10):
+        """In-situ timing of each maximal run of consecutive launches of one kind (e.g. the 20
+        bwd_scale launches of a step) with ONE HIP-event pair around the run: the launches queue
+        back to back on the stream, so run time / launches is the mean kernel duration as a profiler
+        sees it (per-launch event pairs add the host's launch latency to every kernel).
+        Returns {what: (launches, flops, mean_ms_per_step)}."""
+        prog = self.program(mode, n)
+        train = mode == 'tr'
+        ops = [o for o in list(prog['fwd']) + (list(prog['bwd']) if train else []) if o.what not in ('fork', 'join')]
+        runs = []
+        for op in ops:
+            if runs and runs[-1][0] == op.what:
+                runs[-1][1].append(op)
+            else:
+                runs.append((op.what, [op]))
+        st = torch.cuda.current_stream()
+        acc = {}
+        for rep in range(reps + 1):
+            self._begin(train)
+            evs = []
+            for what, group in runs:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                for op in group:
+                    op(st.cuda_stream)
+                e1.record(st)
+                evs.append((what, group, e0, e1))
+            torch.cuda.synchronize()
+            if rep:
+                for what, group, e0, e1 in evs:
+                    a = acc.setdefault(what, [0, 0.0, 0.0])
+                    a[0] += len(group); a[1] += sum(o.flops for o in group); a[2] += e0.elapsed_time(e1)
+        return {k: (v[0] // reps, v[1] / reps, v[2] / reps) for k, v in acc.items()}
+
     def time_ops(self, mode, n, reps=20):
         """Per-launch timing with HIP events on the launch stream (torch's current
         stream is the stream every kernel of the plan is launched on).  Returns
