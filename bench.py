@@ -160,6 +160,28 @@ def main():
                 traffic, traffic_src = pm['traffic_bytes_per_launch'], pm.get('source')
         except Exception:
             pass
+        # launch floor: the same number of launches as a training step, each the smallest kernel of the
+        # library (a 1-item slab reduction), captured and replayed as one hipGraph
+        n_launch = len(ops) + 2                                   # + step_begin + optimizer
+        tab = torch.tensor([0, 0, 4, 1, 4, 0], dtype=torch.int32, device=dev)
+        buf = torch.zeros(64, device=dev)
+        st = torch.cuda.current_stream()
+        tiny = lambda: eng.lib.mpnn_slab_reduce(buf.data_ptr(), buf[32:].data_ptr(), tab.data_ptr(), 1, st.cuda_stream)
+        tiny(); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st = torch.cuda.current_stream()
+            for _ in range(n_launch):
+                tiny()
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            g.replay()
+        torch.cuda.synchronize()
+        floor_us = (time.perf_counter() - t1) / 50 * 1e6
+
         out = {
             'metric': 'images/sec training CIFAR-10 actor-net', 'value': value, 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
@@ -176,6 +198,8 @@ def main():
             'conv_kernels': {'tflops': conv_fl / (conv_ms * 1e-3) / 1e12, 'sum_ms': conv_ms,
                              'all_launches_sum_ms': total_ms, 'n_launches': len(ops)},
             'routed_flops_per_s': value * 2 * moc, 'moc': moc,
+            'launch_floor': {'kernels_per_step': n_launch, 'us_per_step': floor_us, 'us_per_kernel': floor_us / n_launch,
+                             'what': 'hipGraph of that many 1-workgroup kernels'},
         }
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n)

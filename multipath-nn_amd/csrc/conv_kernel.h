@@ -530,9 +530,11 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     gen_tile(gen, bx);
     cu = gen;
     unit_load(cu, xrA, brA);
-    gen_next(gen);
-    n1 = gen;
-    unit_load(n1, xrB, brB);
+    if (n_units > 1) {
+        gen_next(gen);
+        n1 = gen;
+        unit_load(n1, xrB, brB);
+    }
     if (n_units > 0) unit_store(cu, xrA, brA, 0, true);
     __syncthreads();
     trace_stamp(2);
