@@ -202,9 +202,11 @@ __device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], cons
 // Branch- and table-free selects on a 0/1 flag (hipcc turned `flag ? x : y` on loop-varying uniform
 // flags into a lookup table in SCRATCH memory, i.e. a memory load per use inside the pipeline).
 __device__ __forceinline__ int sel_i(int flag, int a, int b) { const int m = -flag; return (a & ~m) | (b & m); }
+// (pointer form: an offset from `a`, so the result stays a GLOBAL pointer -- through an integer cast
+// the compiler lost the address space and emitted flat loads, which also count against lgkmcnt and
+// made every LDS wait of the MFMA loop wait for the prefetch as well)
 __device__ __forceinline__ const float *sel_p(int flag, const float *a, const float *b) {
-    const unsigned long long m = 0ull - (unsigned long long)flag;
-    return (const float *)(((unsigned long long)a & ~m) | ((unsigned long long)b & m));
+    return a + (long)flag * (b - a);
 }
 template <int GK> struct ItemK {
     static constexpr int N = XItems<GK>::N;
@@ -309,30 +311,30 @@ __device__ __forceinline__ void st_items(f32x4 *tile, const f32x4 (*xr)[XW], con
     }
 #pragma unroll
     for (int k = 0; k < ItemK<GK>::N; ++k) {
-        if (!((ik.ok >> k) & 1)) continue;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (qin && ((inb >> k) & 1)) {
-            if (MODE == 2) {
+        // branch-free: transform whatever was loaded, then select (one exec-masked store at the end)
+        const bool live = qin && ((inb >> k) & 1);
+        f32x4 v = xr[k][0];
+        if (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xr[k][1 % XW][j] - cc[j][0]) * cc[j][1];
+                v[j] = cc[j][2] * (xr[k][0][j] - cc[j][3] - xh * cc[j][4]);
+            }
+        } else if (MODE == 0) {
+            if (p.a.mode != MPNN_ACT_IDENTITY) {       // uniform
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float xh = (xr[k][1 % XW][j] - cc[j][0]) * cc[j][1];
-                    v[j] = cc[j][2] * (xr[k][0][j] - cc[j][3] - xh * cc[j][4]);
+                    const float t = fmaxf((v[j] - cc[j][0]) * cc[j][1] + cc[j][2], 0.f);
+                    v[j] = (c + j < p.a.C) ? t : 0.f;
                 }
-            } else if (MODE == 0) {
-                v = xr[k][0];
-                if (p.a.mode != MPNN_ACT_IDENTITY) {
+            } else if (p.a.C & 3) {                    // uniform
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        v[j] = (c + j < p.a.C) ? fmaxf((v[j] - cc[j][0]) * cc[j][1] + cc[j][2], 0.f) : 0.f;
-                } else if (p.a.C & 3) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (c + j < p.a.C) ? v[j] : 0.f;
-                }
-            } else {
-                v = xr[k][0];
+                for (int j = 0; j < 4; ++j) v[j] = (c + j < p.a.C) ? v[j] : 0.f;
             }
         }
-        tile[ik.slot[k]] = v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = live ? v[j] : 0.f;
+        if ((ik.ok >> k) & 1) tile[ik.slot[k]] = v;
     }
 }
 
