@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
     float *DC = CE + a.n_leaves * RB;             // leaf delta_cor           [n_leaves][RB]
     int *ND = (int *)(DC + a.n_leaves * RB);      // node table               [NN][8]
     float *OPS = (float *)(ND + NN * 8);          // node ops                 [NN]
+    float *SM = OPS + ((NN + 3) & ~3);            // softmax(r / tau)         [n_switches*MS][RB]
+    int *ARG = (int *)(SM + a.n_switches * MS * RB);   // arg-max sink       [n_switches][RB]
+    int *SWN = ARG + a.n_switches * RB;           // sinks of each switch     [n_switches]
     {
         const int s0 = blockIdx.x * RB;
         const int rows_r = a.n_switches * MS, rows = rows_r + 2 * a.n_leaves;
@@ -55,11 +58,39 @@ __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
             RIN[i] = v;                            // RIN, CE, DC are contiguous
         }
         for (int i = threadIdx.x; i < NN * 8; i += 256) ND[i] = a.nodes[i];
+        for (int i = threadIdx.x; i < NN; i += 256) {
+            const int sw = a.nodes[i * 8 + 3];
+            if (sw >= 0) SWN[sw] = a.nodes[i * 8 + 2];
+        }
         for (int i = threadIdx.x; i < NN; i += 256) OPS[i] = a.node_ops[i];
     }
     __syncthreads();
-    if (threadIdx.x >= RB) return;
-    const int t = threadIdx.x;
+    // softmax(r / tau) and arg-max (first index on ties) of EVERY (switch, sample), by all four waves:
+    // the serial tree walks below only read them (they used to recompute them up to three times per
+    // node inside the one working wave).
+    {
+        const float inv_tau0 = 1.f / a.hyp[MPNN_HYP_TAU];
+        for (int i = threadIdx.x; i < a.n_switches * RB; i += 256) {
+            const int sw = i / RB, tt = i - sw * RB;
+            const int ns = SWN[sw];
+            const float *r = RIN + (sw * MS) * RB + tt;
+            float mx = r[0];
+            int arg = 0;
+#pragma unroll
+            for (int k = 1; k < MSK; ++k)
+                if (k < ns) { if (r[k * RB] > r[arg * RB]) arg = k; mx = fmaxf(mx, r[k * RB]); }
+            float e[MSK], den = 0.f;
+#pragma unroll
+            for (int k = 0; k < MSK; ++k) { e[k] = k < ns ? expf((r[k * RB] - mx) * inv_tau0) : 0.f; den += e[k]; }
+            const float inv = 1.f / den;
+#pragma unroll
+            for (int k = 0; k < MSK; ++k) if (k < MS) SM[(sw * MS + k) * RB + tt] = e[k] * inv;
+            ARG[sw * RB + tt] = arg;
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x / RB;             // 0: tree walks; 1: TALR node statistics; 2, 3: done
+    const int t = threadIdx.x & (RB - 1);
     const int s = blockIdx.x * RB + t;
     const bool live = s < n;
     const float inv_n = 1.f / (float)a.n_total;
@@ -72,24 +103,16 @@ __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
     const bool dyn = type != MPNN_NET_SR;
     float l_err = 0.f, l_cpt = 0.f, l_aux = 0.f;
 
-    // softmax(r / tau) and arg-max (first index on ties) of switch sw for this sample
+    // softmax / arg-max of switch sw for this sample: precomputed above
     auto soft = [&](int sw, int ns, float *sm, int &arg) {
-        const float *r = RIN + (sw * MS) * RB + t;
-        float mx = r[0];
-        arg = 0;
 #pragma unroll
-        for (int i = 1; i < MSK; ++i)
-            if (i < ns) { if (r[i * RB] > r[arg * RB]) arg = i; mx = fmaxf(mx, r[i * RB]); }
-        float den = 0.f;
-#pragma unroll
-        for (int i = 0; i < MSK; ++i) { sm[i] = i < ns ? expf((r[i * RB] - mx) * inv_tau) : 0.f; den += sm[i]; }
-        const float inv = 1.f / den;
-#pragma unroll
-        for (int i = 0; i < MSK; ++i) sm[i] *= inv;
+        for (int i = 0; i < MSK; ++i) sm[i] = (i < ns && i < MS) ? SM[(sw * MS + i) * RB + t] : 0.f;
+        arg = ARG[sw * RB + t];
     };
 
     // ---- top-down: p_tr, p_ev (DFS preorder: parents first); own cost terms ----
     float pev_par = 1.f;
+    if (wave == 0)
     for (int j = 0; j < NN; ++j) {
         const int *nd = ND + j * 8;
         const int par = nd[0], si = nd[1], leaf = nd[4];
@@ -126,13 +149,17 @@ __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
     }
     (void)pev_par;
 
-    // ---- node statistics for TALR: sum p_tr, sum p_tr^2 ----
-    if (a.node_stat) {
+    __syncthreads();                               // p_tr of every node is in LDS
+    if (wave >= 2) return;
+    // ---- node statistics for TALR: sum p_tr, sum p_tr^2 (wave 1, beside the bottom-up walk) ----
+    if (wave == 1) {
+        if (!a.node_stat) return;
         for (int j = 0; j < NN; ++j) {
             const float p = live ? P[j * RB + t] : 0.f;
             const float s1 = wave_sum_f(p), s2 = wave_sum_f(p * p);
             if (t == 0) { atomicAdd(a.node_stat + j * 2, s1); atomicAdd(a.node_stat + j * 2 + 1, s2); }
         }
+        return;
     }
 
     // ---- bottom-up (reverse preorder: children first); each node pushes into its parent ----
@@ -212,8 +239,8 @@ extern "C" int mpnn_route(const mpnn_route_args *args, void *stream) {
     if (!args || !args->nodes || !args->p_tr || !args->p_ev) return MPNN_E_ARG;
     if (args->n_nodes > MPNN_MAX_NODES || args->max_sinks > MPNN_MAX_SINKS) return MPNN_E_SHAPE;
     if (args->n <= 0) return 0;
-    const size_t lds = (size_t)(3 * args->n_nodes + args->n_switches * args->max_sinks + 2 * args->n_leaves) * RB * 4
-                       + (size_t)args->n_nodes * 9 * 4;
+    const size_t lds = (size_t)(3 * args->n_nodes + 2 * args->n_switches * args->max_sinks + args->n_switches + 2 * args->n_leaves) * RB * 4
+                       + (size_t)(args->n_nodes * 9 + 4 + args->n_switches) * 4;
     if (lds > 160 * 1024) return MPNN_E_SHAPE;
     hipLaunchKernelGGL(route_k, dim3((args->n + RB - 1) / RB), dim3(256), lds, (hipStream_t)stream, *args);
     MPNN_LAUNCH_CHECK();
