@@ -325,6 +325,17 @@ int mpnn_talr_momentum_step(float *params, float *accum, const float *grads,
                             const float *hyp, int talr, float inv_n, float grad_scale,
                             void *stream);
 
+/* ---- training-batch assembly (scripts/lib/data.py:10-34) -------------------
+ * x_out[i] = rand_shift(rand_flip(x_src[j_i])), y_out[i] = y_src[j_i] for a dataset resident in
+ * device memory ([N,H,W,C] and [N,n_cls] fp32, C <= 4).  `draw` is a device array [n][4] of ints
+ * (j, flip, du, dv) drawn on the host with the reference's call sequence on numpy's global
+ * stream (randint(0, N); rand() < 0.5 for symmetric classes; randint(-r, r + 1, 2)).
+ * out[u][v] = a[u + du][v + dv] where that exists, else the image's per-channel mean (computed
+ * in fp64); flip mirrors v.  y_src / y_out may be NULL. */
+int mpnn_augment_batch(const float *x_src, const float *y_src, const int *draw,
+                       float *x_out, float *y_out, int n, int H, int W, int C, int n_cls,
+                       void *stream);
+
 /* Workgroups of the mpnn_msconv_bwd_scale kernel for an H x W x Cout scale that are resident on the
  * device at once (occupancy x compute units; needs a GPU).  The caller gives the weight-gradient
  * split (n_split x channel chunks x cout groups workgroups) about half of them, so that the dgrad

@@ -275,6 +275,60 @@ extern "C" int mpnn_compact_by_branch(const float *p_ev, int n, int *idx_out, in
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// mpnn_augment_batch: the training-batch assembly of scripts/lib/data.py:10-34 on the device.
+//   out[i][u][v][c] = a_i[u + du_i][v + dv_i]  if that pixel exists, else  mean_{u,v} a_i[u][v][c]
+//   a_i = x_src[j_i], mirrored along v when flip_i (data.py:10-11 rand_flip, :13-22 rand_shift);
+//   y_out[i] = y_src[j_i].
+// The draws (j, flip, du, dv) come from the host with the reference's RNG call sequence; the
+// dataset stays resident in HBM.  One workgroup per output image: fp64 per-channel mean through
+// LDS, then the gather.  C <= 4.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void augment_k(const float *__restrict__ x_src, const float *__restrict__ y_src,
+                                                 const int *__restrict__ draw, float *__restrict__ x_out,
+                                                 float *__restrict__ y_out, int H, int W, int C, int n_cls) {
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int j = draw[i * 4], flip = draw[i * 4 + 1], du = draw[i * 4 + 2], dv = draw[i * 4 + 3];
+    const float *a = x_src + (size_t)j * H * W * C;
+    __shared__ double part[256][4];
+    __shared__ float fill[4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int px = tid; px < H * W; px += 256)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < C) acc[c] += (double)a[(size_t)px * C + c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) part[tid][c] = acc[c];
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (tid < w)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[tid][c] += part[tid + w][c];
+        __syncthreads();
+    }
+    if (tid < 4) fill[tid] = (float)(part[0][tid] / (double)(H * W));
+    __syncthreads();
+    float *o = x_out + (size_t)i * H * W * C;
+    for (int e = tid; e < H * W * C; e += 256) {
+        const int c = e % C, px = e / C, u = px / W, v = px - u * W;
+        const int su = u + du, sv = v + dv;
+        float val = fill[c];
+        if ((unsigned)su < (unsigned)H && (unsigned)sv < (unsigned)W)
+            val = a[((size_t)su * W + (flip ? W - 1 - sv : sv)) * C + c];
+        o[e] = val;
+    }
+    if (y_src && y_out)
+        for (int k = tid; k < n_cls; k += 256) y_out[(size_t)i * n_cls + k] = y_src[(size_t)j * n_cls + k];
+}
+
+extern "C" int mpnn_augment_batch(const float *x_src, const float *y_src, const int *draw, float *x_out, float *y_out,
+                                  int n, int H, int W, int C, int n_cls, void *stream) {
+    if (n <= 0) return 0;
+    if (!x_src || !draw || !x_out || C < 1 || C > 4 || H < 1 || W < 1) return MPNN_E_ARG;
+    hipLaunchKernelGGL(augment_k, dim3(n), dim3(256), 0, (hipStream_t)stream, x_src, y_src, draw, x_out, y_out, H, W, C, n_cls);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
 int mpnn_trace_install_fwd(void *buf);
 int mpnn_trace_install_dgrad(void *buf);
 int mpnn_trace_install_wgrad(void *buf);

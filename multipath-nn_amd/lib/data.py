@@ -80,6 +80,39 @@ class Dataset:
     def augmented_training_batch(self, n=128, r_shift=4):
         return augmented_batch(self.x0_tr, self.y_tr, n, self.m_sym, r_shift)
 
+    # ---- device-resident path (mpnn_augment_batch): the dataset is uploaded once, a step costs a
+    # 2 KB upload of the draws and one gather launch; the draws are the reference's, call for call.
+    def to_device(self, device='cuda:0'):
+        import torch
+        self._dev = device
+        self._x_dev = torch.from_numpy(np.ascontiguousarray(self.x0_tr, dtype=np.float32)).to(device)
+        self._y_dev = torch.from_numpy(np.ascontiguousarray(self.y_tr, dtype=np.float32)).to(device)
+        self._draw_host = None
+        return self
+
+    def augmented_training_batch_device(self, n=128, r_shift=4, x_out=None, y_out=None):
+        """Same batch as augmented_training_batch (same numpy RNG draws), assembled on the GPU in fp32.
+        Returns (x, y) device tensors; pass x_out / y_out (e.g. the engine's input buffers) to fill them."""
+        import torch
+        from . import _hip
+        if getattr(self, '_x_dev', None) is None:
+            raise _hip.HipError('Dataset.to_device() first: the augmentation kernel gathers from device memory')
+        lib = _hip.load()
+        j, flip, sh = _draw_augmentation(n, len(self.x0_tr), self.y_tr, self.m_sym, r_shift)
+        draw = np.stack([j, flip.astype(np.int64), sh[:, 0], sh[:, 1]], 1).astype(np.int32)
+        d = torch.from_numpy(draw).to(self._dev, non_blocking=False)
+        h, w, c = self.x0_tr.shape[1:]
+        n_cls = self.y_tr.shape[1]
+        if x_out is None:
+            x_out = torch.empty((n, h, w, c), device=self._dev)
+        if y_out is None:
+            y_out = torch.empty((n, n_cls), device=self._dev)
+        _hip.check(lib.mpnn_augment_batch(self._x_dev.data_ptr(), self._y_dev.data_ptr(), d.data_ptr(),
+                                          x_out.data_ptr(), y_out.data_ptr(), n, h, w, c, n_cls,
+                                          torch.cuda.current_stream().cuda_stream), 'augment_batch')
+        self._keep = d                                  # until the stream has consumed it
+        return x_out, y_out
+
     def training_batch(self, n=128):
         return batch(self.x0_tr, self.y_tr, n)
 

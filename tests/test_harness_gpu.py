@@ -109,3 +109,32 @@ def test_train_nets_cli(tmp_path):
         assert os.path.exists(os.path.join(base, f)), f                      # scripts/train-nets:149-157
     desc = np.load(os.path.join(base, '0001-stats.npy'), allow_pickle=True)[()]
     assert desc['type'] == 'CriticNet' and 0 <= desc['stats_ts']['acc'] <= 1
+
+
+def test_device_augmentation_matches_reference_fixtures():
+    """mpnn_augment_batch (dataset resident in HBM, draws from the host with the reference's RNG
+    sequence) reproduces the batches the REFERENCE's scripts/lib/data.py produced for the same seeds
+    (tests/golden/data_aug_golden.npz, generated by importing that module): gathered pixels exactly,
+    the mean fill to fp32 rounding."""
+    import os
+    from lib import data as D
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'data_aug_golden.npz'))
+    ds = D.Dataset(arrays=dict(x0_tr=gold['x0'], y_tr=gold['y'], x0_ts=gold['x0'][:1], y_ts=gold['y'][:1],
+                               m_sym=gold['m_sym']))
+    ds.to_device('cuda:0')
+    for k in range(3):
+        seed, n, r = (int(v) for v in gold['case%d_args' % k])
+        np.random.seed(seed)
+        x, y = ds.augmented_training_batch_device(n, r)
+        torch.cuda.synchronize()
+        want_x, want_y = gold['case%d_x' % k], gold['case%d_y' % k]
+        assert np.array_equal(y.cpu().numpy(), want_y.astype(np.float32))
+        err = np.abs(x.cpu().numpy().astype(np.float64) - want_x).max()
+        assert err <= 1e-7, (k, err)
+    # and the host path on the same seed draws the same batch (same RNG consumption)
+    np.random.seed(123)
+    xh, yh = ds.augmented_training_batch(16, 2)
+    np.random.seed(123)
+    xd, yd = ds.augmented_training_batch_device(16, 2)
+    assert np.abs(xd.cpu().numpy() - xh.astype(np.float32)).max() <= 1e-7
+    assert np.array_equal(yd.cpu().numpy(), yh.astype(np.float32))
