@@ -135,6 +135,25 @@ def main():
         # routed FLOPs/s = images/s x 2 x moc (scripts/train-nets:120), moc from an 'ev' pass
         net.eval({net.x0: eng.x0[:n], net.y: eng.y[:n]})
         moc = float(net.state()[(net, 'moc')].mean())
+        # evaluation mode, forward only (moving-average BatchNorm, hard routing p_ev): dense over the batch
+        # (no compaction: at batch 128 every launch is latency-bound), routed cost from the statistic
+        ev_feed = {net.x0: eng.x0[:n], net.y: eng.y[:n]}
+        for _ in range(3):
+            net.eval(ev_feed)
+        torch.cuda.synchronize()
+        t_ev = time.perf_counter()
+        for _ in range(100):
+            net.eval(ev_feed)
+        torch.cuda.synchronize()
+        ev_ms = (time.perf_counter() - t_ev) / 100 * 1e3
+        leaves = [nd.layer for nd in eng.leaves]
+        exit_hist = [float(l.p_ev.mean()) for l in leaves]
+        depth_of = {id(b): k for k, b in enumerate(eng.blocks)}
+        blocks_run = sum(h * (k + 1) for k, h in enumerate(exit_hist))       # chain: exit k runs blocks 0..k
+        ev = {'images_per_s_forward_dense': n / (ev_ms * 1e-3), 'ms_per_batch': ev_ms,
+              'exit_histogram': exit_hist, 'skipped_block_fraction': 1.0 - blocks_run / max(1, len(eng.blocks)),
+              'routed_flops_per_s': n / (ev_ms * 1e-3) * 2 * moc, 'compaction': False}
+
         # dominant kernel FAMILY (one kernel symbol, or the instantiations of one template): in-situ
         # per-launch HIP-event timing on the launch stream, whole steps run eagerly
         ops = eng.time_step_ops('tr', n, reps=20)
@@ -197,7 +216,7 @@ def main():
             'step_frac_of_mfma_roofline': value / world * F_TRAIN / 1e12 / PEAK_F32_MFMA,
             'conv_kernels': {'tflops': conv_fl / (conv_ms * 1e-3) / 1e12, 'sum_ms': conv_ms,
                              'all_launches_sum_ms': total_ms, 'n_launches': len(ops)},
-            'routed_flops_per_s': value * 2 * moc, 'moc': moc,
+            'routed_flops_per_s': value * 2 * moc, 'moc': moc, 'eval': ev,
             'launch_floor': {'kernels_per_step': n_launch, 'us_per_step': floor_us, 'us_per_kernel': floor_us / n_launch,
                              'what': 'hipGraph of that many 1-workgroup kernels'},
         }
