@@ -27,6 +27,16 @@ static int resident_slots(const void *kernel, int dyn_lds) {
     int per_cu = 0, dev = 0, cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, (size_t)dyn_lds) != hipSuccess || per_cu < 1)
         per_cu = 2;
+    // The occupancy query was seen to allow two 82 KB workgroups on a 160 KB CU (bwd_scale_k<2,4,2>:
+    // half of the grid then started 11-23 us late): bound it by the LDS arithmetic as well.
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, kernel) == hipSuccess) {
+        const size_t lds = fa.sharedSizeBytes + (size_t)dyn_lds;
+        if (lds > 0) {
+            const int by_lds = (int)((160u * 1024u) / ((lds + 1279) / 1280 * 1280));     // 1280-byte allocation granules
+            if (by_lds >= 1 && by_lds < per_cu) per_cu = by_lds;
+        }
+    }
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;

@@ -348,7 +348,7 @@ extern "C" int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad
     const int gk = (W >= 16 && (W % 16) == 0 && (H % 4) == 0) ? 0 : (W == 8 && H == 8) ? 1 : (W == 4 && H == 4) ? 2 : -1;
     if (gk < 0 || (Cout % 16)) return MPNN_E_SHAPE;
     bool deep = gk != 0 && (Cout % 32) == 0 && has_dgrad;
-    if (nch_env == 1) deep = false;
+    if (nch_env != 2) deep = false;        // 32-channel units: opt-in (MPNN_CONV_NCH=2); their 82 KB of LDS leaves ONE workgroup per CU
     const void *k = gk == 0 ? (const void *)bwd_scale_kernel<0>(wide, deep)
                   : gk == 1 ? (const void *)bwd_scale_kernel<1>(wide, deep) : (const void *)bwd_scale_kernel<2>(wide, deep);
     return resident_slots(k, 0);
@@ -367,7 +367,7 @@ static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hip
     // 32-channel units for the dgrad bodies when g has a multiple of 32 channels on a small map
     static const int nch_env = [] { const char *e = getenv("MPNN_CONV_NCH"); return e ? atoi(e) : 0; }();
     bool deep = GK != 0 && (q.w.c.Cout % 32) == 0 && (has_h || has_v);
-    if (nch_env == 1) deep = false;
+    if (nch_env != 2) deep = false;        // 32-channel units: opt-in (MPNN_CONV_NCH=2); their 82 KB of LDS leaves ONE workgroup per CU
     void (*kern)(const BwdScaleP) = bwd_scale_kernel<GK>(wide, deep);
     // Fit the grid to what is resident at once: the weight-gradient rows keep their split x rows
     // workgroups (the slabs are sized for them), the two dgrad bodies share the rest by work.
