@@ -18,7 +18,7 @@ extern "C" int mpnn_msconv_fwd(const mpnn_conv_fwd_args *a, void *stream) {
 // Rows of the grid are dealt to the members; each member runs the body of its own geometry.
 // The members' serial latency chains overlap instead of queueing as separate launches.
 // ---------------------------------------------------------------------------
-struct FwdGroupP { int gk[4], small[4], gy[4], gx[4], y0[4]; int n; };
+struct FwdGroupP { int gk[4], small[4], gy[4], gx[4], y0[4], w0[4]; int n; };   // w0 = first linear workgroup of a member
 
 __host__ __device__ static inline int fill_fwd(const mpnn_conv_fwd_args *a, ConvP &p) {
     if (!a || !a->a.x || !a->wa_pack || !a->out || !a->bias) return MPNN_E_ARG;
@@ -37,15 +37,16 @@ __host__ __device__ static inline int fill_fwd(const mpnn_conv_fwd_args *a, Conv
 // argument array with a runtime member index makes hipcc copy the whole argument block to scratch.
 __global__ __launch_bounds__(256) void fwd_group_k(const mpnn_conv_fwd_args *__restrict__ tab, const FwdGroupP q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // sized by the host for the members present
-    const int by = blockIdx.y, bx = blockIdx.x;
-    int m = 0, y0 = 0, gx = q.gx[0], kind = q.gk[0] * 2 + q.small[0];
+    // 1-D grid with exactly the workgroups that have work (a 2-D grid padded to the widest member
+    // launches workgroups that exit at once, and they were seen to delay the residency of real ones)
+    const int id = blockIdx.x;
+    int m = 0, w0 = 0, gx = q.gx[0], kind = q.gk[0] * 2 + q.small[0];
 #pragma unroll
     for (int k = 1; k < 4; ++k)
-        if (k < q.n && by >= q.y0[k]) { m = k; y0 = q.y0[k]; gx = q.gx[k]; kind = q.gk[k] * 2 + q.small[k]; }
-    if (bx >= gx) return;
+        if (k < q.n && id >= q.w0[k]) { m = k; w0 = q.w0[k]; gx = q.gx[k]; kind = q.gk[k] * 2 + q.small[k]; }
+    const int yy = (id - w0) / gx, bx = (id - w0) - yy * gx;
     ConvP p = {};
     fill_fwd(tab + m, p);
-    const int yy = by - y0;
     switch (kind) {
         case 0: p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
         case 1: p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
@@ -99,7 +100,10 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         if (q.gx[k] > gxm) gxm = q.gx[k];
     }
     q.n = count;
-    hipLaunchKernelGGL(fwd_group_k, dim3(gxm, rows), dim3(256), lds, (hipStream_t)stream, dev_args, q);
+    int n_wg = 0;
+    for (int k = 0; k < count; ++k) { q.w0[k] = n_wg; n_wg += q.gx[k] * q.gy[k]; }
+    (void)gxm; (void)rows;
+    hipLaunchKernelGGL(fwd_group_k, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, dev_args, q);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

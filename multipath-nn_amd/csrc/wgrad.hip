@@ -254,13 +254,18 @@ __global__ __launch_bounds__(256, (OT == 1 && NCH == 1 ? MPNN_OCC_BWD : 2)) void
     constexpr int GS = OT * 16 + 4;
     constexpr int WB = 4 * WGeom<GK>::PS * 16 + 64 * GS * 4 + (128 * 3 + OT * 16 * 5) * 4;
     __shared__ __attribute__((aligned(16))) char smem[CB > WB ? CB : WB];
-    const int by = blockIdx.y, bx = blockIdx.x;
-    if (by < q.gyh) {
-        if (bx < q.gxh) conv_body<GK, 1, 1, 4, 1, false, EPI_DGH_BN, NCH>(q.h, bx, by, q.gxh, smem);
-    } else if (by < q.gyh + q.gyv) {
-        if (bx < q.gxv) conv_body<GK, 1, 1, 4, 1, false, EPI_DGV, NCH>(q.v, bx, by - q.gyh, q.gxv, smem);
-    } else if (bx < q.gxw) {
-        const int r = by - q.gyh - q.gyv;
+    // 1-D grid of exactly the workgroups that have work: [0, gyh*gxh) dgrad-horz, then gyv*gxv
+    // dgrad-vert, then the weight-gradient workgroups.  (A 2-D grid padded to the widest body launched
+    // workgroups that exit at once; with them only 384 of 512 real workgroups were ever co-resident.)
+    const int id = blockIdx.x, wh = q.gyh * q.gxh, wv = q.gyv * q.gxv;
+    if (id < wh) {
+        const int by = id / q.gxh, bx = id - by * q.gxh;
+        conv_body<GK, 1, 1, 4, 1, false, EPI_DGH_BN, NCH>(q.h, bx, by, q.gxh, smem);
+    } else if (id < wh + wv) {
+        const int l = id - wh, by = l / q.gxv, bx = l - by * q.gxv;
+        conv_body<GK, 1, 1, 4, 1, false, EPI_DGV, NCH>(q.v, bx, by, q.gxv, smem);
+    } else {
+        const int l = id - wh - wv, r = l / q.gxw, bx = l - r * q.gxw;
         const int chunk = r % q.nchw, bz = r / q.nchw;
         f32x4 *tile = (f32x4 *)smem;
         float *gt = (float *)(smem + 4 * WGeom<GK>::PS * 16);
@@ -385,10 +390,7 @@ static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hip
     };
     q.gxh = share(wh, q.gyh);
     q.gxv = share(wv, q.gyv);
-    int gx = q.gxw;
-    if (q.gxh > gx) gx = q.gxh;
-    if (q.gxv > gx) gx = q.gxv;
-    const dim3 grid(gx, q.gyh + q.gyv + gyw);
+    const dim3 grid(q.gyh * q.gxh + q.gyv * q.gxv + gyw * q.gxw);
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, q);
     MPNN_LAUNCH_CHECK();
     return 0;

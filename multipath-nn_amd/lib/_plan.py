@@ -408,7 +408,10 @@ class Engine:
             has_dgrad = 1 if (b.in_map is not None or i > 0) else 0
             slots = self.lib.mpnn_msconv_bwd_scale_slots(b.H[i], b.W[i], b.C[i], has_dgrad)
             if slots > 0:
-                budget = min(512, slots // 2 if has_dgrad else slots)
+                div = int(os.environ.get('MPNN_WSPLIT_DIV', '2'))
+                if b.C[i] % 64 == 0:
+                    div = int(os.environ.get('MPNN_WSPLIT_DIV_WIDE', str(div)))
+                budget = min(512, slots // div if has_dgrad else slots)
         want = max(1, budget // (nch * groups))
         w_bytes = 4 * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
         want = min(want, max(1, (12 << 20) // w_bytes))         # keep a layer's slab under ~12 MB

@@ -48,7 +48,11 @@ for op in ops:
         continue
     t0 = rows[:, 0].min()
     span = (rows[:, 5].max() - t0) / 100.0
-    print('\n%s [%s]  event %.1f us, first start -> last exit %.1f us, %d workgroups' % (op.what, op.tag, e0.elapsed_time(e1) * 1e3, span, len(rows)))
+    ev_t = sorted([(int(r[0]), 1) for r in rows if r[5]] + [(int(r[5]), -1) for r in rows if r[5]])
+    cur = peak = 0
+    for _, dlt in ev_t:
+        cur += dlt; peak = max(peak, cur)
+    print('\n%s [%s]  event %.1f us, first start -> last exit %.1f us, %d workgroups, peak concurrency %d' % (op.what, op.tag, e0.elapsed_time(e1) * 1e3, span, len(rows), peak))
     for kind in sorted(set(rows[:, 6])):
         r = rows[rows[:, 6] == kind]
         rel = (r[:, :6] - t0) / 100.0
