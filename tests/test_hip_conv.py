@@ -23,6 +23,7 @@ SHAPES = [
     (8, 64, 0, 64, 0), (4, 64, 64, 64, 0),                                             # L5
     (4, 64, 0, 128, 0), (4, 128, 0, 128, 0),                                           # L6, L7
     (32, 1, 0, 16, 0), (8, 1, 16, 16, 2),                                              # MNIST variant
+    (16, 32, 32, 64, 0), (32, 16, 0, 64, 0),      # beyond the shipped specs: 64-channel tiles on W >= 16 maps
 ]
 
 
