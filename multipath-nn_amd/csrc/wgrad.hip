@@ -124,7 +124,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     // t + gx is landed / landing in the other set and tile t + 2 gx is requested into the set that was
     // just written to LDS.  (With one set the loop waited a full memory round trip per tile.)
     // (64-channel groups, OT > 1, keep one set: two would not fit the register file.)
-    constexpr int NS = MPNN_WG_SETS;                 // register sets = prefetch distance in tiles
+    constexpr int NS = OT == 1 ? MPNN_WG_SETS : 1;   // register sets = prefetch distance in tiles
     f32x4 xrS[NS][XN][1], grS[NS][OT], gsS[NS][OT];
     int on0[NS], oy0[NS], ox0[NS];
     auto request = [&](auto sel, int t) {
