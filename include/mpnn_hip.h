@@ -212,6 +212,11 @@ typedef struct {
     float *dx;                           /* [n, HW*C] written, or NULL             */
     const float *k_cpt;  float alpha_cpt;  int extra_col[2];
     int n;
+    /* Optional fusion of mpnn_bn_bwd_reduce for an exit whose block has no child (its dX is the
+     * only gradient of that map): when dz_out is set (a.mode must be a BatchNorm mode), the kernel
+     * also writes dz = dX where relu(bn(x)) > 0 else 0 to dz_out [n, HW*C] and adds
+     * [sum dz, sum dz * xhat] per channel to red_out (fp64 [red_nslot][2C], caller-zeroed). */
+    float *dz_out;  double *red_out;  int red_nslot;
 } mpnn_lin_bwd_args;
 int mpnn_lin_bwd(const mpnn_lin_bwd_args *dev_table, int count, int n_max, int k_max,
                  void *stream);

@@ -106,8 +106,10 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
     const int k = blockIdx.x * 256 + tid;
     const int M0 = a.w[0] ? a.M[0] : 0, M1 = a.w[1] ? a.M[1] : 0;
     const bool bn = a.a.mode != MPNN_ACT_IDENTITY;
-    float cm = 0.f, ca = 1.f, cb = 0.f;
-    if (bn && k < K) { const BnC c = bn_coef(a.a, k % C); cm = c.m; ca = c.gamma * c.rstd; cb = c.beta; }
+    float cm = 0.f, ca = 1.f, cb = 0.f, crs = 0.f;
+    if (bn && k < K) { const BnC c = bn_coef(a.a, k % C); cm = c.m; ca = c.gamma * c.rstd; cb = c.beta; crs = c.rstd; }
+    const bool fuse_bn = a.dz_out != nullptr && bn;          // uniform: fused mpnn_bn_bwd_reduce
+    float r1 = 0.f, r2 = 0.f;                                // sum dz, sum dz * xhat of this thread's feature
     float w[32], acc[32];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
                 const int rr = rb + u;
                 if (rr >= nr) continue;            // (no `break`: the loop must stay fully unrolled)
                 float x = xv[u];
-                if (bn && k < K) x = fmaxf((x - cm) * ca + cb, 0.f);
+                const float xc = x - cm;
+                if (bn && k < K) x = fmaxf(xc * ca + cb, 0.f);
                 const f32x4 *d4 = (const f32x4 *)(dys + rr * 32);
                 float dx = 0.f;
 #pragma unroll
@@ -153,6 +156,11 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
                     for (int j = 0; j < 4; ++j) { acc[q * 4 + j] += x * d[j]; dx += d[j] * w[q * 4 + j]; }
                 }
                 if (a.dx && k < K) a.dx[(size_t)(r0 + rr) * K + k] = dx;
+                if (fuse_bn && k < K) {
+                    const float dz = x > 0.f ? dx : 0.f;
+                    a.dz_out[(size_t)(r0 + rr) * K + k] = dz;
+                    r1 += dz; r2 += dz * (xc * crs);
+                }
             }
         }
     }
@@ -180,6 +188,23 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
     if (blockIdx.x == 0 && tid < 32) {
         const int s = tid >> 4, m = tid & 15;
         if (a.w[s] && a.db[s] && m < a.M[s]) atomicAdd(a.db[s] + m, dbs);
+    }
+    // fused BatchNorm-backward reductions: feature k = pixel * C + c; the workgroup's 256 features are
+    // 256 / C pixels of all C channels (C | 256) or a 256-channel slice of one pixel
+    if (fuse_bn) {
+        __syncthreads();
+        tr[tid] = r1; tr[256 + tid] = r2;
+        __syncthreads();
+        const int k0 = blockIdx.x * 256;
+        const int span = C < 256 ? C : 256;                  // distinct channels in this workgroup
+        if (tid < span && k0 + tid < K) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int t = tid; t < 256 && k0 + t < K; t += span) { a1 += (double)tr[t]; a2 += (double)tr[256 + t]; }
+            const int c = (k0 + tid) % C;
+            double *slot = a.red_out + (size_t)((blockIdx.x + blockIdx.z * gridDim.x) % a.red_nslot) * 2 * C;
+            atomicAdd(slot + c, a1);
+            atomicAdd(slot + C + c, a2);
+        }
     }
 }
 

@@ -60,7 +60,8 @@ class LinFwdArgs(C.Structure):
 class LinBwdArgs(C.Structure):
     _fields_ = [('a', Act), ('HW', C.c_int), ('w', P * 2), ('dy', P * 2), ('M', C.c_int * 2),
                 ('dw', P * 2), ('db', P * 2), ('dx', P), ('k_cpt', P), ('alpha_cpt', C.c_float),
-                ('extra_col', C.c_int * 2), ('n', C.c_int)]
+                ('extra_col', C.c_int * 2), ('n', C.c_int),
+                ('dz_out', P), ('red_out', P), ('red_nslot', C.c_int)]
 
 
 class ExitTailArgs(C.Structure):

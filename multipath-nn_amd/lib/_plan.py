@@ -529,6 +529,13 @@ class Engine:
             lf.k_cpt = lb.k_cpt = self.k_cpt.data_ptr()
             lf.alpha_cpt = lb.alpha_cpt = float(_attr(ϕ, 'α_cpt', 0.0))
             lb.dx = b.dx.data_ptr()
+            if mode == 'tr' and b.child is None and not self.multi_stream:
+                # the exit's dX is the only gradient of this map: lin_bwd masks it and accumulates the
+                # BatchNorm-backward reductions itself (no mpnn_bn_bwd_reduce launch)
+                lb.dx = None
+                lb.dz_out = b.dzg[L1].data_ptr()
+                lb.red_out = self.dred[b.sum_off[L1]:].data_ptr()
+                lb.red_nslot = self._nslot(b, L1)
             tf.mode = act_mode
             if b.head is not None:
                 lt, ce = b.head.layer.comps[1], b.head.layer.comps[3]
@@ -610,7 +617,7 @@ class Engine:
             cp = b.conv.params
             L1 = b.L - 1
             # coarsest scale without a child block: its dy is the exit's dX alone
-            if b.child is None:
+            if b.child is None and (self.multi_stream or not b.has_exit):
                 ctx = self._bn_ctx(b, L1, n, with_red=False)
                 bwd.append(call(lib.mpnn_bn_bwd_reduce, 'bn_bwd_reduce', b.dx.data_ptr(), C.byref(ctx),
                                 b.dzg[L1].data_ptr(), self.dred[b.sum_off[L1]:].data_ptr(),
