@@ -119,6 +119,9 @@ EXPORTS = sorted(_SIGS) + ['mpnn_version']
 _lib = None
 
 
+E_SHAPE, E_ARG = -1, -2          # MPNN_E_SHAPE, MPNN_E_ARG
+
+
 class HipError(RuntimeError):
     pass
 

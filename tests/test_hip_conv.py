@@ -217,3 +217,95 @@ def test_pack_layout():
             for o in range(co):
                 refb[:, o // 16, (o % 16) // 4, :, o % 4] = wf[::-1, :, o]
             assert np.array_equal(bw[0].cpu().numpy().reshape(refb.shape), refb)
+
+
+def test_step_begin_packs_and_clears():
+    """mpnn_step_begin = mpnn_pack_weights + clearing the accumulator arena, in one launch."""
+    import ctypes as C
+    import torch
+    import hiputil as U
+    from lib import _hip
+    lib = _hip.load()
+    rng = np.random.default_rng(11)
+    ws = [rng.standard_normal((3, 3, ci, co)).astype(np.float32) for ci, co in [(3, 16), (16, 32), (32, 64)]]
+    fw, bw = U.pack_weights(ws)
+    flat = np.concatenate([w.reshape(-1) for w in ws]).astype(np.float32)
+    desc, off, poff = [], 0, 0
+    for w in ws:
+        _, _, ci, co = w.shape
+        fs, bs = U.pack_sizes(ci, co)
+        has_b = ci % 16 == 0
+        desc += [off, poff, poff + fs if has_b else -1, ci, co, 0]
+        off += w.size; poff += fs + (bs if has_b else 0)
+    params, packs = U.dev(flat), torch.zeros(poff, device=U.DEV)
+    d = U.dev(np.array(desc, np.int32), torch.int32)
+    arena = torch.full((4096 + 8,), 7.0, device=U.DEV)
+    z = arena[4:4 + 4096]                                   # 16-byte aligned interior slice
+    _hip.check(lib.mpnn_step_begin(params.data_ptr(), packs.data_ptr(), d.data_ptr(), len(ws),
+                                   z.data_ptr(), z.numel() * 4, U.stream()), 'step_begin')
+    torch.cuda.synchronize()
+    ref = torch.cat([t for pair in zip(fw, bw) for t in pair if t is not None])
+    assert torch.equal(packs, ref)
+    assert float(z.abs().max()) == 0.0 and float(arena[:4].min()) == 7.0 and float(arena[4 + 4096:].min()) == 7.0
+    # misaligned / odd sizes are refused
+    assert lib.mpnn_step_begin(params.data_ptr(), packs.data_ptr(), d.data_ptr(), len(ws),
+                               arena[1:].data_ptr(), 64, U.stream()) == _hip.E_ARG
+
+
+def test_bwd_scale_slots_query():
+    from lib import _hip
+    import torch
+    torch.zeros(1, device='cuda')
+    lib = _hip.load()
+    for H, Cc in ((4, 128), (8, 64), (16, 32), (32, 16)):
+        s = lib.mpnn_msconv_bwd_scale_slots(H, H, Cc, 1)
+        assert s >= 256 and s % 256 == 0, (H, Cc, s)          # whole workgroups per CU x 256 CUs
+    assert lib.mpnn_msconv_bwd_scale_slots(5, 5, 16, 1) == _hip.E_SHAPE
+
+
+@pytest.mark.parametrize('C_', [32, 128])
+def test_lin_bwd_fused_bn_reduce(C_):
+    """lin_bwd with dz_out/red_out set = lin_bwd followed by mpnn_bn_bwd_reduce on its dX."""
+    import ctypes as C
+    import torch
+    import hiputil as U
+    from lib import _hip
+    lib = _hip.load()
+    rng = np.random.default_rng(C_)
+    n, HW, M = 37, 16, 10
+    K = HW * C_
+    s = rng.standard_normal((n, 4, 4, C_)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, C_), rng.standard_normal(C_) * 0.3
+    bn, cnt = U.bn_dict(s, gamma, beta)
+    w = (rng.standard_normal((K, M)) / np.sqrt(K)).astype(np.float32)
+    dy = rng.standard_normal((n, M)).astype(np.float32)
+    sd, wd, dyd = U.dev(s), U.dev(w), U.dev(dy)
+
+    def run(fused):
+        a = _hip.LinBwdArgs()
+        a.a = U.bn_ctx(sd, C_, bn, cnt).bn
+        a.a.x = sd.data_ptr()
+        a.HW, a.n = HW, n
+        a.w[0], a.dy[0], a.M[0] = wd.data_ptr(), dyd.data_ptr(), M
+        dw, db = torch.zeros(K * M, device=U.DEV), torch.zeros(M, device=U.DEV)
+        a.dw[0], a.db[0] = dw.data_ptr(), db.data_ptr()
+        dx = torch.zeros(n * K, device=U.DEV)
+        dz = torch.zeros(n * K, device=U.DEV)
+        red = torch.zeros(_hip.BN_SLOTS * 2 * C_, device=U.DEV, dtype=torch.float64)
+        a.dx = dx.data_ptr()
+        if fused:
+            a.dz_out, a.red_out, a.red_nslot = dz.data_ptr(), red.data_ptr(), _hip.BN_SLOTS
+        tab = _hip.to_device_table([a], U.DEV)
+        _hip.check(lib.mpnn_lin_bwd(tab.data_ptr(), 1, n, K, U.stream()), 'lin_bwd')
+        torch.cuda.synchronize()
+        return dx.cpu().numpy(), dz.cpu().numpy(), U.unslot(red, 2 * C_), dw.cpu().numpy()
+
+    dx0, _, _, dw0 = run(False)
+    dx1, dz1, red1, dw1 = run(True)
+    assert np.array_equal(dx0, dx1)
+    close(dw1, dw0, 1e-5)
+    dz_ref, red_ref = U.bn_bwd_reduce(dx0.reshape(n, 4, 4, C_), s, bn, cnt)
+    y, _, _ = O.bn_train(s.astype(np.float64), gamma, beta)
+    safe = (np.abs(y) > 1e-4).reshape(-1)
+    assert np.abs(dz1 - dz_ref.reshape(-1))[safe].max() < 1e-6
+    close(red1, red_ref, 1e-4)
