@@ -37,8 +37,10 @@ __device__ __forceinline__ void chan_reduce(int n, float *scratch, float *out, F
 }
 
 // Batch mean / rstd of x[n][TR] (two-pass) or the moving averages.  Channels >= R are inert.
+// m_old / v_old: the moving averages, loaded by the caller at kernel start (a load here would sit in
+// the middle of the serial chain: one more memory round trip per BatchNorm before the barrier).
 __device__ void bn_stats(const float *x, int n, int R, int mode, float eps, float decay, float *m_avg,
-                         float *v_avg, float *scratch, float *mean, float *rstd) {
+                         float *v_avg, float m_old, float v_old, float *scratch, float *mean, float *rstd) {
     const int tid = threadIdx.x;
     if (mode == MPNN_ACT_BN_BATCH) {
         chan_reduce(n, scratch, mean, [&](int s, int c) { return x[s * TR + c]; });
@@ -47,13 +49,13 @@ __device__ void bn_stats(const float *x, int n, int R, int mode, float eps, floa
         chan_reduce(n, scratch, rstd, [&](int s, int c) { const float d = x[s * TR + c] - mean[c]; return d * d; });
         if (tid < R) {
             const float var = rstd[tid] / (float)n;
-            m_avg[tid] = decay * m_avg[tid] + (1.f - decay) * mean[tid];
-            v_avg[tid] = decay * v_avg[tid] + (1.f - decay) * var;
+            m_avg[tid] = decay * m_old + (1.f - decay) * mean[tid];
+            v_avg[tid] = decay * v_old + (1.f - decay) * var;
             rstd[tid] = rsqrtf(var + eps);
         }
     } else if (tid < R) {
-        mean[tid] = m_avg[tid];
-        rstd[tid] = rsqrtf(v_avg[tid] + eps);
+        mean[tid] = m_old;
+        rstd[tid] = rsqrtf(v_old + eps);
     }
     __syncthreads();
 }
@@ -86,6 +88,24 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
     __shared__ float w2s[TR * TR], w3s[TR * TS], vec[5 * TR + TS];
     __shared__ float h1s[CHUNK * TR], h2s[CHUNK * TR];
 
+    // The router's inputs and parameters are requested FIRST; the head (softmax, cross-entropy: its own
+    // loads, exp/log, stores) runs while they fly.
+    const bool has_router = a.h1 && n <= CHUNK;    // the host rejects n > CHUNK (MPNN_E_SHAPE)
+    const int R = a.R, S = a.n_sinks;
+    float m1o = 0.f, v1o = 1.f, m2o = 0.f, v2o = 1.f;
+    if (has_router) {
+        if (tid < R) { m1o = a.m1[tid]; v1o = a.v1[tid]; m2o = a.m2[tid]; v2o = a.v2[tid]; }
+        for (int i = tid; i < TR * TR; i += 256) { const int c = i / TR, j = i & (TR - 1); w2s[i] = (c < R && j < R) ? a.w2[c * R + j] : 0.f; }
+        for (int i = tid; i < TR * TS; i += 256) { const int c = i / TS, k = i & (TS - 1); w3s[i] = (c < R && k < S) ? a.w3[c * S + k] : 0.f; }
+        if (tid < TR) {
+            const bool ok = tid < R;
+            vec[tid] = ok ? a.g1[tid] : 0.f; vec[TR + tid] = ok ? a.b1[tid] : 0.f; vec[2 * TR + tid] = ok ? a.bias2[tid] : 0.f;
+            vec[3 * TR + tid] = ok ? a.g2[tid] : 0.f; vec[4 * TR + tid] = ok ? a.b2[tid] : 0.f;
+        }
+        if (tid < TS) vec[5 * TR + tid] = tid < S ? a.bias3[tid] : 0.f;
+        if (tid < 4 * TR) bnp[tid] = 0.f;
+        stage_rows(h1s, a.h1, n, R);
+    }
     if (a.z) {
         const int nc = a.n_cls;
         for (int s = tid; s < n; s += 256) {
@@ -109,21 +129,10 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
             a.d_cor[s] = ap == ay ? 1.f : 0.f;
         }
     }
-    if (!a.h1 || n > CHUNK) return;               // the host rejects n > CHUNK (MPNN_E_SHAPE)
-    const int R = a.R, S = a.n_sinks;
-    for (int i = tid; i < TR * TR; i += 256) { const int c = i / TR, j = i & (TR - 1); w2s[i] = (c < R && j < R) ? a.w2[c * R + j] : 0.f; }
-    for (int i = tid; i < TR * TS; i += 256) { const int c = i / TS, k = i & (TS - 1); w3s[i] = (c < R && k < S) ? a.w3[c * S + k] : 0.f; }
-    if (tid < TR) {
-        const bool ok = tid < R;
-        vec[tid] = ok ? a.g1[tid] : 0.f; vec[TR + tid] = ok ? a.b1[tid] : 0.f; vec[2 * TR + tid] = ok ? a.bias2[tid] : 0.f;
-        vec[3 * TR + tid] = ok ? a.g2[tid] : 0.f; vec[4 * TR + tid] = ok ? a.b2[tid] : 0.f;
-    }
-    if (tid < TS) vec[5 * TR + tid] = tid < S ? a.bias3[tid] : 0.f;
-    if (tid < 4 * TR) bnp[tid] = 0.f;
-    stage_rows(h1s, a.h1, n, R);
+    if (!has_router) return;
     __syncthreads();
 
-    bn_stats(h1s, n, R, a.mode, a.bn_eps, a.bn_decay, a.m1, a.v1, scratch, bnp, bnp + TR);
+    bn_stats(h1s, n, R, a.mode, a.bn_eps, a.bn_decay, a.m1, a.v1, m1o, v1o, scratch, bnp, bnp + TR);
     for (int s = tid; s < n; s += 256) {
         float a1[TR];
 #pragma unroll
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
         }
     }
     __syncthreads();
-    bn_stats(h2s, n, R, a.mode, a.bn_eps, a.bn_decay, a.m2, a.v2, scratch, bnp + 2 * TR, bnp + 3 * TR);
+    bn_stats(h2s, n, R, a.mode, a.bn_eps, a.bn_decay, a.m2, a.v2, m2o, v2o, scratch, bnp + 2 * TR, bnp + 3 * TR);
     for (int s = tid; s < n; s += 256) {
         float a2[TR];
 #pragma unroll
@@ -174,6 +183,27 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
     const mpnn_exit_tail_args &a = b.f;
     const int tid = threadIdx.x, n = a.n;
 
+    const int R = a.R, S = a.n_sinks;
+    __shared__ float w2s[TR * TR], w3s[TR * TS], vec[4 * TR], bnp[4 * TR];
+    __shared__ float red[4 * TR];                 // dbeta2, dgamma2, dbeta1, dgamma1
+    __shared__ float rowA[CHUNK * TR], rowB[CHUNK * TR];
+    __shared__ float h1s[CHUNK * TR], h2s[CHUNK * TR], drs[CHUNK * TS];
+    // requests of the router tail's inputs first; the head's backward (loads, exp, stores) runs meanwhile
+    const bool has_router = a.h1 && n <= CHUNK;
+    if (has_router) {
+        stage_rows(h1s, a.h1, n, R);
+        stage_rows(h2s, a.h2, n, R);
+        for (int i = tid; i < n * TS; i += 256) { const int s = i / TS, k = i & (TS - 1); drs[i] = k < S ? b.dr[(size_t)s * a.r_stride + k] : 0.f; }
+        for (int i = tid; i < TR * TR; i += 256) { const int c = i / TR, j = i & (TR - 1); w2s[i] = (c < R && j < R) ? a.w2[c * R + j] : 0.f; }
+        for (int i = tid; i < TR * TS; i += 256) { const int c = i / TS, k = i & (TS - 1); w3s[i] = (c < R && k < S) ? a.w3[c * S + k] : 0.f; }
+        if (tid < TR) {
+            const bool ok = tid < R;
+            vec[tid] = ok ? a.g1[tid] : 0.f; vec[TR + tid] = ok ? a.b1[tid] : 0.f;
+            vec[2 * TR + tid] = ok ? a.g2[tid] : 0.f; vec[3 * TR + tid] = ok ? a.b2[tid] : 0.f;
+            bnp[tid] = ok ? a.bn_save[tid] : 0.f; bnp[TR + tid] = ok ? a.bn_save[R + tid] : 0.f;
+            bnp[2 * TR + tid] = ok ? a.bn_save[2 * R + tid] : 0.f; bnp[3 * TR + tid] = ok ? a.bn_save[3 * R + tid] : 0.f;
+        }
+    }
     if (a.z && b.dz) {
         const int nc = a.n_cls;
         for (int s = tid; s < n; s += 256) {
@@ -196,25 +226,7 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
             for (int k = 0; k < TC; ++k) if (k < nc) b.dz[(size_t)s * nc + k] = p[k] * (gp[k] - dot);
         }
     }
-    if (!a.h1 || n > CHUNK) return;
-
-    const int R = a.R, S = a.n_sinks;
-    __shared__ float w2s[TR * TR], w3s[TR * TS], vec[4 * TR], bnp[4 * TR];
-    __shared__ float red[4 * TR];                 // dbeta2, dgamma2, dbeta1, dgamma1
-    __shared__ float rowA[CHUNK * TR], rowB[CHUNK * TR];
-    __shared__ float h1s[CHUNK * TR], h2s[CHUNK * TR], drs[CHUNK * TS];
-    stage_rows(h1s, a.h1, n, R);
-    stage_rows(h2s, a.h2, n, R);
-    for (int i = tid; i < n * TS; i += 256) { const int s = i / TS, k = i & (TS - 1); drs[i] = k < S ? b.dr[(size_t)s * a.r_stride + k] : 0.f; }
-    for (int i = tid; i < TR * TR; i += 256) { const int c = i / TR, j = i & (TR - 1); w2s[i] = (c < R && j < R) ? a.w2[c * R + j] : 0.f; }
-    for (int i = tid; i < TR * TS; i += 256) { const int c = i / TS, k = i & (TS - 1); w3s[i] = (c < R && k < S) ? a.w3[c * S + k] : 0.f; }
-    if (tid < TR) {
-        const bool ok = tid < R;
-        vec[tid] = ok ? a.g1[tid] : 0.f; vec[TR + tid] = ok ? a.b1[tid] : 0.f;
-        vec[2 * TR + tid] = ok ? a.g2[tid] : 0.f; vec[3 * TR + tid] = ok ? a.b2[tid] : 0.f;
-        bnp[tid] = ok ? a.bn_save[tid] : 0.f; bnp[TR + tid] = ok ? a.bn_save[R + tid] : 0.f;
-        bnp[2 * TR + tid] = ok ? a.bn_save[2 * R + tid] : 0.f; bnp[3 * TR + tid] = ok ? a.bn_save[3 * R + tid] : 0.f;
-    }
+    if (!has_router) return;
     __syncthreads();
     const float inv_n = 1.f / (float)n;
 
