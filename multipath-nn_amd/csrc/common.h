@@ -59,11 +59,11 @@ static __device__ unsigned long long *mpnn_trace_buf_ = nullptr;
 __device__ __forceinline__ void trace_stamp(int k) {
     unsigned long long *b = mpnn_trace_buf_;
     if (b && threadIdx.x == 0)
-        b[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * MPNN_TRACE_SLOTS + k] = __builtin_amdgcn_s_memrealtime();
+        b[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * MPNN_TRACE_SLOTS + k] = __builtin_amdgcn_s_memrealtime();
 }
 __device__ __forceinline__ void trace_note(int k, unsigned long long v) {
     unsigned long long *b = mpnn_trace_buf_;
-    if (b && threadIdx.x == 0) b[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * MPNN_TRACE_SLOTS + k] = v;
+    if (b && threadIdx.x == 0) b[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * MPNN_TRACE_SLOTS + k] = v;
 }
 static inline int mpnn_trace_install(void *buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(mpnn_trace_buf_), &buf, sizeof(buf));

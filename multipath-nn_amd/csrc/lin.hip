@@ -16,6 +16,7 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
     const mpnn_lin_fwd_args &a = tab[blockIdx.y];
     const int n0 = blockIdx.x * 16;
     if (n0 >= a.n) return;
+    trace_stamp(0); trace_note(6, 10);
     __shared__ float cA[128 * 3];
     __shared__ float red[LF_WAVES * 2 * 256];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
         }
     }
     __syncthreads();
+    trace_stamp(1);
     const int row = n0 + li;
     const bool valid = row < a.n;
     const int M0 = a.w[0] ? a.M[0] : 0, M1 = a.w[1] ? a.M[1] : 0;
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], b1[j], acc1, 0, 0, 0);
         }
     }
+    trace_stamp(4);
     mfma_drain();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -78,7 +81,10 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
             }
         }
     }
+    trace_stamp(5);
 }
+
+int mpnn_trace_install_lin(void *buf) { return mpnn_trace_install(buf); }
 
 extern "C" int mpnn_lin_fwd(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void *stream) {
     if (count <= 0 || n_max <= 0) return 0;
@@ -94,13 +100,16 @@ extern "C" int mpnn_lin_fwd(const mpnn_lin_fwd_args *dev_table, int count, int n
 //   dX[r][k]   = sum_s sum_m dY_s[r][m] * W_s[k][m]
 //   dW_s[k][m] += act(X)[r][k] * dY_s[r][m]           db_s[m] = sum_r dY_s[r][m]
 // W rows live in registers, dY rows are staged in LDS (<= LB_ROWS rows per pass).
-#define LB_ROWS 32
+#ifndef LB_ROWS
+#define LB_ROWS 16          // rows per pass and per z-slice (the row loop is VALU-bound: ~100 instructions per row)
+#endif
 __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__restrict__ tab) {
     const mpnn_lin_bwd_args &a = tab[blockIdx.y];
     const int C = a.a.C, K = a.HW * C;
     const bool has_extra = a.extra_col[0] || a.extra_col[1];
     const int kext = K + (has_extra ? 1 : 0);
     if ((int)(blockIdx.x * 256) >= kext) return;
+    trace_stamp(0); trace_note(6, 11);
     __shared__ float dys[LB_ROWS * 32];
     const int tid = threadIdx.x;
     const int k = blockIdx.x * 256 + tid;
@@ -117,6 +126,7 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
         w[16 + m] = (k < kext && m < M1 && (k < K || a.extra_col[1])) ? a.w[1][(size_t)k * M1 + m] : 0.f;
         acc[m] = 0.f; acc[16 + m] = 0.f;
     }
+    trace_stamp(1);
     float dbs = 0.f;
     // blockIdx.z owns rows [z*LB_ROWS, ...) with stride gridDim.z*LB_ROWS: four times the workgroups,
     // a quarter of the serial row loop; dW/db are then ADDED into the (zeroed) gradient tensors.
@@ -167,6 +177,7 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
     // dW block of this workgroup = rows [k0, k0+256) of a [K(+1)][M] tensor: contiguous in memory.
     // Transpose the per-thread rows through LDS so every atomic wave-instruction adds 256 contiguous
     // bytes (one lane per row would put 64 lanes in 64 different 64-B segments: ~17x slower).
+    trace_stamp(4);
     __shared__ float tr[256 * 17];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -206,12 +217,14 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
             atomicAdd(slot + C + c, a2);
         }
     }
+    trace_stamp(5);
 }
 
 extern "C" int mpnn_lin_bwd(const mpnn_lin_bwd_args *dev_table, int count, int n_max, int k_max, void *stream) {
     if (count <= 0 || n_max <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    const int zsplit = n_max > 3 * LB_ROWS ? 4 : (n_max > LB_ROWS ? 2 : 1);
+    int zsplit = (n_max + LB_ROWS - 1) / LB_ROWS;              // one pass of LB_ROWS rows per workgroup
+    if (zsplit > 16) zsplit = 16;
     hipLaunchKernelGGL(lin_bwd_k, dim3((k_max + 1 + 255) / 256, count, zsplit), dim3(256), 0, (hipStream_t)stream,
                        dev_table);
     MPNN_LAUNCH_CHECK();
