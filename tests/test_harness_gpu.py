@@ -111,6 +111,21 @@ def test_train_nets_cli(tmp_path):
     assert desc['type'] == 'CriticNet' and 0 <= desc['stats_ts']['acc'] <= 1
 
 
+def test_train_adaptive_nets_cli(tmp_path):
+    """train-adaptive-nets counterpart: per-sample k_cpt drawn each step, one stats file per k_cpt."""
+    out = str(tmp_path / 'nets')
+    cmd = [sys.executable, os.path.join(ROOT, 'multipath-nn_amd', 'train-adaptive-nets'), 'hybrid-ac-dynkcpt',
+           '--synthetic', '--iters', '3', '--out', out]
+    subprocess.check_call(cmd, cwd=str(tmp_path))
+    base = os.path.join(out, 'hybrid-ac-dynkcpt')
+    sys.path.insert(0, os.path.join(ROOT, 'multipath-nn_amd'))
+    import arch_and_hypers as A
+    for i in range(len(A.k_cpts)):
+        desc = np.load(os.path.join(base, '%.4i-stats.npy' % i), allow_pickle=True)[()]       # train-adaptive-nets:102-105
+        assert desc['type'] == 'ActorNet' and 0 <= desc['stats_ts']['acc'] <= 1
+    assert os.path.exists(os.path.join(base, 'net.npy'))
+
+
 def test_device_augmentation_matches_reference_fixtures():
     """mpnn_augment_batch (dataset resident in HBM, draws from the host with the reference's RNG
     sequence) reproduces the batches the REFERENCE's scripts/lib/data.py produced for the same seeds
