@@ -45,6 +45,7 @@ def attach(net):
     eng = net.engine()
     eng.world = dist.get_world_size()
     eng.allreduce = allreduce_sum
+    eng._graphs.clear()                        # graphs captured so far folded the optimizer into the step
     for buf in (eng.P, eng.S, eng.A):          # identical replicas to start from
         dist.broadcast(buf, src=0)
     return net

@@ -894,18 +894,21 @@ class Engine:
             return
         if g == 'warm':
             torch.cuda.synchronize()
+            single = train and self.allreduce is None      # one process: nothing sits between the phases
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
                 self._phase_a(prog, train)
+                if single:
+                    self._opt(n)
             gb = None
-            if train:
+            if train and not single:
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb):
                     self._opt(n)
             g = self._graphs[key] = (ga, gb)
         ga, gb = g
         ga.replay()
-        if train:
+        if train and gb is not None:
             if self.allreduce is not None:
                 self.allreduce(self.G)
             gb.replay()
