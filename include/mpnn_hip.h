@@ -341,6 +341,12 @@ int mpnn_augment_batch(const float *x_src, const float *y_src, const int *draw,
                        float *x_out, float *y_out, int n, int H, int W, int C, int n_cls,
                        void *stream);
 
+/* mpnn_slab_reduce and mpnn_bn_finalize in ONE launch (same arguments and semantics; the two are
+ * independent of each other and both end the backward pass). */
+int mpnn_backward_finish(const float *slabs, float *grads, const int *slab_table, int n_items,
+                         const double *sums, const double *reds, float *state, const int *bn_table,
+                         int n_bn, float decay, int n_img, void *stream);
+
 /* Workgroups of the mpnn_msconv_bwd_scale kernel for an H x W x Cout scale that are resident on the
  * device at once (occupancy x compute units; needs a GPU).  The caller gives the weight-gradient
  * split (n_split x channel chunks x cout groups workgroups) about half of them, so that the dgrad

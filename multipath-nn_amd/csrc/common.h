@@ -116,6 +116,27 @@ __device__ __forceinline__ BnC bn_coef(const mpnn_act &b, int c) {
     return k;
 }
 
+// One BatchNorm of mpnn_bn_finalize (table record t: see misc.hip): moving averages from the forward
+// sums, dgamma / dbeta from the backward reductions.  Shared by bn_finalize_k and backward_finish_k.
+__device__ __forceinline__ void bn_finalize_body(const double *__restrict__ sums, const double *__restrict__ reds,
+                                                 float *__restrict__ state, float *__restrict__ grads,
+                                                 const int *__restrict__ t, float decay, int n_img) {
+    const int C = t[3];
+    const double inv = 1.0 / ((double)t[4] * (double)n_img);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double mean = slot_sum(sums + t[0], 2 * C, c, t[7]) * inv;
+        double var = slot_sum(sums + t[0], 2 * C, C + c, t[7]) * inv - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        float *m = state + t[1] + c, *v = state + t[2] + c;
+        *m = decay * *m + (1.f - decay) * (float)mean;
+        *v = decay * *v + (1.f - decay) * (float)var;
+        if (reds && grads && t[5] >= 0) {
+            grads[t[6] + c] = (float)slot_sum(reds + t[0], 2 * C, c, t[7]);          // dbeta  = sum dz
+            grads[t[5] + c] = (float)slot_sum(reds + t[0], 2 * C, C + c, t[7]);      // dgamma = sum dz * xhat
+        }
+    }
+}
+
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations
 // (lgkmcnt(0)), NOT for its global loads.  __syncthreads() also drains vmcnt, which would wait for
 // the prefetch loads that are deliberately left in flight across pipeline steps.

@@ -172,21 +172,7 @@ extern "C" int mpnn_bn_bwd_apply(float *dz_inout, const mpnn_bn_ctx *ctx, long n
 __global__ void bn_finalize_k(const double *__restrict__ sums, const double *__restrict__ reds,
                               float *__restrict__ state, float *__restrict__ grads,
                               const int *__restrict__ table, float decay, int n_img) {
-    const int *t = table + blockIdx.x * 8;
-    const int C = t[3];
-    const double inv = 1.0 / ((double)t[4] * (double)n_img);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double mean = slot_sum(sums + t[0], 2 * C, c, t[7]) * inv;
-        double var = slot_sum(sums + t[0], 2 * C, C + c, t[7]) * inv - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        float *m = state + t[1] + c, *v = state + t[2] + c;
-        *m = decay * *m + (1.f - decay) * (float)mean;
-        *v = decay * *v + (1.f - decay) * (float)var;
-        if (reds && grads && t[5] >= 0) {
-            grads[t[6] + c] = (float)slot_sum(reds + t[0], 2 * C, c, t[7]);          // dbeta  = sum dz
-            grads[t[5] + c] = (float)slot_sum(reds + t[0], 2 * C, C + c, t[7]);      // dgamma = sum dz * xhat
-        }
-    }
+    bn_finalize_body(sums, reds, state, grads, table + blockIdx.x * 8, decay, n_img);
 }
 
 extern "C" int mpnn_bn_finalize(const double *sums, const double *reds, float *state, float *grads,

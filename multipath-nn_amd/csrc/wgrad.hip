@@ -427,9 +427,7 @@ extern "C" int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *h, const mpnn_d
 // contiguous quarter of the slabs (8 loads in flight), and the quarters are combined through LDS in
 // wave order -- the serial chain is n_split / 32 round trips instead of n_split / 8.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void slab_reduce_k(const float *__restrict__ slabs, float *__restrict__ grads,
-                                                     const int *__restrict__ table) {
-    const int *t = table + blockIdx.x * 6;
+__device__ __forceinline__ void slab_item(const float *__restrict__ slabs, float *__restrict__ grads, const int *__restrict__ t) {
     const int src = t[0], dst = t[1], cnt = t[2], ns = t[3], stride = t[4];
     __shared__ f32x4 part[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -465,6 +463,32 @@ __global__ __launch_bounds__(256) void slab_reduce_k(const float *__restrict__ s
         if (vec && i + 4 <= cnt) *(f32x4 *)(grads + dst + i) = r;
         else for (int j = 0; j < 4 && i + j < cnt; ++j) grads[dst + i + j] = r[j];
     }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_k(const float *__restrict__ slabs, float *__restrict__ grads,
+                                                     const int *__restrict__ table) {
+    slab_item(slabs, grads, table + blockIdx.x * 6);
+}
+
+// mpnn_backward_finish: the two launches that end the backward pass -- the slab reduction and
+// mpnn_bn_finalize -- as one (they are independent of each other).
+__global__ __launch_bounds__(256) void backward_finish_k(const float *__restrict__ slabs, float *__restrict__ grads,
+                                                         const int *__restrict__ slab_table, int n_items,
+                                                         const double *__restrict__ sums, const double *__restrict__ reds,
+                                                         float *__restrict__ state, const int *__restrict__ bn_table,
+                                                         float decay, int n_img) {
+    if ((int)blockIdx.x < n_items) slab_item(slabs, grads, slab_table + blockIdx.x * 6);
+    else bn_finalize_body(sums, reds, state, grads, bn_table + (blockIdx.x - n_items) * 8, decay, n_img);
+}
+
+extern "C" int mpnn_backward_finish(const float *slabs, float *grads, const int *slab_table, int n_items,
+                                    const double *sums, const double *reds, float *state, const int *bn_table,
+                                    int n_bn, float decay, int n_img, void *stream) {
+    if (n_items < 0 || n_bn < 0 || n_items + n_bn == 0) return n_items + n_bn == 0 ? 0 : MPNN_E_ARG;
+    hipLaunchKernelGGL(backward_finish_k, dim3(n_items + n_bn), dim3(256), 0, (hipStream_t)stream, slabs, grads, slab_table,
+                       n_items, sums, reds, state, bn_table, decay, n_img);
+    MPNN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int mpnn_slab_reduce(const float *slabs, float *grads, const int *table, int n_items, void *stream) {

@@ -93,6 +93,7 @@ _SIGS = {
     'mpnn_msconv_fwd': [C.POINTER(ConvFwdArgs), P],
     'mpnn_msconv_fwd_group': [C.POINTER(ConvFwdArgs), P, C.c_int, P],
     'mpnn_debug_set_trace': [P],
+    'mpnn_backward_finish': [P, P, P, C.c_int, P, P, P, P, C.c_int, C.c_float, C.c_int, P],
     'mpnn_augment_batch': [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P],
     'mpnn_msconv_bwd_scale_slots': [C.c_int, C.c_int, C.c_int, C.c_int],
     'mpnn_bn_bwd_reduce': [P, C.POINTER(BnCtx), P, P, C.c_long, P],

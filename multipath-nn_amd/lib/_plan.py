@@ -732,11 +732,14 @@ class Engine:
                 setattr(a, field, slab[off:].data_ptr())
             tab = torch.tensor(slab_plan['table'], dtype=torch.int32, device=self.dev)
             keep += [slab, tab]
-            bwd.append(call(lib.mpnn_slab_reduce, 'slab_reduce', slab.data_ptr(), self.G.data_ptr(),
-                            tab.data_ptr(), len(slab_plan['table']) // 6))
-        bwd.append(call(lib.mpnn_bn_finalize, 'bn_finalize', self.dsum.data_ptr(), self.dred.data_ptr(),
-                        self.S.data_ptr(), self.G.data_ptr(), self.bn_table.data_ptr(), self.n_bn,
-                        self.bn_decay, n))
+            # slab reduction + BatchNorm finalisation (moving averages, dgamma/dbeta): one launch
+            bwd.append(call(lib.mpnn_backward_finish, 'backward_finish', slab.data_ptr(), self.G.data_ptr(),
+                            tab.data_ptr(), len(slab_plan['table']) // 6, self.dsum.data_ptr(), self.dred.data_ptr(),
+                            self.S.data_ptr(), self.bn_table.data_ptr(), self.n_bn, self.bn_decay, n))
+        else:
+            bwd.append(call(lib.mpnn_bn_finalize, 'bn_finalize', self.dsum.data_ptr(), self.dred.data_ptr(),
+                            self.S.data_ptr(), self.G.data_ptr(), self.bn_table.data_ptr(), self.n_bn,
+                            self.bn_decay, n))
         return prog
 
     # ------------------------------------------------------------------ running
