@@ -347,11 +347,12 @@ int mpnn_backward_finish(const float *slabs, float *grads, const int *slab_table
                          const double *sums, const double *reds, float *state, const int *bn_table,
                          int n_bn, float decay, int n_img, void *stream);
 
-/* Workgroups of the mpnn_msconv_bwd_scale kernel for an H x W x Cout scale that are resident on the
+/* Workgroups of the mpnn_msconv_bwd_scale kernel (the variant for this shape, with or without a
+ * dgrad-vert body) for an H x W x Cout scale that are resident on the
  * device at once (occupancy x compute units; needs a GPU).  The caller gives the weight-gradient
  * split (n_split x channel chunks x cout groups workgroups) about half of them, so that the dgrad
  * and wgrad workgroups of the launch all start together.  Negative = MPNN_E_*. */
-int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad);
+int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad, int has_vert);
 
 /* Profiling aid (no reference counterpart).  Installs (or, with NULL, removes) a device buffer of
  * MPNN_TRACE_SLOTS (8) uint64 per workgroup of the largest grid to be traced: thread 0 of every

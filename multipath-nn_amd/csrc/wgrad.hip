@@ -248,8 +248,11 @@ struct BwdScaleP {
 #ifndef MPNN_OCC_BWD
 #define MPNN_OCC_BWD 3       // waves per SIMD asked of the narrow backward kernel (4 = 128 VGPRs spilled 26-42 registers)
 #endif
-template <int GK, int OT, int NCH>
-__global__ __launch_bounds__(256, (OT == 1 && NCH == 1 ? MPNN_OCC_BWD : 2)) void bwd_scale_k(const BwdScaleP q) {
+// HASV = the launch has a dgrad-vert body.  Launches without one (the finest scale of a block) get
+// their own instantiation: the dgrad-vert epilogue prefetch costs ~30 registers, and the narrow
+// variant without it fits 4 waves per SIMD (1024 resident workgroups instead of 768).
+template <int GK, int OT, int NCH, bool HASV>
+__global__ __launch_bounds__(256, (OT == 1 && NCH == 1 ? (HASV ? MPNN_OCC_BWD : MPNN_OCC) : 2)) void bwd_scale_k(const BwdScaleP q) {
     constexpr int CB = ConvSmem<GK, 4, 16, NCH>::BYTES;
     constexpr int GS = OT * 16 + 4;
     constexpr int WB = 4 * WGeom<GK>::PS * 16 + 64 * GS * 4 + (128 * 3 + OT * 16 * 5) * 4;
@@ -261,9 +264,11 @@ __global__ __launch_bounds__(256, (OT == 1 && NCH == 1 ? MPNN_OCC_BWD : 2)) void
     if (id < wh) {
         const int by = id / q.gxh, bx = id - by * q.gxh;
         conv_body<GK, 1, 1, 4, 1, false, EPI_DGH_BN, NCH>(q.h, bx, by, q.gxh, smem);
-    } else if (id < wh + wv) {
-        const int l = id - wh, by = l / q.gxv, bx = l - by * q.gxv;
-        conv_body<GK, 1, 1, 4, 1, false, EPI_DGV, NCH>(q.v, bx, by, q.gxv, smem);
+    } else if (HASV && id < wh + wv) {
+        if constexpr (HASV) {
+            const int l = id - wh, by = l / q.gxv, bx = l - by * q.gxv;
+            conv_body<GK, 1, 1, 4, 1, false, EPI_DGV, NCH>(q.v, bx, by, q.gxv, smem);
+        }
     } else {
         const int l = id - wh - wv, r = l / q.gxw, bx = l - r * q.gxw;
         const int chunk = r % q.nchw, bz = r / q.nchw;
@@ -340,22 +345,25 @@ int mpnn_fill_dgrad_horz(const mpnn_dgrad_horz_args *a, ConvP &p);     // conv_d
 int mpnn_fill_dgrad_vert(const mpnn_dgrad_vert_args *a, ConvP &p);
 
 template <int GK>
-static auto bwd_scale_kernel(bool wide, bool deep) -> void (*)(const BwdScaleP) {
-    return deep ? (wide ? bwd_scale_k<GK, 4, 2> : bwd_scale_k<GK, 1, 2>)
-                : (wide ? bwd_scale_k<GK, 4, 1> : bwd_scale_k<GK, 1, 1>);
+static auto bwd_scale_kernel(bool wide, bool deep, bool hasv) -> void (*)(const BwdScaleP) {
+    if (hasv) return deep ? (wide ? bwd_scale_k<GK, 4, 2, true> : bwd_scale_k<GK, 1, 2, true>)
+                          : (wide ? bwd_scale_k<GK, 4, 1, true> : bwd_scale_k<GK, 1, 1, true>);
+    return deep ? (wide ? bwd_scale_k<GK, 4, 2, false> : bwd_scale_k<GK, 1, 2, false>)
+                : (wide ? bwd_scale_k<GK, 4, 1, false> : bwd_scale_k<GK, 1, 1, false>);
 }
 
 // Resident workgroups of the kernel mpnn_msconv_bwd_scale runs for this shape (the caller sizes
 // the weight-gradient split, and with it the slabs, to a share of them).
-extern "C" int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad) {
+extern "C" int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad, int has_vert) {
     static const int nch_env = [] { const char *e = getenv("MPNN_CONV_NCH"); return e ? atoi(e) : 0; }();
     const bool wide = (Cout % 64) == 0;
     const int gk = (W >= 16 && (W % 16) == 0 && (H % 4) == 0) ? 0 : (W == 8 && H == 8) ? 1 : (W == 4 && H == 4) ? 2 : -1;
     if (gk < 0 || (Cout % 16)) return MPNN_E_SHAPE;
     bool deep = gk != 0 && (Cout % 32) == 0 && has_dgrad;
     if (nch_env != 2) deep = false;        // 32-channel units: opt-in (MPNN_CONV_NCH=2); their 82 KB of LDS leaves ONE workgroup per CU
-    const void *k = gk == 0 ? (const void *)bwd_scale_kernel<0>(wide, deep)
-                  : gk == 1 ? (const void *)bwd_scale_kernel<1>(wide, deep) : (const void *)bwd_scale_kernel<2>(wide, deep);
+    const bool hv = has_vert != 0;
+    const void *k = gk == 0 ? (const void *)bwd_scale_kernel<0>(wide, deep, hv)
+                  : gk == 1 ? (const void *)bwd_scale_kernel<1>(wide, deep, hv) : (const void *)bwd_scale_kernel<2>(wide, deep, hv);
     return resident_slots(k, 0);
 }
 
@@ -373,7 +381,7 @@ static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hip
     static const int nch_env = [] { const char *e = getenv("MPNN_CONV_NCH"); return e ? atoi(e) : 0; }();
     bool deep = GK != 0 && (q.w.c.Cout % 32) == 0 && (has_h || has_v);
     if (nch_env != 2) deep = false;        // 32-channel units: opt-in (MPNN_CONV_NCH=2); their 82 KB of LDS leaves ONE workgroup per CU
-    void (*kern)(const BwdScaleP) = bwd_scale_kernel<GK>(wide, deep);
+    void (*kern)(const BwdScaleP) = bwd_scale_kernel<GK>(wide, deep, has_v);
     // Fit the grid to what is resident at once: the weight-gradient rows keep their split x rows
     // workgroups (the slabs are sized for them), the two dgrad bodies share the rest by work.
     const long slots = resident_slots((const void *)kern, 0);

@@ -406,7 +406,7 @@ class Engine:
             # about half of the workgroups that are resident at once: the dgrad bodies of the same
             # launch take the rest, and everything starts together
             has_dgrad = 1 if (b.in_map is not None or i > 0) else 0
-            slots = self.lib.mpnn_msconv_bwd_scale_slots(b.H[i], b.W[i], b.C[i], has_dgrad)
+            slots = self.lib.mpnn_msconv_bwd_scale_slots(b.H[i], b.W[i], b.C[i], has_dgrad, 1 if i > 0 else 0)
             if slots > 0:
                 div = int(os.environ.get('MPNN_WSPLIT_DIV', '2'))
                 if b.C[i] % 64 == 0:

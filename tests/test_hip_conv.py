@@ -258,9 +258,9 @@ def test_bwd_scale_slots_query():
     torch.zeros(1, device='cuda')
     lib = _hip.load()
     for H, Cc in ((4, 128), (8, 64), (16, 32), (32, 16)):
-        s = lib.mpnn_msconv_bwd_scale_slots(H, H, Cc, 1)
+        s = lib.mpnn_msconv_bwd_scale_slots(H, H, Cc, 1, 1)
         assert s >= 256 and s % 256 == 0, (H, Cc, s)          # whole workgroups per CU x 256 CUs
-    assert lib.mpnn_msconv_bwd_scale_slots(5, 5, 16, 1) == _hip.E_SHAPE
+    assert lib.mpnn_msconv_bwd_scale_slots(5, 5, 16, 1, 0) == _hip.E_SHAPE
 
 
 @pytest.mark.parametrize('C_', [32, 128])
