@@ -35,7 +35,10 @@ __host__ __device__ static inline int fill_fwd(const mpnn_conv_fwd_args *a, Conv
 
 // The member records live in DEVICE memory (uploaded once per plan): indexing a by-value kernel
 // argument array with a runtime member index makes hipcc copy the whole argument block to scratch.
-__global__ __launch_bounds__(256) void fwd_group_k(const mpnn_conv_fwd_args *__restrict__ tab, const FwdGroupP q) {
+// SMALL = some member has a 1- or 3-channel operand A (block 0).  Groups without one run an
+// instantiation that omits those bodies: 128 instead of 160 VGPRs, i.e. 4 instead of 3 waves per SIMD.
+template <bool SMALL>
+__global__ __launch_bounds__(256, SMALL ? 3 : MPNN_OCC) void fwd_group_k(const mpnn_conv_fwd_args *__restrict__ tab, const FwdGroupP q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // sized by the host for the members present
     // 1-D grid with exactly the workgroups that have work (a 2-D grid padded to the widest member
     // launches workgroups that exit at once, and they were seen to delay the residency of real ones)
@@ -49,11 +52,15 @@ __global__ __launch_bounds__(256) void fwd_group_k(const mpnn_conv_fwd_args *__r
     fill_fwd(tab + m, p);
     switch (kind) {
         case 0: p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
-        case 1: p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
         case 2: p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
-        case 3: p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
         case 4: p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
-        default: p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); break;
+        default:
+            if constexpr (SMALL) {
+                if (kind == 1)      { p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); }
+                else if (kind == 3) { p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); }
+                else                { p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); }
+            }
+            break;
     }
 }
 
@@ -84,7 +91,10 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
     const int bytes[3] = {ConvSmem<0, 4, 16>::BYTES, ConvSmem<1, 4, 16>::BYTES, ConvSmem<2, 4, 16>::BYTES};
     int lds = 0;
     for (int k = 0; k < count; ++k) if (bytes[q.gk[k]] > lds) lds = bytes[q.gk[k]];
-    const long slots = resident_slots((const void *)fwd_group_k, lds);
+    bool any_small = false;
+    for (int k = 0; k < count; ++k) any_small = any_small || q.small[k];
+    void (*kern)(const mpnn_conv_fwd_args *, const FwdGroupP) = any_small ? fwd_group_k<true> : fwd_group_k<false>;
+    const long slots = resident_slots((const void *)kern, lds);
     // work of a member = tile-rows x units per tile (16-channel chunks of both operands)
     long total = 0, work[4];
     for (int k = 0; k < count; ++k) {
@@ -103,7 +113,7 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
     int n_wg = 0;
     for (int k = 0; k < count; ++k) { q.w0[k] = n_wg; n_wg += q.gx[k] * q.gy[k]; }
     (void)gxm; (void)rows;
-    hipLaunchKernelGGL(fwd_group_k, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, dev_args, q);
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, dev_args, q);
     MPNN_LAUNCH_CHECK();
     return 0;
 }
