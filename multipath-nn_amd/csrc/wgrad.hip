@@ -252,7 +252,7 @@ struct BwdScaleP {
 // their own instantiation: the dgrad-vert epilogue prefetch costs ~30 registers, and the narrow
 // variant without it fits 4 waves per SIMD (1024 resident workgroups instead of 768).
 template <int GK, int OT, int NCH, bool HASV>
-__global__ __launch_bounds__(256, (OT == 1 && NCH == 1 && GK != 2 ? (HASV ? MPNN_OCC_BWD : MPNN_OCC) : 2)) void bwd_scale_k(const BwdScaleP q) {   // (4x4 maps: few workgroups, no spills at 2 waves)
+__global__ __launch_bounds__(256, (OT == 1 && NCH == 1 && GK != 2 ? (HASV || GK == 1 ? MPNN_OCC_BWD : MPNN_OCC) : 2)) void bwd_scale_k(const BwdScaleP q) {   // (4x4 maps: few workgroups, no spills at 2 waves)
     constexpr int CB = ConvSmem<GK, 4, 16, NCH>::BYTES;
     constexpr int GS = OT * 16 + 4;
     constexpr int WB = 4 * WGeom<GK>::PS * 16 + 64 * GS * 4 + (128 * 3 + OT * 16 * 5) * 4;
