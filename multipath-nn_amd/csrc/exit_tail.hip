@@ -73,10 +73,21 @@ __device__ __forceinline__ void head_softmax(const float *z, int n_cls, float *p
 }
 
 // Stage x[n][R] (global, row stride R) into LDS rows of TR, zero-padded.
+// (fixed trip count, loads from clamped addresses issued back to back: a rolled loop with runtime
+// bounds made one dependent memory round trip per iteration -- 8 per staged array, 10 us per kernel)
 __device__ __forceinline__ void stage_rows(float *dst, const float *src, int rows, int R) {
-    for (int i = threadIdx.x; i < rows * TR; i += 256) {
-        const int s = i / TR, c = i & (TR - 1);
-        dst[i] = c < R ? src[s * R + c] : 0.f;
+    float v[CHUNK * TR / 256];
+#pragma unroll
+    for (int k = 0; k < CHUNK * TR / 256; ++k) {
+        const int i = threadIdx.x + k * 256, s = i / TR, c = i & (TR - 1);
+        const bool ok = s < rows && c < R;
+        v[k] = src[ok ? s * R + c : 0];
+        v[k] = ok ? v[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < CHUNK * TR / 256; ++k) {
+        const int i = threadIdx.x + k * 256;
+        if (i < rows * TR) dst[i] = v[k];
     }
 }
 
@@ -168,6 +179,8 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
     }
 }
 
+int mpnn_trace_install_tail(void *buf) { return mpnn_trace_install(buf); }
+
 extern "C" int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int count, int n_max, void *stream) {
     if (count <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
@@ -182,18 +195,39 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
     const mpnn_exit_tail_bwd_args &b = tab[blockIdx.x];
     const mpnn_exit_tail_args &a = b.f;
     const int tid = threadIdx.x, n = a.n;
+    trace_stamp(0); trace_note(6, 13);
 
     const int R = a.R, S = a.n_sinks;
     __shared__ float w2s[TR * TR], w3s[TR * TS], vec[4 * TR], bnp[4 * TR];
     __shared__ float red[4 * TR];                 // dbeta2, dgamma2, dbeta1, dgamma1
     __shared__ float rowA[CHUNK * TR], rowB[CHUNK * TR];
     __shared__ float h1s[CHUNK * TR], h2s[CHUNK * TR], drs[CHUNK * TS];
-    // requests of the router tail's inputs first; the head's backward (loads, exp, stores) runs meanwhile
+    // ONE memory round trip for everything the kernel reads: the head's operands go to registers
+    // first, then the router tail's inputs are requested; head arithmetic and stores follow.
+    const bool has_head = a.z && b.dz && tid < n;       // (n <= CHUNK <= 256: one sample per thread)
+    float hz[TC], hy[TC], hw = 0.f;
+    {
+        const int nc = a.n_cls;
+#pragma unroll
+        for (int k = 0; k < TC; ++k) {
+            const bool ok = has_head && k < nc;
+            hz[k] = a.z ? a.z[ok ? (size_t)tid * nc + k : 0] : 0.f;
+            hy[k] = a.y ? a.y[ok ? (size_t)tid * nc + k : 0] : 0.f;
+            if (!ok) { hz[k] = 0.f; hy[k] = 0.f; }
+        }
+        if (has_head) hw = b.w_cerr[tid];
+    }
     const bool has_router = a.h1 && n <= CHUNK;
     if (has_router) {
         stage_rows(h1s, a.h1, n, R);
         stage_rows(h2s, a.h2, n, R);
-        for (int i = tid; i < n * TS; i += 256) { const int s = i / TS, k = i & (TS - 1); drs[i] = k < S ? b.dr[(size_t)s * a.r_stride + k] : 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < CHUNK * TS / 256; ++kk) {
+            const int i = tid + kk * 256, s = i / TS, k = i & (TS - 1);
+            const bool ok = s < n && k < S;
+            const float v = b.dr[ok ? (size_t)s * a.r_stride + k : 0];
+            if (i < n * TS) drs[i] = ok ? v : 0.f;
+        }
         for (int i = tid; i < TR * TR; i += 256) { const int c = i / TR, j = i & (TR - 1); w2s[i] = (c < R && j < R) ? a.w2[c * R + j] : 0.f; }
         for (int i = tid; i < TR * TS; i += 256) { const int c = i / TS, k = i & (TS - 1); w3s[i] = (c < R && k < S) ? a.w3[c * S + k] : 0.f; }
         if (tid < TR) {
@@ -204,17 +238,15 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
             bnp[2 * TR + tid] = ok ? a.bn_save[2 * R + tid] : 0.f; bnp[3 * TR + tid] = ok ? a.bn_save[3 * R + tid] : 0.f;
         }
     }
-    if (a.z && b.dz) {
+    if (a.z && b.dz && n > 256) return;              // (never: the host rejects n > CHUNK)
+    if (has_head) {
         const int nc = a.n_cls;
-        for (int s = tid; s < n; s += 256) {
-            float z[TC], y[TC], p[TC], gp[TC];
-#pragma unroll
-            for (int k = 0; k < TC; ++k) {
-                z[k] = k < nc ? a.z[(size_t)s * nc + k] : 0.f;
-                y[k] = k < nc ? a.y[(size_t)s * nc + k] : 0.f;
-            }
+        {
+            const int s = tid;
+            float p[TC], gp[TC];
+            float (&z)[TC] = hz, (&y)[TC] = hy;
             head_softmax(z, nc, p);
-            const float w = b.w_cerr[s];
+            const float w = hw;
             float dot = 0.f;
 #pragma unroll
             for (int k = 0; k < TC; ++k) {
@@ -228,6 +260,7 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
     }
     if (!has_router) return;
     __syncthreads();
+    trace_stamp(1);
     const float inv_n = 1.f / (float)n;
 
     // ---- phase A: per-sample a2, masked dL/d(bn2 out); dW3, dbias3, dbeta2, dgamma2 ----
@@ -265,6 +298,7 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
         if (i < S) b.dbias3[i] = t;
     }
     __syncthreads();
+    trace_stamp(2);
 
     // ---- phase B: dh2 (BN2 backward), a1; dW2 ----
     if (tid < n) {
@@ -284,6 +318,7 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
         if (c < R && j < R) b.dw2[c * R + j] = t;
     }
     __syncthreads();
+    trace_stamp(3);
     // ---- phase C: masked dL/d(bn1 out) overwrites rowA; dbias2, dbeta1, dgamma1 ----
     if (tid < n) {
         float dh2[TR];
@@ -309,6 +344,7 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
         if (tid < R) { b.dbias2[tid] = t0; b.db1[tid] = t1; b.dg1[tid] = t2; }
     }
     __syncthreads();
+    trace_stamp(4);
     // ---- phase D: dh1 (BN1 backward) ----
     for (int i = tid; i < n * TR; i += 256) {
         const int s = i / TR, c = i & (TR - 1);
@@ -317,6 +353,7 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
             b.dh1[s * R + c] = vec[c] * bnp[TR + c] * (rowA[i] - red[2 * TR + c] * inv_n - xh1 * red[3 * TR + c] * inv_n);
         }
     }
+    trace_stamp(5);
 }
 
 extern "C" int mpnn_exit_tail_bwd(const mpnn_exit_tail_bwd_args *dev_table, int count, int n_max, void *stream) {

@@ -30,10 +30,10 @@ for op in ops: op(st.cuda_stream)
 torch.cuda.synchronize()
 NWG = 1 << 16
 buf = torch.zeros(NWG * 8, dtype=torch.int64, device=eng.dev)
-KIND = {1: 'fwd', 2: 'dgh_bn', 3: 'dgh_raw', 4: 'dgv', 8: 'wgrad', 10: 'lin_fwd', 11: 'lin_bwd'}
+KIND = {1: 'fwd', 2: 'dgh_bn', 3: 'dgh_raw', 4: 'dgv', 8: 'wgrad', 10: 'lin_fwd', 11: 'lin_bwd', 13: 'tail_bwd'}
 NAMES = ['start', 'tables', 'staged', 'unit0', 'loop', 'exit']
 for op in ops:
-    if op.what not in ('fwd_group', 'msconv_fwd', 'bwd_scale', 'lin_fwd', 'lin_bwd') or (want not in op.tag and want != op.what):
+    if op.what not in ('fwd_group', 'msconv_fwd', 'bwd_scale', 'lin_fwd', 'lin_bwd', 'exit_tail_bwd') or (want not in op.tag and want != op.what):
         continue
     for _ in range(2): op(st.cuda_stream)            # warm caches
     torch.cuda.synchronize()
