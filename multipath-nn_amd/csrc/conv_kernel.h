@@ -696,7 +696,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             // 2x2 max-pool of the finished tile for the next coarser scale's vert conv
             // (layer_types.py:185): the tile's 64 pixels meet in LDS, each thread pools one value.
             if (EPI == EPI_FWD && GK != 2 && p.pool_out) {        // uniform across the workgroup
-                __syncthreads();
+                lds_barrier();                     // LDS only: __syncthreads would also wait for the output stores just issued
                 if (n0 < p.n) {
                     constexpr int TWp = GK == 0 ? 8 : 4, ROW = GK == 0 ? 16 : 8;   // pooled tile width, tile row length
                     const int H2 = p.H >> 1, W2 = p.W >> 1;
@@ -736,7 +736,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                     redbuf[(wm * CT + cl) * 2 + 1] = a2;
                 }
             }
-            __syncthreads();
+            lds_barrier();                         // (LDS only: do not wait for the tile stores before the statistics atomics)
             if (tid < CT) {
                 double a1 = 0.0, a2 = 0.0;
 #pragma unroll
