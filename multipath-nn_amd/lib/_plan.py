@@ -81,7 +81,7 @@ class Engine:
         self.dev = torch.device(device)
         torch.cuda.set_device(self.dev)
         self.n_max = 0
-        self.use_graph = bool(int(os.environ.get('MPNN_GRAPH', '0')))
+        self.use_graph = bool(int(os.environ.get('MPNN_GRAPH', '1')))     # hipGraph replay of the step (0: eager launches)
         self.multi_stream = bool(int(os.environ.get('MPNN_STREAMS', '0')))
         self.group_fwd = bool(int(os.environ.get('MPNN_FWD_GROUP', '1')))   # wavefront-grouped forward launches
         self._streams = []
@@ -408,10 +408,7 @@ class Engine:
             has_dgrad = 1 if (b.in_map is not None or i > 0) else 0
             slots = self.lib.mpnn_msconv_bwd_scale_slots(b.H[i], b.W[i], b.C[i], has_dgrad, 1 if i > 0 else 0)
             if slots > 0:
-                div = int(os.environ.get('MPNN_WSPLIT_DIV', '2'))
-                if b.C[i] % 64 == 0:
-                    div = int(os.environ.get('MPNN_WSPLIT_DIV_WIDE', str(div)))
-                budget = min(512, slots // div if has_dgrad else slots)
+                budget = min(512, slots // 2 if has_dgrad else slots)      # (a third / a quarter: measured slower)
         want = max(1, budget // (nch * groups))
         w_bytes = 4 * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
         want = min(want, max(1, (12 << 20) // w_bytes))         # keep a layer's slab under ~12 MB
