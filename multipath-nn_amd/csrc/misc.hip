@@ -23,8 +23,13 @@ __global__ __launch_bounds__(256) void pack_k(const float *__restrict__ params, 
     if (fwd >= 0) {
         const int nch = (Cin + 15) >> 4, per_tap = nch * 16 * Cout;
         float *dst = packs + fwd + (size_t)tap * per_tap;
+        // (channel counts are powers of two in every shipped spec: shifts instead of integer divisions,
+        // which made this kernel VALU-bound)
+        const bool p2 = (Cout & (Cout - 1)) == 0;
+        const int sh = 31 - __clz(Cout);
         for (int i = t0; i < per_tap; i += tstride) {
-            const int j = i & 3, co = (i >> 2) % Cout, rest = (i >> 2) / Cout;   // rest = ch*4 + gb
+            const int j = i & 3, q = i >> 2;
+            const int co = p2 ? (q & (Cout - 1)) : q % Cout, rest = p2 ? (q >> sh) : q / Cout;   // rest = ch*4 + gb
             const int c = rest * 4 + j;
             dst[i] = c < Cin ? W[((size_t)tap * Cin + c) * Cout + co] : 0.f;
         }
@@ -32,8 +37,11 @@ __global__ __launch_bounds__(256) void pack_k(const float *__restrict__ params, 
     if (bwd >= 0) {
         const int nch = (Cout + 15) >> 4, per_tap = nch * 16 * Cin;
         float *dst = packs + bwd + (size_t)tap * per_tap;
+        const bool p2 = (Cin & (Cin - 1)) == 0;
+        const int sh = 31 - __clz(Cin);
         for (int i = t0; i < per_tap; i += tstride) {
-            const int j = i & 3, ci = (i >> 2) % Cin, rest = (i >> 2) / Cin;
+            const int j = i & 3, q = i >> 2;
+            const int ci = p2 ? (q & (Cin - 1)) : q % Cin, rest = p2 ? (q >> sh) : q / Cin;
             const int co = rest * 4 + j;
             dst[i] = co < Cout ? W[((size_t)(8 - tap) * Cin + ci) * Cout + co] : 0.f;
         }
