@@ -355,10 +355,10 @@ int mpnn_backward_finish(const float *slabs, float *grads, const int *slab_table
 int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad, int has_vert);
 
 /* Profiling aid (no reference counterpart).  Installs (or, with NULL, removes) a device buffer of
- * MPNN_TRACE_SLOTS (8) uint64 per workgroup of the largest grid to be traced: thread 0 of every
+ * MPNN_TRACE_SLOTS (12) uint64 per workgroup of the largest grid to be traced: thread 0 of every
  * workgroup of the conv / dgrad / wgrad kernels stamps the 100 MHz device clock at its phase
  * boundaries (entry, tables ready, first tile staged, first unit done, loop done, exit; slot 6 = body
- * kind, slot 7 = units).  tools/trace_phases.py prints the timeline.  Synchronises the device. */
+ * kind, slot 7 = units; slots 8-10: first unit's MFMAs done, next unit staged, epilogue done).  tools/trace_phases.py prints the timeline.  Synchronises the device. */
 int mpnn_debug_set_trace(unsigned long long *buf);
 
 const char *mpnn_version(void);

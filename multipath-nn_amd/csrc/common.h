@@ -53,7 +53,7 @@ static int resident_slots(const void *kernel, int dyn_lds) {
 // Every translation unit has its own copy of the pointer (no relocatable device code).
 // ---------------------------------------------------------------------------
 // Compiled in only with -DMPNN_TRACE (make trace -> libmpnn_hip_trace.so): the stamps cost registers.
-#define MPNN_TRACE_SLOTS 8
+#define MPNN_TRACE_SLOTS 12
 #ifdef MPNN_TRACE
 static __device__ unsigned long long *mpnn_trace_buf_ = nullptr;
 __device__ __forceinline__ void trace_stamp(int k) {

@@ -630,10 +630,12 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             }
         }
         mfma_drain();
+        if (u == 0) trace_stamp(8);
         // ----------------------------- stage unit u+1 ------------------------------
         // BEFORE the epilogue: its wait then covers exactly the loads of unit u+2 issued above
         // (vmcnt(N)); behind the epilogue's conditional global stores the count would be unknown.
         if (more && !(p.dbg & 2)) unit_store(n1, xn1, bn1, (u + 1) & 1, !b_once);
+        if (u == 0) trace_stamp(9);
         // ----------------------------- epilogue of a finished tile -----------------
         // D layout: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel of the M-tile).
         if ((!more || t2 != t) && !(p.dbg & 4)) {
@@ -714,6 +716,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         cu = n1; n1 = n2;
+        if (u == 0) trace_stamp(10);
         lds_barrier();              // LDS-only: the prefetch loads of unit u+2 stay in flight
     };
     for (int u = 0; u < n_units; u += 2) {

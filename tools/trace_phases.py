@@ -29,7 +29,8 @@ eng._zero(True); eng._pack()
 for op in ops: op(st.cuda_stream)
 torch.cuda.synchronize()
 NWG = 1 << 16
-buf = torch.zeros(NWG * 8, dtype=torch.int64, device=eng.dev)
+SL = 12
+buf = torch.zeros(NWG * SL, dtype=torch.int64, device=eng.dev)
 KIND = {1: 'fwd', 2: 'dgh_bn', 3: 'dgh_raw', 4: 'dgv', 8: 'wgrad', 10: 'lin_fwd', 11: 'lin_bwd', 13: 'tail_bwd'}
 NAMES = ['start', 'tables', 'staged', 'unit0', 'loop', 'exit']
 for op in ops:
@@ -42,7 +43,7 @@ for op in ops:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st); op(st.cuda_stream); e1.record(st); e1.synchronize()
     _hip.check(eng.lib.mpnn_debug_set_trace(None), 'set_trace')
-    t = buf.cpu().numpy().reshape(NWG, 8)
+    t = buf.cpu().numpy().reshape(NWG, SL)
     rows = t[t[:, 0] != 0]
     if not len(rows):
         continue
@@ -56,11 +57,16 @@ for op in ops:
     for kind in sorted(set(rows[:, 6])):
         r = rows[rows[:, 6] == kind]
         rel = (r[:, :6] - t0) / 100.0
+        rel2 = (r[:, 8:11] - t0) / 100.0
         units = r[:, 7]
         print('  %-7s %4d wgs, units/wg %d..%d' % (KIND.get(int(kind), str(kind)), len(r), units.min(), units.max()))
         for k in range(6):
             col = rel[:, k][r[:, k] != 0]
             if len(col):
                 print('     %-7s min %6.2f  med %6.2f  max %6.2f us' % (NAMES[k], col.min(), np.median(col), col.max()))
+        for k, nm in enumerate(('u0 mfma', 'u0 stage', 'u0 epi')):
+            col = rel2[:, k][r[:, 8 + k] != 0]
+            if len(col):
+                print('     %-8s min %6.2f  med %6.2f  max %6.2f us' % (nm, col.min(), np.median(col), col.max()))
         d = (r[:, 5] - r[:, 0]) / 100.0
         print('     in-wg time (start->exit): min %.2f med %.2f max %.2f us' % (d.min(), np.median(d), d.max()))
