@@ -124,3 +124,28 @@ def test_train_nets_experiment_keys():
             'cifar5-ac', 'cifar10-sr', 'cifar10-ac'} <= keys            # scripts/train-nets:28-88
     assert {'cifar10-cr', 'mnist-sr'} <= keys                             # BASELINE.json configs
     assert len(ns['experiments']['cifar10-ac'].nets) == 8 and len(ns['experiments']['cifar10-sr'].nets) == 8
+
+
+def test_isa_has_no_uncovered_mfma_result_reads():
+    """Every read of an MFMA accumulator by a VALU copy (v_accvgpr_read / v_accvgpr_mov) is separated
+    from the last MFMA by an s_nop or >= 11 vector instructions (tools/scan_mfma_hazard.py; DESIGN.md
+    section 3, "MFMA -> AGPR-copy hazard").  The 2x2-register-tile conv variants (conv_k<GK,2,...>) are
+    exempt: their flagged reads are of accumulators written at least one MFMA earlier and hipcc puts its
+    own s_nop before the last one."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('hipcc') is None:
+        pytest.skip('hipcc not available')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import scan_mfma_hazard as S
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for name in ('conv_fwd.hip', 'conv_dgrad.hip', 'wgrad.hip', 'lin.hip'):
+            out = os.path.join(tmp, name + '.s')
+            subprocess.check_call(['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'),
+                                   '-munsafe-fp-atomics', '--cuda-device-only', '-S', os.path.join(S.CSRC, name), '-o', out],
+                                  cwd=S.CSRC, stderr=subprocess.DEVNULL)
+            bad += [(name,) + site for site in S.scan(out)
+                    if not (site[0] or '').startswith('_Z6conv_kILi') or 'ELi2ELi' not in (site[0] or '')[:20]]
+    assert not bad, bad[:5]
