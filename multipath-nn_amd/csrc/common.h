@@ -18,14 +18,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // device at once (occupancy x compute units), cached per kernel instantiation.  The persistent grids
 // are sized to this: workgroups beyond it only start when earlier ones exit, which serialises the
 // bodies of a fused launch (measured: the weight-gradient workgroups of bwd_scale started 8-13 us late).
-static int resident_slots(const void *kernel, int dyn_lds) {
-    struct Entry { const void *fn; int lds, slots; };
+static int resident_slots(const void *kernel, int dyn_lds, int threads = 256) {
+    struct Entry { const void *fn; int lds, slots; };            // (a kernel is always queried with the same block size)
     static Entry cache[64];
     static int n_cached = 0;
     for (int i = 0; i < n_cached; ++i)
         if (cache[i].fn == kernel && cache[i].lds == dyn_lds) return cache[i].slots;
     int per_cu = 0, dev = 0, cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, (size_t)dyn_lds) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, (size_t)dyn_lds) != hipSuccess || per_cu < 1)
         per_cu = 2;
     // The occupancy query was seen to allow two 82 KB workgroups on a 160 KB CU (bwd_scale_k<2,4,2>:
     // half of the grid then started 11-23 us late): bound it by the LDS arithmetic as well.

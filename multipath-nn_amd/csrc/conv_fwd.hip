@@ -64,6 +64,17 @@ __global__ __launch_bounds__(256, SMALL ? 3 : MPNN_OCC) void fwd_group_k(const m
     }
 }
 
+// One deep small-map member alone in its launch: K-split body, 512 threads (see conv_body).
+template <int GK>
+__global__ __launch_bounds__(512) void fwd_ks_k(const mpnn_conv_fwd_args *__restrict__ tab, const int gx) {
+    __shared__ __attribute__((aligned(16))) char smem[ConvSmem<GK, 4, 16, 2>::BYTES];
+    const int id = blockIdx.x, yy = id / gx, bx = id - yy * gx;
+    ConvP p = {};
+    fill_fwd(tab, p);
+    p.n_tiles = conv_grid_x<GK>(p.n, p.H, p.W);
+    conv_body<GK, 1, 1, 4, 1, false, EPI_FWD, 2, true>(p, bx, yy, gx, smem);
+}
+
 extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
                                      void *stream) {
     if (count <= 0) return 0;
@@ -91,6 +102,20 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
     const int bytes[3] = {ConvSmem<0, 4, 16>::BYTES, ConvSmem<1, 4, 16>::BYTES, ConvSmem<2, 4, 16>::BYTES};
     int lds = 0;
     for (int k = 0; k < count; ++k) if (bytes[q.gk[k]] > lds) lds = bytes[q.gk[k]];
+    // a single deep member on a small map: 128-256 workgroups of 4 waves would leave every SIMD with one
+    // wave and nothing to overlap -> K-split body (two thread groups per workgroup, 32-channel units)
+    static const int ks_env = [] { const char *e = getenv("MPNN_FWD_KSPLIT"); return e ? atoi(e) : 1; }();
+    if (ks_env && count == 1 && q.gk[0] != 0 && !q.small[0] && (hp[0].a.C % 32) == 0 && (hp[0].Cv % 32) == 0 &&
+        hp[0].a.C + hp[0].Cv >= 64) {
+        const int gy = q.gy[0];
+        int gx = hp[0].n_tiles;
+        const long slots = q.gk[0] == 1 ? resident_slots((const void *)fwd_ks_k<1>, 0, 512) : resident_slots((const void *)fwd_ks_k<2>, 0, 512);
+        if ((long)gx * gy > slots) gx = (int)(slots / gy > 0 ? slots / gy : 1);
+        if (q.gk[0] == 1) hipLaunchKernelGGL(fwd_ks_k<1>, dim3(gx * gy), dim3(512), 0, (hipStream_t)stream, dev_args, gx);
+        else              hipLaunchKernelGGL(fwd_ks_k<2>, dim3(gx * gy), dim3(512), 0, (hipStream_t)stream, dev_args, gx);
+        MPNN_LAUNCH_CHECK();
+        return 0;
+    }
     bool any_small = false;
     for (int k = 0; k < count; ++k) any_small = any_small || q.small[k];
     void (*kern)(const mpnn_conv_fwd_args *, const FwdGroupP) = any_small ? fwd_group_k<true> : fwd_group_k<false>;

@@ -356,8 +356,13 @@ struct ConvSmem {
 // NCH = 16-channel chunks per unit (1 or 2).  With 2 a unit spans 32 input channels: half as many
 // barriers and load round trips on the deep-K, small-M layers whose per-unit MFMA time (~0.5 us)
 // cannot cover a load latency (~2 us).  Requires every operand's channel count % 32 == 0.
-template <int GK, int MT, int NT, int WM, int WN, bool SMALL_A, int EPI, int NCH = 1>
+// KSPLIT (with NCH == 2, 512 threads): the workgroup's two 256-thread halves each stage and multiply ONE
+// of the unit's two chunks; their partial sums meet in LDS when a tile is finished.  For the deep 4x4 /
+// 8x8 layers, whose 128-256 workgroups otherwise leave one wave per SIMD with nothing to overlap.
+template <int GK, int MT, int NT, int WM, int WN, bool SMALL_A, int EPI, int NCH = 1, bool KSPLIT = false>
 __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const int by, const int gx, char *smem) {
+    static_assert(!KSPLIT || (NCH == 2 && MT == 1 && NT == 1 && !SMALL_A && EPI == EPI_FWD), "K-split: forward, 32-channel units");
+    constexpr int SC = KSPLIT ? 1 : NCH;            // chunks staged / multiplied by ONE thread group per unit
     using G = Geom<GK>;
     constexpr int P = G::P, R = G::R, HR = G::TH + 2;
     constexpr int CT = WN * NT * 16;
@@ -376,7 +381,8 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     float *pool_lds = (float *)(smem + SM::TILE + SM::WT + SM::CA + ((SM::CE + 15) & ~15) + SM::RED);   // [64 px][CT]
 
     trace_stamp(0);
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = KSPLIT ? (threadIdx.x & 255) : threadIdx.x, lane = tid & 63;
+    const int kg = KSPLIT ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;      // K-group of this wave
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int wm = wid / WN, wn = wid - wm * WN;
@@ -444,21 +450,25 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         const float *src = sel_p(q.part, aX, vX), *wp = sel_p(q.part, wAp, wVp);
         const int C = sel_i(q.part, aC, vC), nch = sel_i(q.part, nchA, nchV);
 #pragma unroll
-        for (int sc = 0; sc < NCH; ++sc)
-            ld_items<GK, LK, XW, SMALL_A>(xq + sc * XN, p, tgeo, ik, q.part, (q.ch + sc) * 16, q.np - 4 * sc, src, C);
+        for (int sc = 0; sc < SC; ++sc) {
+            const int cs = KSPLIT ? kg : sc;           // chunk of the unit this thread group handles
+            ld_items<GK, LK, XW, SMALL_A>(xq + sc * XN, p, tgeo, ik, q.part, (q.ch + cs) * 16, q.np - 4 * cs, src, C);
+        }
 #pragma unroll
-        for (int sc = 0; sc < NCH; ++sc) {
-            const int uo = (q.ch + sc) * 16 * p.Cout;
+        for (int sc = 0; sc < SC; ++sc) {
+            const int cs = KSPLIT ? kg : sc;
+            const int uo = (q.ch + cs) * 16 * p.Cout;
 #pragma unroll
             for (int k = 0; k < BN; ++k) bq[sc * BN + k] = *(const f32x4 *)(wp + (w_off(k, nch) + uo));
         }
     };
     auto unit_store = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq, int buf, bool with_b) {
 #pragma unroll
-        for (int sc = 0; sc < NCH; ++sc) {
-            f32x4 *td = tile[buf] + sc * 4 * P;
+        for (int sc = 0; sc < SC; ++sc) {
+            const int cs = KSPLIT ? kg : sc;
+            f32x4 *td = tile[buf] + cs * 4 * P;
             f32x4 (*xs)[XW] = xq + sc * XN;
-            const int c0 = (q.ch + sc) * 16, np = q.np - 4 * sc;
+            const int c0 = (q.ch + cs) * 16, np = q.np - 4 * cs;
             bool done = false;
             if constexpr (EPI == EPI_FWD) {
                 if (q.part) { done = true; st_items<GK, 1, XW>(td, xs, p, cA, q.inb, ik, c0, np); }
@@ -471,9 +481,9 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         if (with_b) {
             f32x4 *dst = wtile[b_once ? 0 : buf];
 #pragma unroll
-            for (int sc = 0; sc < NCH; ++sc)
+            for (int sc = 0; sc < SC; ++sc)
 #pragma unroll
-                for (int k = 0; k < BN; ++k) { const int i = tid + k * 256; if (i < BI) dst[sc * BI + i] = bq[sc * BN + k]; }
+                for (int k = 0; k < BN; ++k) { const int i = tid + k * 256; if (i < BI) dst[(KSPLIT ? kg : sc) * BI + i] = bq[sc * BN + k]; }
         }
     };
 
@@ -481,8 +491,8 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     // landed/landing in one set (written to LDS at the end of the step) and unit u+2 is being loaded
     // into the other: the prefetch distance is
     // two units, enough to cover a load round trip with ~0.5 us of MFMAs per unit.
-    f32x4 xrA[NCH * XN][XW], xrB[NCH * XN][XW];
-    f32x4 brA[NCH * BN], brB[NCH * BN];
+    f32x4 xrA[SC * XN][XW], xrB[SC * XN][XW];
+    f32x4 brA[SC * BN], brB[SC * BN];
     f32x4 acc[MT][NT];
     float s1[NT], s2[NT];
 #pragma unroll
@@ -606,7 +616,8 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                 // MFMAs instead of stalling the wave once per tap.
                 f32x4 fa[2][MT], fb[2][NT];
                 auto frag = [&](int it, f32x4 *a, f32x4 *bq) {
-                    const int sc = it / 9, tap = it - sc * 9, dy = tap / 3, dx = tap - dy * 3;
+                    const int s9 = it / 9, tap = it - s9 * 9, dy = tap / 3, dx = tap - dy * 3;
+                    const int sc = KSPLIT ? kg : s9;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bq[nt] = wl[sc * BI + (tap * 4 + g) * CT + wcol + nt * 16];
 #pragma unroll
@@ -614,8 +625,8 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                 };
                 frag(0, fa[0], fb[0]);
 #pragma unroll
-                for (int it = 0; it < NCH * 9; ++it) {
-                    if (it + 1 < NCH * 9) frag(it + 1, fa[(it + 1) & 1], fb[(it + 1) & 1]);
+                for (int it = 0; it < SC * 9; ++it) {
+                    if (it + 1 < SC * 9) frag(it + 1, fa[(it + 1) & 1], fb[(it + 1) & 1]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -624,7 +635,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                             for (int nt = 0; nt < NT; ++nt)
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[it & 1][mt][j], fb[it & 1][nt][j], acc[mt][nt], 0, 0, 0);
                     // pin the order for the machine scheduler (it otherwise sinks the reads to their use)
-                    if (it + 1 < NCH * 9) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);   // DS reads of t+1
+                    if (it + 1 < SC * 9) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);   // DS reads of t+1
                     __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);                        // MFMAs of t
                 }
             }
@@ -639,6 +650,12 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         // ----------------------------- epilogue of a finished tile -----------------
         // D layout: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel of the M-tile).
         if ((!more || t2 != t) && !(p.dbg & 4)) {
+            if constexpr (KSPLIT) {                     // partial sums of the second K-group -> LDS -> first group
+                f32x4 *kred = (f32x4 *)pool_lds;         // [wave][lane]: the wave's own kilobyte of the pooling area
+                if (kg == 1) kred[wid * 64 + lane] = acc[0][0];
+                lds_barrier();
+                if (kg == 0) acc[0][0] += kred[wid * 64 + lane];
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -646,7 +663,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                     int img, ty, tx;
                     mtile_pix<GK>(wm * MT + mt, g * 4 + r, img, ty, tx);
                     const int n = n0 + img, y = y0 + ty, x = x0 + tx;
-                    if (n >= p.n) continue;
+                    if (n >= p.n || kg != 0) continue;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const int co = cw + nt * 16;
@@ -699,7 +716,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             // (layer_types.py:185): the tile's 64 pixels meet in LDS, each thread pools one value.
             if (EPI == EPI_FWD && GK != 2 && p.pool_out) {        // uniform across the workgroup
                 lds_barrier();                     // LDS only: __syncthreads would also wait for the output stores just issued
-                if (n0 < p.n) {
+                if (n0 < p.n && kg == 0) {
                     constexpr int TWp = GK == 0 ? 8 : 4, ROW = GK == 0 ? 16 : 8;   // pooled tile width, tile row length
                     const int H2 = p.H >> 1, W2 = p.W >> 1;
                     for (int e = tid; e < 16 * CT; e += 256) {
@@ -733,14 +750,14 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             for (int nt = 0; nt < NT; ++nt) {
                 const double a1 = reduce_g4((double)s1[nt]);
                 const double a2 = reduce_g4((double)s2[nt]);
-                if (g == 0) {
+                if (g == 0 && kg == 0) {
                     const int cl = wn * NT * 16 + nt * 16 + li;
                     redbuf[(wm * CT + cl) * 2] = a1;
                     redbuf[(wm * CT + cl) * 2 + 1] = a2;
                 }
             }
             lds_barrier();                         // (LDS only: do not wait for the tile stores before the statistics atomics)
-            if (tid < CT) {
+            if (tid < CT && kg == 0) {
                 double a1 = 0.0, a2 = 0.0;
 #pragma unroll
                 for (int w = 0; w < WM; ++w) { a1 += redbuf[(w * CT + tid) * 2]; a2 += redbuf[(w * CT + tid) * 2 + 1]; }
