@@ -72,7 +72,7 @@ def pool2_np(v):
     return np.ascontiguousarray(v.reshape(n, h // 2, 2, w // 2, 2, c).max(axis=(2, 4)))
 
 
-def conv_fwd(x, wh, b, v=None, wv=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0, bn_cnt=1, want_pool=False):
+def conv_fwd(x, wh, b, v=None, wv=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0, bn_cnt=1, want_pool=False, group=False):
     """x: [n, H<<shift, W<<shift, Ca]; v: the UNPOOLED finer map [n, 2H, 2W, Cv] (pooled here, as its
     producer would).  Returns (out, out_sum[, pooled out])."""
     if v is not None:
@@ -93,7 +93,12 @@ def conv_fwd(x, wh, b, v=None, wv=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0
     pool = torch.full((n, H // 2, W // 2, co), 9.0, device=DEV) if want_pool else None
     a.pool_out = _hip.ptr(pool)
     a.n, a.H, a.W, a.Cout = n, H, W, co
-    _hip.check(lib.mpnn_msconv_fwd(C.byref(a), stream()), 'msconv_fwd')
+    if group:            # the same conv as a one-member wavefront group (device table; K-split body on deep small maps)
+        arr = (_hip.ConvFwdArgs * 1)(a)
+        tab = _hip.to_device_table([a], DEV)
+        _hip.check(lib.mpnn_msconv_fwd_group(arr, tab.data_ptr(), 1, stream()), 'msconv_fwd_group')
+    else:
+        _hip.check(lib.mpnn_msconv_fwd(C.byref(a), stream()), 'msconv_fwd')
     torch.cuda.synchronize()
     if want_pool:
         return out.cpu().numpy(), unslot(osum, 2 * co), pool.cpu().numpy()

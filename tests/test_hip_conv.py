@@ -309,3 +309,39 @@ def test_lin_bwd_fused_bn_reduce(C_):
     safe = (np.abs(y) > 1e-4).reshape(-1)
     assert np.abs(dz1 - dz_ref.reshape(-1))[safe].max() < 1e-6
     close(red1, red_ref, 1e-4)
+
+
+@pytest.mark.parametrize('shape', [(4, 64, 64, 64), (4, 64, 0, 128), (4, 128, 0, 128), (8, 64, 0, 64), (8, 32, 32, 64), (16, 32, 0, 32)])
+def test_one_member_group_equals_single_launch(shape):
+    """mpnn_msconv_fwd_group with ONE member (the deep 4x4 / 8x8 shapes take the K-split body: 512
+    threads, the two halves' partial sums meet in LDS) against mpnn_msconv_fwd and the oracle, on a
+    ragged batch, with BatchNorm on load and the pooled output."""
+    import hiputil as U
+    H, ca, cv, co = shape
+    rng = np.random.default_rng(sum(shape))
+    n = 11
+    x = rng.standard_normal((n, H, H, ca)).astype(np.float32)
+    wh = (rng.standard_normal((3, 3, ca, co)) / np.sqrt(9 * ca)).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    v = rng.standard_normal((n, 2 * H, 2 * H, cv)).astype(np.float32) if cv else None
+    wv = (rng.standard_normal((3, 3, cv, co)) / np.sqrt(9 * cv)).astype(np.float32) if cv else None
+    gamma, beta = rng.uniform(0.5, 1.5, ca), rng.standard_normal(ca) * 0.3
+    bn, cnt = U.bn_dict(x, gamma, beta)
+    want_pool = H >= 8
+    one = U.conv_fwd(x, wh, b, v, wv, bn, _hip_mode(), 0, cnt, want_pool=want_pool)
+    grp = U.conv_fwd(x, wh, b, v, wv, bn, _hip_mode(), 0, cnt, want_pool=want_pool, group=True)
+    scale = 1 + np.abs(one[0]).max()
+    assert np.abs(grp[0] - one[0]).max() <= 2e-5 * scale           # (different summation order over K)
+    close(grp[1], one[1], 1e-4)
+    if want_pool:
+        assert np.abs(grp[2] - one[2]).max() <= 2e-5 * scale
+    y, _, _ = O.bn_train(x.astype(np.float64), gamma, beta)
+    ref = O.conv_same(np.maximum(y, 0), wh.astype(np.float64)) + b
+    if cv:
+        ref = ref + O.conv_same(U.pool2_np(v).astype(np.float64), wv.astype(np.float64))
+    close(grp[0], ref, 2e-5)
+
+
+def _hip_mode():
+    from lib import _hip
+    return _hip.ACT_BN_BATCH
