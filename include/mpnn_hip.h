@@ -96,7 +96,11 @@ typedef struct {
 int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
 /* Up to four mutually independent forward convs (one wavefront level of the block x scale grid)
  * as ONE launch; `args` is a HOST array of `count` records (sizes the grid) and `dev_args` a
- * DEVICE copy of it (read by the kernel; uploaded once per plan). */
+ * DEVICE copy of it (read by the kernel; uploaded once per plan).  The grid is 1-D, holds exactly
+ * the workgroups that have work and is fitted to what is resident at once, shared between the
+ * members by work.  A single member on an 8x8 / 4x4 map with >= 64 input channels (multiples of
+ * 32 per operand) takes the K-split body (512 threads, two chunks of a 32-channel unit in
+ * parallel); results are the same up to fp32 summation order. */
 int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
                           void *stream);
 
