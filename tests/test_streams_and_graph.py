@@ -85,3 +85,22 @@ def test_wavefront_groups_equal_single_launches():
         if k < n0:
             assert torch.equal(a, b), k
         assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item(), k
+
+
+def test_training_memorises_fixed_batches_and_stays_finite():
+    """1500 graph-replayed steps over 4 fixed random batches with the driver's schedules: parameters
+    stay finite and the routed net classifies the batches it has seen (a functional check of the whole
+    step -- forward, exits, router, backward, TALR/momentum -- beyond per-step parity)."""
+    import arch_and_hypers as A
+    net = A.ac_chain(k_cpt=1.6e-8, seed=3)((32, 32, 3), (10,))
+    eng = net.engine()
+    g = torch.Generator(device='cuda').manual_seed(0)
+    xs = torch.rand((4, 128, 32, 32, 3), device='cuda', generator=g)
+    ys = torch.eye(10, device='cuda')[torch.randint(0, 10, (4, 128), device='cuda', generator=g)]
+    for t in range(1500):
+        net.train.run({net.x0: xs[t % 4], net.y: ys[t % 4], net.mode: 'tr', net.λ_lrn: A.λ_lrn(t), net.τ: A.τ_ds(t)})
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.P).all() and torch.isfinite(eng.S).all()
+    net.eval({net.x0: xs[0], net.y: ys[0]})
+    acc = float(net.state()[(net, 'acc')].mean())
+    assert acc > 0.9, acc
