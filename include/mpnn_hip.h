@@ -25,6 +25,9 @@
 extern "C" {
 #endif
 
+#define MPNN_MAX_NODES 128     /* routing-tree nodes (mpnn_route)            */
+#define MPNN_MAX_SINKS 4       /* children of one switch                      */
+
 #define MPNN_E_SHAPE   (-1)   /* unsupported geometry / channel count      */
 #define MPNN_E_ARG     (-2)   /* inconsistent arguments                     */
 
@@ -92,6 +95,15 @@ typedef struct {
     double *out_sum;                                /* [SLOTS][2*Cout], accumulated */
     int out_nslot;                                  /* slots of out_sum to spread over */
     int n, H, W, Cout;
+    /* Routed evaluation (mpnn_msconv_fwd_group only; 'ev' mode, BatchNorm moving averages): when
+     * `idx` is set, the launch processes the *cnt samples idx[0..*cnt) -- sample slot s is image
+     * idx[s] of EVERY buffer of the record (a, v, out, pool_out): inputs are gathered and results
+     * scattered by the tile loader / epilogue themselves, nothing is copied.  `cnt` is read on the
+     * DEVICE when the kernel starts (written by an earlier mpnn_exit_ev on the same stream: no host
+     * sync); `n` stays the capacity the grid is sized for.  The samples that did not reach this
+     * node keep whatever the buffers held.  Replaces the 0/1 masks p_ev of net_types.py:127-131. */
+    const int *idx;
+    const int *cnt;
 } mpnn_conv_fwd_args;
 int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
 /* Up to four mutually independent forward convs (one wavefront level of the block x scale grid)
@@ -142,6 +154,9 @@ typedef struct {
     float  *out;                         /* dz (prev != NULL) or dy                */
     double *red_out;                     /* [SLOTS][2*Cout] accumulated (prev != NULL) */
     int n, H, W, Cout;
+    int accumulate;                      /* 1: out += result (a map feeding SEVERAL child blocks, tree nets:
+                                            the ReLU mask and the reductions are linear in dy, so each child's
+                                            launch adds its own masked share) */
 } mpnn_dgrad_horz_args;
 int mpnn_msconv_dgrad_horz(const mpnn_dgrad_horz_args *args, void *stream);
 
@@ -262,6 +277,38 @@ typedef struct {
 int mpnn_exit_tail_bwd(const mpnn_exit_tail_bwd_args *dev_table, int count, int n_max,
                        void *stream);
 
+/* ---- one exit in evaluation mode, with routing ------------------------------
+ * Head + router of one tree node in 'ev' mode (moving-average BatchNorm:
+ * layer_types.py:237-238), any batch size, and the node's hard routing decision
+ * pi_ev = one-hot(arg-max r) (net_types.py:127-129, first index on ties) turned
+ * into per-child sample lists:
+ *   z = flatten(act(a)) @ w_head + b_head -> softmax -> c_err, d_cor   (as mpnn_exit_tail_fwd)
+ *   r = router MLP (as mpnn_lin_fwd + mpnn_exit_tail_fwd with MPNN_ACT_BN_MOVING)
+ *   sample s (image idx[s]) is APPENDED to child_idx[i] (count child_cnt[i], atomically) for
+ *   i = arg-max r, when sink i has a list (a child block); sinks without one (the exit's own
+ *   classifier leaf) need none.
+ * The sample list idx[0..*cnt) is the node's own (NULL: all n samples); c_err, d_cor and r are
+ * indexed by IMAGE (r: [image][r_stride]), entries of samples that do not reach the node are
+ * not touched (the caller clears them once per batch).  Table driven like the other exit-path
+ * entry points; the grid is sized for n_max samples, counts are read on the device.
+ * Limits (mpnn_exit_ev_check, host records): n_cls <= 16, R <= 16, n_sinks <= 4, C <= 128,
+ * HW*C % 16 == 0. */
+typedef struct {
+    mpnn_act a;  int HW;                 /* the block's coarsest scale, pre-BN: [images, HW, C] */
+    const float *w_head, *b_head;  int n_cls;         /* NULL: no classifier at this node */
+    const float *y;  float eps_ce;  float *c_err, *d_cor;
+    const float *w1, *b1;  int R;  int n_sinks;       /* NULL: no router */
+    int extra_col;  const float *k_cpt;  float alpha_cpt;   /* dyn_k_cpt column (net_types.py:149-160) */
+    const float *g1, *be1, *m1, *v1;  const float *w2, *bias2;
+    const float *g2, *be2, *m2, *v2;  const float *w3, *bias3;
+    float bn_eps;
+    float *r;  int r_stride;
+    const int *idx;  const int *cnt;  int n;           /* this node's sample list / capacity */
+    int *child_idx[MPNN_MAX_SINKS];  int *child_cnt[MPNN_MAX_SINKS];
+} mpnn_exit_ev_args;
+int mpnn_exit_ev(const mpnn_exit_ev_args *dev_table, int count, int n_max, void *stream);
+int mpnn_exit_ev_check(const mpnn_exit_ev_args *host_record);
+
 /* ---- the router: routing probabilities, costs and their gradients ----------
  * Replaces ActorNet._route/_route_sinks_dyn + cost assembly
  * (net_types.py:108-131,165-177), CriticNet's (net_types.py:193-243,273-280)
@@ -287,8 +334,6 @@ int mpnn_exit_tail_bwd(const mpnn_exit_tail_bwd_args *dev_table, int count, int 
 #define MPNN_HYP_KCRE 6
 #define MPNN_HYP_ARTR 7
 #define MPNN_HYP_N    16
-#define MPNN_MAX_NODES 128
-#define MPNN_MAX_SINKS 4
 typedef struct {
     int net_type;  int n_nodes, n_leaves, n_switches, max_sinks;
     int optimistic, use_cls_err, want_grad;

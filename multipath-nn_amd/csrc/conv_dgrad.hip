@@ -15,7 +15,7 @@ int mpnn_fill_dgrad_horz(const mpnn_dgrad_horz_args *a, ConvP &p) {
     p.a.x = a->g;  p.a.C = a->Cg;  p.a.mode = MPNN_ACT_IDENTITY;  p.a.shift = 0;
     p.wa = a->w_pack;
     p.n = a->n;  p.H = a->H;  p.W = a->W;  p.Cout = a->Cout;
-    p.extra = a->dy_extra;  p.out = a->out;
+    p.extra = a->dy_extra;  p.out = a->out;  p.acc_out = a->accumulate ? 1 : 0;
     if (a->prev) {
         if (!a->prev->s || !a->red_out) return MPNN_E_ARG;
         p.sprev = a->prev->s;  p.pbn = a->prev->bn;  p.red_out = a->red_out;

@@ -9,6 +9,7 @@ extern "C" int mpnn_msconv_fwd(const mpnn_conv_fwd_args *a, void *stream) {
     ConvP p = {};
     const int rc = fill_fwd(a, p);
     if (rc) return rc;
+    if (a->idx || a->cnt) return MPNN_E_ARG;          // index lists: mpnn_msconv_fwd_group (device-side records)
     return conv_launch<EPI_FWD>(p, (hipStream_t)stream);
 }
 
@@ -30,6 +31,11 @@ __host__ __device__ static inline int fill_fwd(const mpnn_conv_fwd_args *a, Conv
     p.bias = a->bias;  p.out = a->out;  p.out_sum = a->out_sum;  p.pool_out = a->pool_out;
     p.out_nslot = a->out_nslot < 1 ? 1 : (a->out_nslot > MPNN_BN_SLOTS ? MPNN_BN_SLOTS : a->out_nslot);
     if (a->pool_out && (a->H < 8 || (a->H & 1) || (a->W & 1))) return MPNN_E_SHAPE;
+    p.idx = a->idx;
+    if (a->idx && !a->cnt) return MPNN_E_ARG;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (a->cnt) { const int c = *a->cnt; p.n = c < a->n ? c : a->n; }     // device-side count of the routed sub-batch
+#endif
     return 0;
 }
 
@@ -37,7 +43,8 @@ __host__ __device__ static inline int fill_fwd(const mpnn_conv_fwd_args *a, Conv
 // argument array with a runtime member index makes hipcc copy the whole argument block to scratch.
 // SMALL = some member has a 1- or 3-channel operand A (block 0).  Groups without one run an
 // instantiation that omits those bodies: 128 instead of 160 VGPRs, i.e. 4 instead of 3 waves per SIMD.
-template <bool SMALL>
+// IDX = the members carry index lists (routed evaluation): the same bodies with the image indirection.
+template <bool SMALL, bool IDX>
 __global__ __launch_bounds__(256, SMALL ? 3 : MPNN_OCC) void fwd_group_k(const mpnn_conv_fwd_args *__restrict__ tab, const FwdGroupP q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // sized by the host for the members present
     // 1-D grid with exactly the workgroups that have work (a 2-D grid padded to the widest member
@@ -51,14 +58,14 @@ __global__ __launch_bounds__(256, SMALL ? 3 : MPNN_OCC) void fwd_group_k(const m
     ConvP p = {};
     fill_fwd(tab + m, p);
     switch (kind) {
-        case 0: p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
-        case 2: p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
-        case 4: p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, false, EPI_FWD>(p, bx, yy, gx, smem); break;
+        case 0: p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
+        case 2: p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
+        case 4: p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
         default:
             if constexpr (SMALL) {
-                if (kind == 1)      { p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); }
-                else if (kind == 3) { p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); }
-                else                { p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, true, EPI_FWD>(p, bx, yy, gx, smem); }
+                if (kind == 1)      { p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, true, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); }
+                else if (kind == 3) { p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, true, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); }
+                else                { p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, true, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); }
             }
             break;
     }
@@ -82,10 +89,13 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
     FwdGroupP q = {};
     ConvP hp[4] = {};
     int rows = 0, gxm = 0;
+    bool any_idx = false;
     for (int k = 0; k < count; ++k) {
         ConvP &p = hp[k];
         int rc = fill_fwd(&args[k], p);
         if (rc) return rc;
+        if ((args[k].idx != nullptr) != (args[0].idx != nullptr)) return MPNN_E_ARG;    // all members routed, or none
+        any_idx = any_idx || args[k].idx;
         if (p.n <= 0 || (p.Cout % 16) || p.a.C > 128 || p.Cv > 128 || (p.Cv & 3)) return MPNN_E_SHAPE;
         q.small[k] = p.a.C <= 4;
         if (!q.small[k] && (p.a.C & 3)) return MPNN_E_SHAPE;
@@ -105,7 +115,7 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
     // a single deep member on a small map: 128-256 workgroups of 4 waves would leave every SIMD with one
     // wave and nothing to overlap -> K-split body (two thread groups per workgroup, 32-channel units)
     static const int ks_env = [] { const char *e = getenv("MPNN_FWD_KSPLIT"); return e ? atoi(e) : 1; }();
-    if (ks_env && count == 1 && q.gk[0] != 0 && !q.small[0] && (hp[0].a.C % 32) == 0 && (hp[0].Cv % 32) == 0 &&
+    if (ks_env && !any_idx && count == 1 && q.gk[0] != 0 && !q.small[0] && (hp[0].a.C % 32) == 0 && (hp[0].Cv % 32) == 0 &&
         hp[0].a.C + hp[0].Cv >= 64) {
         const int gy = q.gy[0];
         int gx = hp[0].n_tiles;
@@ -118,7 +128,9 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
     }
     bool any_small = false;
     for (int k = 0; k < count; ++k) any_small = any_small || q.small[k];
-    void (*kern)(const mpnn_conv_fwd_args *, const FwdGroupP) = any_small ? fwd_group_k<true> : fwd_group_k<false>;
+    void (*kern)(const mpnn_conv_fwd_args *, const FwdGroupP) =
+        any_idx ? (any_small ? fwd_group_k<true, true> : fwd_group_k<false, true>)
+                : (any_small ? fwd_group_k<true, false> : fwd_group_k<false, false>);
     const long slots = resident_slots((const void *)kern, lds);
     // work of a member = tile-rows x units per tile (16-channel chunks of both operands)
     long total = 0, work[4];

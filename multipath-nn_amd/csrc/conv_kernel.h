@@ -46,6 +46,11 @@ struct ConvP {
     const float *ga_s;  mpnn_act ga_bn;  const double *ga_red;  int ga_nslot;  int ga_on;
     int n_tiles;                                            // set by the launcher
     int dbg;                                                // ablation mask (MPNN_CONV_DBG), 0 in production
+    // Routed evaluation (IDX bodies): sample slot s of this launch is image idx[s] of EVERY buffer
+    // (inputs, outputs, pooled map); `n` is then the device-side count of slots.  The gather and the
+    // scatter are this indirection in the tile loader and the epilogue: no sub-batch is materialised.
+    const int *idx;
+    int acc_out;                                            // EPI_DGH_*: out += result (several child blocks)
 };
 
 // Geometry kinds.  TH x TW output pixels per image x IMG images = 64 pixels;
@@ -241,13 +246,25 @@ template <int GK, bool SHIFTED> struct TileGeo {
     int pixs[SHIFTED ? N : 1];        // the same in the un-subsampled pyramid input (ToPyramid's pick)
     unsigned inb;                     // bit k: pixel inside the image and the batch
 };
+// Image of slot `img` of a tile: a mask select over the (uniform) table im[] -- a `?:` chain on a
+// lane-varying index was compiled to a scratch-memory table.
+template <int IMG>
+__device__ __forceinline__ int pick_img(const int *im, int img) {
+    int r = im[0];
+#pragma unroll
+    for (int j = 1; j < IMG; ++j) { const int m = -(int)(img == j); r = (r & ~m) | (im[j] & m); }
+    return r;
+}
+// im != nullptr (routed evaluation): im[j] = image behind slot n0 + j of the tile.
 template <int GK, bool SHIFTED>
-__device__ __forceinline__ void tile_geo(TileGeo<GK, SHIFTED> &tg, const ItemK<GK> &ik, const ConvP &p, int n0, int y0, int x0) {
+__device__ __forceinline__ void tile_geo(TileGeo<GK, SHIFTED> &tg, const ItemK<GK> &ik, const ConvP &p, int n0, int y0, int x0,
+                                         const int *im = nullptr) {
     tg.inb = 0;
 #pragma unroll
     for (int k = 0; k < ItemK<GK>::N; ++k) {
-        const int n = n0 + (ik.geo[k] >> 16), y = y0 + ((ik.geo[k] >> 8) & 255) - 1, x = x0 + (ik.geo[k] & 255) - 1;
-        const bool ok = ((ik.ok >> k) & 1) && n < p.n && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const int slot = n0 + (ik.geo[k] >> 16), y = y0 + ((ik.geo[k] >> 8) & 255) - 1, x = x0 + (ik.geo[k] & 255) - 1;
+        const bool ok = ((ik.ok >> k) & 1) && slot < p.n && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const int n = im ? pick_img<Geom<GK>::IMG>(im, ik.geo[k] >> 16) : slot;
         tg.pix[k] = ok ? (n * p.H + y) * p.W + x : 0;
         if (SHIFTED) {
             const int sh = p.a.shift;
@@ -359,9 +376,11 @@ struct ConvSmem {
 // KSPLIT (with NCH == 2, 512 threads): the workgroup's two 256-thread halves each stage and multiply ONE
 // of the unit's two chunks; their partial sums meet in LDS when a tile is finished.  For the deep 4x4 /
 // 8x8 layers, whose 128-256 workgroups otherwise leave one wave per SIMD with nothing to overlap.
-template <int GK, int MT, int NT, int WM, int WN, bool SMALL_A, int EPI, int NCH = 1, bool KSPLIT = false>
+// IDX (forward only): routed evaluation -- the tile's image slots go through p.idx (see ConvP).
+template <int GK, int MT, int NT, int WM, int WN, bool SMALL_A, int EPI, int NCH = 1, bool KSPLIT = false, bool IDX = false>
 __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const int by, const int gx, char *smem) {
     static_assert(!KSPLIT || (NCH == 2 && MT == 1 && NT == 1 && !SMALL_A && EPI == EPI_FWD), "K-split: forward, 32-channel units");
+    static_assert(!IDX || (EPI == EPI_FWD && !KSPLIT), "index lists: forward bodies of the evaluation path");
     constexpr int SC = KSPLIT ? 1 : NCH;            // chunks staged / multiplied by ONE thread group per unit
     using G = Geom<GK>;
     constexpr int P = G::P, R = G::R, HR = G::TH + 2;
@@ -416,7 +435,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         return tap * 16 * p.Cout * nch + (gg * p.Cout + co0 + c4) * 4;
     };
     // The unit sequence is generated incrementally (no divisions): chunk, then operand part, then tile.
-    struct UI { int t, part, ch, np, n0, y0, x0; unsigned inb; };
+    struct UI { int t, part, ch, np, n0, y0, x0; unsigned inb; int im[IDX ? G::IMG : 1]; };
     TileGeo<GK, SMALL_A> tgeo;                       // geometry of the tile the generator stands on
     UI gen = {};
     const int aC = p.a.C, vC = p.Cv;
@@ -428,6 +447,11 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     auto gen_tile = [&](UI &r, int t) {
         r.t = t; r.part = 0; r.ch = 0;
         tile_origin<GK>(p, t, r.n0, r.y0, r.x0);
+        if constexpr (IDX) {                         // (uniform loads; slots past the count read slot 0 and are masked)
+#pragma unroll
+            for (int j = 0; j < G::IMG; ++j) r.im[j] = p.idx[r.n0 + j < p.n ? r.n0 + j : 0];
+            tile_geo<GK, SMALL_A>(tgeo, ik, p, r.n0, r.y0, r.x0, r.im);
+        } else
         tile_geo<GK, SMALL_A>(tgeo, ik, p, r.n0, r.y0, r.x0);
         r.inb = tgeo.inb;
         set_np(r);
@@ -662,8 +686,10 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                 for (int r = 0; r < 4; ++r) {
                     int img, ty, tx;
                     mtile_pix<GK>(wm * MT + mt, g * 4 + r, img, ty, tx);
-                    const int n = n0 + img, y = y0 + ty, x = x0 + tx;
-                    if (n >= p.n || kg != 0) continue;
+                    const int y = y0 + ty, x = x0 + tx;
+                    if (n0 + img >= p.n || kg != 0) continue;
+                    int n = n0 + img;
+                    if constexpr (IDX) n = pick_img<G::IMG>(cu.im, img);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const int co = cw + nt * 16;
@@ -678,6 +704,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                         } else if (EPI == EPI_DGH_RAW) {
                             const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
                             if (p.extra) val += p.extra[idx];
+                            if (p.acc_out) val += p.out[idx];
                             p.out[idx] = val;
                         } else if (EPI == EPI_DGH_BN) {
                             const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
@@ -686,7 +713,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                             const float d = p.sprev[idx] - e[0];
                             const float yv = d * e[2] + e[3];
                             const float dz = yv > 0.f ? val : 0.f;
-                            p.out[idx] = dz;
+                            p.out[idx] = p.acc_out ? p.out[idx] + dz : dz;
                             s1[nt] += dz; s2[nt] += dz * (d * e[1]);
                         } else {  // EPI_DGV: val = d(pooled fine map) at coarse pixel (y, x)
                             const float *e = cE + cl * 5;
@@ -723,7 +750,8 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                         const int c = e % CT, pp = e / CT, py = pp / TWp, px = pp - py * TWp;
                         const float *q0 = pool_lds + ((2 * py) * ROW + 2 * px) * CT + c;
                         const float m4 = fmaxf(fmaxf(q0[0], q0[CT]), fmaxf(q0[ROW * CT], q0[ROW * CT + CT]));
-                        p.pool_out[(((size_t)n0 * H2 + (y0 >> 1) + py) * W2 + (x0 >> 1) + px) * p.Cout + co0 + c] = m4;
+                        const int np0 = IDX ? cu.im[0] : n0;          // (one image per tile in these geometries)
+                        p.pool_out[(((size_t)np0 * H2 + (y0 >> 1) + py) * W2 + (x0 >> 1) + px) * p.Cout + co0 + c] = m4;
                     }
                 }
             }

@@ -1,0 +1,224 @@
+// mpnn_exit_ev: one exit of the routing tree in EVALUATION mode, fused, for any batch size.
+//
+//   head   : Select(-1) -> LinTrans -> Softmax -> CrossEntropyError      (arch_and_hypers.py:66-70,
+//            layer_types.py:39-53, 81-84, 262-272)
+//   router : Select(-1) -> LinTrans(R) -> BN -> ReLU -> LinTrans(R) -> BN -> ReLU -> LinTrans(n_sinks)
+//            (arch_and_hypers.py:45-49) with MOVING-AVERAGE BatchNorm (layer_types.py:237-238)
+//   routing: pi_ev = one-hot(arg-max r), first index on ties (net_types.py:127-129)
+//
+// In 'ev' mode every sample is independent (no batch statistics), so a workgroup owns 16 samples
+// end to end: the two affine maps over the block's coarsest scale (BatchNorm + ReLU applied on
+// load) run on v_mfma_f32_16x16x4_f32 with K split over 16 waves, the partial tiles meet in LDS,
+// and 16 threads finish one sample each.  No 128-sample cap (mpnn_exit_tail_fwd needs the whole
+// batch in one workgroup for its batch statistics; this kernel does not).
+//
+// Routed evaluation: the launch works on the sample list idx[0..*cnt) of its node (device-side
+// count) and APPENDS every sample to the list of the child it is routed to: wave64 ballot of
+// `arg-max == sink`, popcount prefix for the rank inside the wave, ONE atomicAdd per (wave, sink)
+// to reserve the range.  Nothing returns to the host; the child's launches read the count on the
+// device.  The order of a list depends on workgroup timing; results do not (every sample's
+// arithmetic is independent of its slot).
+#include "common.h"
+
+#define EV_WAVES 16
+#define TR 16          // max router width
+#define TS MPNN_MAX_SINKS
+#define TC 16          // max classes
+
+__global__ __launch_bounds__(EV_WAVES * 64) void exit_ev_k(const mpnn_exit_ev_args *__restrict__ tab) {
+    const mpnn_exit_ev_args &a = tab[blockIdx.y];
+    int n = a.n;
+    if (a.cnt) { const int c = *a.cnt; n = c < n ? c : n; }
+    const int n0 = blockIdx.x * 16;
+    if (n0 >= n) return;
+    __shared__ float cA[128 * 3];
+    __shared__ float red[EV_WAVES * 2 * 256];
+    __shared__ float zs[16 * TC], hs[16 * TR];
+    __shared__ float w2s[TR * TR], w3s[TR * TS], vec[9 * TR + TS];
+    __shared__ int img_s[16];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.a.C, K = a.HW * C;
+    const bool bn = a.a.mode != MPNN_ACT_IDENTITY;
+    const bool has_head = a.w_head != nullptr, has_router = a.w1 != nullptr;
+    const int R = has_router ? a.R : 0, S = has_router ? a.n_sinks : 0;
+    if (bn) {
+        for (int c = tid; c < C; c += EV_WAVES * 64) {
+            const BnC k = bn_coef(a.a, c);
+            cA[c * 3] = k.m; cA[c * 3 + 1] = k.gamma * k.rstd; cA[c * 3 + 2] = k.beta;
+        }
+    }
+    if (tid < 16) img_s[tid] = n0 + tid < n ? (a.idx ? a.idx[n0 + tid] : n0 + tid) : -1;
+    // router tail parameters -> LDS (requested now, used after the affine maps)
+    if (has_router) {
+        if (tid < TR * TR) { const int c = tid / TR, j = tid & (TR - 1); w2s[tid] = (c < R && j < R) ? a.w2[c * R + j] : 0.f; }
+        else if (tid < TR * TR + TR * TS) {
+            const int i = tid - TR * TR, c = i / TS, k = i % TS;
+            w3s[i] = (c < R && k < S) ? a.w3[c * S + k] : 0.f;
+        } else if (tid < TR * TR + TR * TS + TR) {
+            const int c = tid - TR * TR - TR * TS;
+            const bool ok = c < R;
+            // BatchNorm with moving averages folded to scale/shift: y = k*(x - m) + beta
+            const float k1 = ok ? a.g1[c] * rsqrtf(a.v1[c] + a.bn_eps) : 0.f, k2 = ok ? a.g2[c] * rsqrtf(a.v2[c] + a.bn_eps) : 0.f;
+            vec[c] = k1; vec[TR + c] = ok ? a.m1[c] : 0.f; vec[2 * TR + c] = ok ? a.be1[c] : 0.f;
+            vec[3 * TR + c] = k2; vec[4 * TR + c] = ok ? a.m2[c] : 0.f; vec[5 * TR + c] = ok ? a.be2[c] : 0.f;
+            vec[6 * TR + c] = ok ? a.bias2[c] : 0.f;
+            vec[7 * TR + c] = ok ? a.b1[c] : 0.f;
+            vec[8 * TR + c] = (ok && a.extra_col) ? a.w1[(size_t)K * R + c] : 0.f;
+            if (c < TS) vec[9 * TR + c] = c < S ? a.bias3[c] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int img = img_s[li];
+    const bool valid = img >= 0;
+    const int M0 = has_head ? a.n_cls : 0, M1 = R;
+    const float *xrow = a.a.x + (size_t)(valid ? img : 0) * K;
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    // two 16-feature blocks per iteration: their loads are in flight together
+    for (int kb = wid * 2; kb < (K >> 4); kb += EV_WAVES * 2) {
+        f32x4 x[2];
+        float b0[2][4], b1[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kk = kb + u < (K >> 4) ? kb + u : kb;           // (K/16 odd: the second block repeats the first, masked below)
+            const int k = kk * 16 + 4 * g;
+            x[u] = *(const f32x4 *)(xrow + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                b0[u][j] = li < M0 ? a.w_head[(size_t)(k + j) * M0 + li] : 0.f;
+                b1[u][j] = li < M1 ? a.w1[(size_t)(k + j) * M1 + li] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bool on = valid && kb + u < (K >> 4);
+            const int k = (kb + u) * 16 + 4 * g;
+            if (bn) {
+                const int c = k % C;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float *cc = cA + (c + j) * 3;
+                    x[u][j] = fmaxf((x[u][j] - cc[0]) * cc[1] + cc[2], 0.f);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xv = on ? x[u][j] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, b0[u][j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, b1[u][j], acc1, 0, 0, 0);
+            }
+        }
+    }
+    mfma_drain();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[(wid * 2 + 0) * 256 + lane * 4 + r] = acc0[r];
+        red[(wid * 2 + 1) * 256 + lane * 4 + r] = acc1[r];
+    }
+    __syncthreads();
+    if (tid < 512) {                         // (set, lane, r): D row = 4*(lane>>4) + r (sample), col = lane & 15 (output)
+        const int s = tid >> 8, e = tid & 255, l = e >> 2, r = e & 3;
+        const int row = (l >> 4) * 4 + r, col = l & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < EV_WAVES; ++w) v += red[(w * 2 + s) * 256 + e];
+        if (s == 0) zs[row * TC + col] = (has_head && col < M0) ? v + a.b_head[col] : 0.f;
+        else hs[row * TR + col] = col < M1 ? v : 0.f;          // (bias and k_cpt column: in the tail, from LDS)
+    }
+    __syncthreads();
+    if (tid >= 64) return;                   // wave 0: one sample per lane (lanes 0..15)
+    const bool mine = tid < 16 && img_s[tid < 16 ? tid : 0] >= 0;
+    const int my = mine ? img_s[tid] : 0;
+    if (has_head && mine) {
+        const int nc = a.n_cls;
+        float z[TC], p[TC];
+#pragma unroll
+        for (int k = 0; k < TC; ++k) z[k] = zs[tid * TC + k];
+        float mx = z[0];
+#pragma unroll
+        for (int k = 1; k < TC; ++k) if (k < nc) mx = fmaxf(mx, z[k]);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < TC; ++k) { p[k] = k < nc ? expf(z[k] - mx) : 0.f; sum += p[k]; }
+        const float inv = 1.f / sum;
+        float ce = 0.f, pmax = 0.f, ymax = 0.f; int ap = 0, ay = 0;
+#pragma unroll
+        for (int k = 0; k < TC; ++k) {
+            if (k < nc) {
+                const float pk = p[k] * inv, yk = a.y[(size_t)my * nc + k];
+                ce -= yk * logf(a.eps_ce / (float)nc + (1.f - a.eps_ce) * pk);
+                if (k == 0 || pk > pmax) { pmax = pk; ap = k; }
+                if (k == 0 || yk > ymax) { ymax = yk; ay = k; }
+            }
+        }
+        a.c_err[my] = ce;
+        a.d_cor[my] = ap == ay ? 1.f : 0.f;
+    }
+    if (!has_router) return;
+    int arg = 0;
+    if (mine) {
+        const float kc = a.extra_col ? a.alpha_cpt * a.k_cpt[my] : 0.f;
+        float a1[TR];
+#pragma unroll
+        for (int c = 0; c < TR; ++c) {
+            const float h1 = hs[tid * TR + c] + vec[7 * TR + c] + kc * vec[8 * TR + c];
+            a1[c] = fmaxf(vec[c] * (h1 - vec[TR + c]) + vec[2 * TR + c], 0.f);
+        }
+        float a2[TR];
+#pragma unroll
+        for (int j = 0; j < TR; ++j) {
+            float h = vec[6 * TR + j];
+#pragma unroll
+            for (int c = 0; c < TR; ++c) h += a1[c] * w2s[c * TR + j];
+            a2[j] = fmaxf(vec[3 * TR + j] * (h - vec[4 * TR + j]) + vec[5 * TR + j], 0.f);
+        }
+        float rmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < TS; ++i) {
+            float r = vec[9 * TR + i];
+#pragma unroll
+            for (int c = 0; c < TR; ++c) r += a2[c] * w3s[c * TS + i];
+            if (i < S) {
+                a.r[(size_t)my * a.r_stride + i] = r;
+                if (i == 0 || r > rmax) { rmax = r; arg = i; }       // first index on ties (tf.argmax)
+            }
+        }
+    }
+    // ---- compaction into the children's lists: ballot + popcount prefix, one atomic per (wave, sink) ----
+#pragma unroll
+    for (int i = 0; i < TS; ++i) {
+        if (i >= S || !a.child_idx[i]) continue;                    // uniform
+        const unsigned long long m = __ballot(mine && arg == i);
+        if (!m) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.child_cnt[i], (int)__popcll(m));
+        base = __shfl(base, 0);
+        if (mine && arg == i) a.child_idx[i][base + __popcll(m & ((1ull << lane) - 1ull))] = my;
+    }
+}
+
+extern "C" int mpnn_exit_ev(const mpnn_exit_ev_args *dev_table, int count, int n_max, void *stream) {
+    if (count <= 0 || n_max <= 0) return 0;
+    if (!dev_table) return MPNN_E_ARG;
+    hipLaunchKernelGGL(exit_ev_k, dim3((n_max + 15) / 16, count), dim3(EV_WAVES * 64), 0, (hipStream_t)stream, dev_table);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Host-side check of one record against the kernel's compile-time limits (the table itself lives in
+// device memory, so the caller validates each record before uploading it).
+extern "C" int mpnn_exit_ev_check(const mpnn_exit_ev_args *host_rec) {
+    if (!host_rec || !host_rec->a.x) return MPNN_E_ARG;
+    const mpnn_exit_ev_args &a = *host_rec;
+    if (a.a.C > 128 || a.a.C <= 0 || (a.a.C & 3) || ((a.HW * a.a.C) & 15)) return MPNN_E_SHAPE;
+    if (a.w_head && (a.n_cls < 1 || a.n_cls > TC || !a.b_head || !a.y || !a.c_err || !a.d_cor)) return a.n_cls > TC ? MPNN_E_SHAPE : MPNN_E_ARG;
+    if (a.w1) {
+        if (a.R < 1 || a.R > TR || a.n_sinks < 2 || a.n_sinks > TS) return MPNN_E_SHAPE;
+        if (!a.b1 || !a.g1 || !a.be1 || !a.m1 || !a.v1 || !a.w2 || !a.bias2 || !a.g2 || !a.be2 || !a.m2 || !a.v2 ||
+            !a.w3 || !a.bias3 || !a.r || a.r_stride < a.n_sinks) return MPNN_E_ARG;
+        if (a.extra_col && !a.k_cpt) return MPNN_E_ARG;
+        for (int i = 0; i < TS; ++i) if ((a.child_idx[i] != nullptr) != (a.child_cnt[i] != nullptr)) return MPNN_E_ARG;
+    }
+    if (a.idx && !a.cnt) return MPNN_E_ARG;
+    return 0;
+}

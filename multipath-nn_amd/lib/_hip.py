@@ -27,7 +27,7 @@ class Act(C.Structure):
 class ConvFwdArgs(C.Structure):
     _fields_ = [('a', Act), ('v', P), ('Cv', C.c_int), ('wa_pack', P), ('wv_pack', P), ('bias', P),
                 ('out', P), ('pool_out', P), ('out_sum', P), ('out_nslot', C.c_int), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int),
-                ('Cout', C.c_int)]
+                ('Cout', C.c_int), ('idx', P), ('cnt', P)]
 
 
 class BnCtx(C.Structure):
@@ -37,7 +37,8 @@ class BnCtx(C.Structure):
 class DgradHorzArgs(C.Structure):
     _fields_ = [('g', P), ('Cg', C.c_int), ('g_ctx', C.POINTER(BnCtx)), ('w_pack', P), ('dy_extra', P),
                 ('prev', C.POINTER(BnCtx)),
-                ('out', P), ('red_out', P), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int)]
+                ('out', P), ('red_out', P), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int),
+                ('accumulate', C.c_int)]
 
 
 class DgradVertArgs(C.Structure):
@@ -79,6 +80,18 @@ class ExitTailBwdArgs(C.Structure):
                 ('dw3', P), ('dbias3', P)]
 
 
+class ExitEvArgs(C.Structure):
+    _fields_ = [('a', Act), ('HW', C.c_int), ('w_head', P), ('b_head', P), ('n_cls', C.c_int), ('y', P),
+                ('eps_ce', C.c_float), ('c_err', P), ('d_cor', P),
+                ('w1', P), ('b1', P), ('R', C.c_int), ('n_sinks', C.c_int),
+                ('extra_col', C.c_int), ('k_cpt', P), ('alpha_cpt', C.c_float),
+                ('g1', P), ('be1', P), ('m1', P), ('v1', P), ('w2', P), ('bias2', P),
+                ('g2', P), ('be2', P), ('m2', P), ('v2', P), ('w3', P), ('bias3', P),
+                ('bn_eps', C.c_float), ('r', P), ('r_stride', C.c_int),
+                ('idx', P), ('cnt', P), ('n', C.c_int),
+                ('child_idx', P * 4), ('child_cnt', P * 4)]
+
+
 class RouteArgs(C.Structure):
     _fields_ = [('net_type', C.c_int), ('n_nodes', C.c_int), ('n_leaves', C.c_int), ('n_switches', C.c_int),
                 ('max_sinks', C.c_int), ('optimistic', C.c_int), ('use_cls_err', C.c_int), ('want_grad', C.c_int),
@@ -110,6 +123,8 @@ _SIGS = {
     'mpnn_exit_tail_fwd': [P, C.c_int, C.c_int, P],
     'mpnn_exit_tail_bwd': [P, C.c_int, C.c_int, P],
     'mpnn_route': [C.POINTER(RouteArgs), P],
+    'mpnn_exit_ev': [P, C.c_int, C.c_int, P],
+    'mpnn_exit_ev_check': [C.POINTER(ExitEvArgs)],
     'mpnn_compact_by_branch': [P, C.c_int, P, P, P],
     'mpnn_bn_finalize': [P, P, P, P, P, C.c_int, C.c_float, C.c_int, P],
     'mpnn_talr_momentum_step': [P, P, P, P, C.c_int, P, P, C.c_int, C.c_float, C.c_float, P],

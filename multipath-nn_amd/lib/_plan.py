@@ -80,7 +80,7 @@ class Engine:
             device = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', '0'))
         self.dev = torch.device(device)
         torch.cuda.set_device(self.dev)
-        self.n_max = 0
+        self.n_max = self.n_max_bwd = 0
         self.use_graph = bool(int(os.environ.get('MPNN_GRAPH', '1')))     # hipGraph replay of the step (0: eager launches)
         self.multi_stream = bool(int(os.environ.get('MPNN_STREAMS', '0')))
         self.group_fwd = bool(int(os.environ.get('MPNN_FWD_GROUP', '1')))   # wavefront-grouped forward launches
@@ -173,29 +173,41 @@ class Engine:
                 b.Cin = [b.parent.C[j] for j in b.in_map]
             else:
                 raise NotImplementedError('block below a %s node' % par.kind)
-            b.child = None
-            b.heads = [self.nodes[nd.idx].layer]  # placeholder, replaced below
+            b.children = []
             nd.block = b
             self.blocks.append(b)
         for b in self.blocks:
             kids = [self.nodes_by_layer(s) for s in b.node.layer.sinks]
-            cb = [k.block for k in kids if k.kind == 'block']
-            if len(cb) > 1:
-                raise NotImplementedError('tree-structured nets (more than one child block) are a later row')
-            b.child = cb[0] if cb else None
+            b.children = [k.block for k in kids if k.kind == 'block']       # tree nets: several (arch_and_hypers.py:99-127)
+            b.sink_blocks = [k.block if k.kind == 'block' else None for k in kids]
             hs = [k for k in kids if k.kind == 'head']
             if len(hs) > 1:
                 raise NotImplementedError('more than one LogReg under a block')
             b.head = hs[0] if hs else None
             b.router = b.node.layer.router
             b.has_exit = b.head is not None or b.router is not None
-            # which scales' BN outputs are consumed (by the child block or the exit)
+            # which scales' BN outputs are consumed (by child blocks or the exit)
             b.has_dz = [False] * b.L
-            if b.child is not None:
-                for j in b.child.in_map:
+            for cb in b.children:
+                for j in cb.in_map:
                     b.has_dz[j] = True
             if b.has_exit:
                 b.has_dz[b.L - 1] = True
+            # compile-time limits of the exit kernels (exit_tail.hip, exit_ev.hip, lin.hip): beyond them
+            # the kernels would silently work on a prefix, so refuse here
+            if b.has_exit:
+                K = b.H[-1] * b.W[-1] * b.C[-1]
+                if b.C[-1] > 128 or K % 16:
+                    raise NotImplementedError('exit on a %dx%dx%d map: the exit kernels need C <= 128 and H*W*C %% 16 == 0'
+                                              % (b.H[-1], b.W[-1], b.C[-1]))
+                if b.head is not None and self.n_cls > 16:
+                    raise NotImplementedError('%d classes: the exit kernels hold at most 16' % self.n_cls)
+                if b.router is not None:
+                    widths = [b.router.comps[k].hypers.n_chan for k in (1, 4)]
+                    if widths[0] != widths[1] or widths[0] > 16:
+                        raise NotImplementedError('router widths %r: the exit kernels need two equal hidden layers of <= 16 units' % (widths,))
+                    if len(b.node.layer.sinks) > _hip.MAX_SINKS:
+                        raise NotImplementedError('more than %d sinks under one switch' % _hip.MAX_SINKS)
         for nd in self.nodes:
             if nd.kind == 'head' and self.nodes[nd.parent].kind != 'block':
                 raise NotImplementedError('LogReg must hang off a ReConvMax block')
@@ -308,7 +320,9 @@ class Engine:
         self.node_ops = torch.tensor(ops, dtype=torch.float32, device=dev)
         self.node_ops_host = ops
         self.hyp = torch.zeros(_hip.HYP_N, device=dev)
-        self.hyp_host = torch.zeros(_hip.HYP_N).pin_memory()
+        self._hyp_stage = torch.zeros(_hip.HYP_N)
+        self._hyp_ring = [(torch.zeros(_hip.HYP_N).pin_memory(), None) for _ in range(8)]
+        self._hyp_slot = -1
         self._hyp_sent = None
 
     def init_params(self, seed=None):
@@ -333,36 +347,62 @@ class Engine:
         self.A.zero_()
 
     # ------------------------------------------------------------------ buffers
-    def _ensure_capacity(self, n):
-        if n <= self.n_max:
-            return
-        self.n_max = n
-        self._progs.clear()
-        self._graphs.clear()
+    def _ensure_capacity(self, n, train=True):
+        """Device buffers for batches of up to n samples.  The evaluation path ('ev': forward only, any
+        batch size -- the statistics pass of scripts/lib/desc.py:10-22 feeds thousands of images per
+        launch) allocates only what a forward pass touches; the gradient buffers follow the largest
+        TRAINING batch seen."""
         dev = self.dev
         z = lambda *shape: torch.zeros(shape, device=dev)
-        h, w, c0 = self.x0_shape
-        self.x0 = z(n, h, w, c0)
-        self.y = z(n, self.n_cls)
-        self.k_cpt = z(n)
-        for b in self.blocks:
-            b.s = [z(n, b.H[i], b.W[i], b.C[i]) for i in range(b.L)]
-            b.dzg = [z(n, b.H[i], b.W[i], b.C[i]) for i in range(b.L)]
-            b.sp = [z(n, b.H[i] // 2, b.W[i] // 2, b.C[i]) for i in range(b.L - 1)]     # 2x2-max-pooled s
-            if b.has_exit:
-                K = b.H[-1] * b.W[-1] * b.C[-1]
-                b.dx = z(n, K)
-                b.z = z(n, self.n_cls) if b.head is not None else None
-                b.dzh = z(n, self.n_cls) if b.head is not None else None
-                if b.router is not None:
-                    R = b.router.comps[1].hypers.n_chan
-                    b.R = R
-                    b.h1, b.h2, b.dh1 = z(n, R), z(n, R), z(n, R)
-                    b.bn_save = z(4 * R)
-        nn, nl, ns = len(self.nodes), len(self.leaves), max(len(self.switches), 1)
-        self.p_tr, self.p_ev = z(nn * n), z(nn * n)
-        self.c_err, self.d_cor, self.w_cerr = z(nl * n), z(nl * n), z(nl * n)
-        self.r, self.dr = z(ns * n * self.max_sinks), z(ns * n * self.max_sinks)
+        if n > self.n_max:
+            if n * 32 * 32 * 128 >= 2 ** 31:
+                raise ValueError('batch of %d samples: the kernels index activations with 32-bit offsets' % n)
+            self.n_max = n
+            self._progs.clear()
+            self._graphs.clear()
+            self.n_max_bwd = 0
+            h, w, c0 = self.x0_shape
+            self.x0 = z(n, h, w, c0)
+            self.y = z(n, self.n_cls)
+            self.k_cpt = z(n)
+            for b in self.blocks:
+                b.s = [z(n, b.H[i], b.W[i], b.C[i]) for i in range(b.L)]
+                b.sp = [z(n, b.H[i] // 2, b.W[i] // 2, b.C[i]) for i in range(b.L - 1)]     # 2x2-max-pooled s
+                if b.has_exit:
+                    b.z = z(n, self.n_cls) if b.head is not None else None
+                    if b.router is not None:
+                        R = b.router.comps[1].hypers.n_chan
+                        b.R = R
+                        b.h1, b.h2 = z(n, R), z(n, R)
+                        b.bn_save = z(4 * R)
+            nn, nl, ns = len(self.nodes), len(self.leaves), max(len(self.switches), 1)
+            self.p_tr, self.p_ev = z(nn * n), z(nn * n)
+            self.w_cerr = z(nl * n)
+            self.dr = z(ns * n * self.max_sinks)
+            # One allocation that the evaluation path clears with the launch that packs the weights:
+            # loss sums | per-block sample counts of the routed evaluation | r | c_err | d_cor
+            # (routed evaluation only writes the entries of samples that REACH a node).
+            nb = (len(self.blocks) + 3) // 4 * 4
+            n_r, n_l = ns * n * self.max_sinks, nl * n
+            self._ev_arena = torch.zeros(32 + 4 * nb + 4 * ((n_r + 2 * n_l + 3) // 4 * 4), dtype=torch.uint8, device=dev)
+            self.loss_ev = self._ev_arena[:32].view(torch.float64)
+            self.ev_cnt = self._ev_arena[32:32 + 4 * nb].view(torch.int32)
+            fl = self._ev_arena[32 + 4 * nb:].view(torch.float32)
+            self.r, self.c_err, self.d_cor = fl[:n_r], fl[n_r:n_r + n_l], fl[n_r + n_l:n_r + 2 * n_l]
+            for k, b in enumerate(self.blocks):
+                b.ev_idx = torch.zeros(n, dtype=torch.int32, device=dev)     # samples routed to this block ('ev')
+                b.ev_cnt = self.ev_cnt[k:k + 1]
+        if train and n > self.n_max_bwd:
+            self.n_max_bwd = n
+            self._progs = {k: v for k, v in self._progs.items() if k[0] != 'tr'}
+            self._graphs = {k: v for k, v in self._graphs.items() if k[0] != 'tr'}
+            for b in self.blocks:
+                b.dzg = [z(n, b.H[i], b.W[i], b.C[i]) for i in range(b.L)]
+                if b.has_exit:
+                    b.dx = z(n, b.H[-1] * b.W[-1] * b.C[-1])
+                    b.dzh = z(n, self.n_cls) if b.head is not None else None
+                    if b.router is not None:
+                        b.dh1 = z(n, b.R)
 
     # ------------------------------------------------------------------ programs
     @staticmethod
@@ -414,11 +454,17 @@ class Engine:
         want = min(want, max(1, (12 << 20) // w_bytes))         # keep a layer's slab under ~12 MB
         return max(1, min(tiles, want))
 
-    def program(self, mode, n):
-        key = (mode, n, self.multi_stream, self.group_fwd)
+    def program(self, mode, n, routed=False):
+        """Launch lists of one (mode, batch size).  routed ('ev' only): the routed evaluation -- every
+        block runs on the sample list its parent's router produced on the device (see _program_ev)."""
+        routed = bool(routed) and mode != 'tr' and bool(self.switches) and self.net._net_kind != 'sr'
+        key = (mode, n, self.multi_stream, self.group_fwd, routed)
         if key in self._progs:
             return self._progs[key]
-        self._ensure_capacity(n)
+        self._ensure_capacity(n, mode == 'tr')
+        if mode != 'tr':
+            prog = self._progs[key] = self._program_ev(n, routed)
+            return prog
         lib, keep = self.lib, self._keep
         act_mode = _hip.ACT_BN_BATCH if mode == 'tr' else _hip.ACT_BN_MOVING
         net, kind = self.net, self.net._net_kind
@@ -526,7 +572,7 @@ class Engine:
             lf.k_cpt = lb.k_cpt = self.k_cpt.data_ptr()
             lf.alpha_cpt = lb.alpha_cpt = float(_attr(ϕ, 'α_cpt', 0.0))
             lb.dx = b.dx.data_ptr()
-            if mode == 'tr' and b.child is None and not self.multi_stream:
+            if mode == 'tr' and not b.children and not self.multi_stream:
                 # the exit's dX is the only gradient of this map: lin_bwd masks it and accumulates the
                 # BatchNorm-backward reductions itself (no mpnn_bn_bwd_reduce launch)
                 lb.dx = None
@@ -582,21 +628,7 @@ class Engine:
             fwd.append(call(lib.mpnn_exit_tail_fwd, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n))
 
         # ---- route ----
-        ra = _hip.RouteArgs()
-        ra.net_type = {'sr': _hip.NET_SR, 'actor': _hip.NET_ACTOR, 'critic': _hip.NET_CRITIC}[kind]
-        ra.n_nodes, ra.n_leaves, ra.n_switches, ra.max_sinks = len(self.nodes), len(self.leaves), len(self.switches), MS
-        ra.optimistic = int(bool(getattr(ϕ, 'optimistic', False)))
-        ra.use_cls_err = int(bool(getattr(ϕ, 'use_cls_err', False)))
-        ra.want_grad = 1 if mode == 'tr' else 0
-        ra.nodes, ra.sw_children, ra.node_ops = self.node_tab.data_ptr(), self.kid_tab.data_ptr(), self.node_ops.data_ptr()
-        ra.hyp = self.hyp.data_ptr()
-        ra.k_cpt_vec = self.k_cpt.data_ptr() if dyn else None
-        ra.r, ra.c_err, ra.d_cor = self.r.data_ptr(), self.c_err.data_ptr(), self.d_cor.data_ptr()
-        ra.p_tr, ra.p_ev, ra.w_cerr, ra.dr = self.p_tr.data_ptr(), self.p_ev.data_ptr(), self.w_cerr.data_ptr(), self.dr.data_ptr()
-        ra.node_stat = self.node_stat.data_ptr() if mode == 'tr' else None
-        ra.loss = self.loss.data_ptr()
-        ra.n, ra.n_total = n, n
-        keep.append(ra)
+        ra = self._route_args(n, mode, self.loss)
         fwd.append(call(lib.mpnn_route, 'route', C.byref(ra)))
 
         prog = dict(fwd=fwd, bwd=bwd, n=n, mode=mode)
@@ -610,11 +642,12 @@ class Engine:
             bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
             bwd.append(call(lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
         bwd.append(marker('fork'))
+        dz_written = set()
         for b in reversed(self.blocks):
             cp = b.conv.params
             L1 = b.L - 1
             # coarsest scale without a child block: its dy is the exit's dX alone
-            if b.child is None and (self.multi_stream or not b.has_exit):
+            if not b.children and (self.multi_stream or not b.has_exit):
                 ctx = self._bn_ctx(b, L1, n, with_red=False)
                 bwd.append(call(lib.mpnn_bn_bwd_reduce, 'bn_bwd_reduce', b.dx.data_ptr(), C.byref(ctx),
                                 b.dzg[L1].data_ptr(), self.dred[b.sum_off[L1]:].data_ptr(),
@@ -650,7 +683,12 @@ class Engine:
                 if i == L1 and g_ctx is not None:
                     a.g_ctx = g_ctx
                 a.w_pack = self.packs[b.pack['w_horz_%i' % i][1]:].data_ptr()
-                a.dy_extra = pb.dx.data_ptr() if (pb.has_exit and j == pb.L - 1) else None
+                # a map that feeds several child blocks (tree nets): the first child to run writes it
+                # (with the exit's dX), the others add their masked share
+                first = (id(pb), j) not in dz_written
+                dz_written.add((id(pb), j))
+                a.accumulate = 0 if first else 1
+                a.dy_extra = pb.dx.data_ptr() if (first and pb.has_exit and j == pb.L - 1) else None
                 prev = self._bn_ctx(pb, j, n, with_red=False)
                 a.prev = C.pointer(prev)
                 a.out = pb.dzg[j].data_ptr()
@@ -739,12 +777,185 @@ class Engine:
                             self.bn_decay, n))
         return prog
 
+    # ------------------------------------------------------------------ evaluation programs
+    def _groupable(self):
+        return all(c % 16 == 0 and not (c % 64 == 0 and h >= 16) for b in self.blocks for c, h in zip(b.C, b.H))
+
+    def _program_ev(self, n, routed):
+        """Forward-only program in evaluation mode (BatchNorm moving averages, layer_types.py:237-238;
+        hard routing pi_ev, net_types.py:127-131).
+
+        dense : the reference's schedule -- every block on every sample (11 wavefront launches), then
+                ONE mpnn_exit_ev launch for all exits and mpnn_route for p_ev / p_tr.
+        routed: the reference multiplies 0/1 masks p_ev into the statistics and still evaluates every
+                block densely; here a block only runs on the samples its ancestors' routers sent to it.
+                Per tree depth: the block's convs gather their inputs through the block's sample list
+                (mpnn_conv_fwd_args.idx/cnt: indirection in the tile loader, results land at the
+                samples' own rows), then mpnn_exit_ev evaluates head + router on that list and appends
+                each sample to the list of the child it is routed to (wave ballot + prefix sum, count
+                on the device).  No host sync anywhere; mpnn_route at the end reads the (cleared,
+                then sparsely written) r / c_err / d_cor and produces the same p_ev as the dense pass.
+        """
+        lib, keep = self.lib, self._keep
+        net, kind = self.net, self.net._net_kind
+        ϕ = net.hypers
+        act_mode = _hip.ACT_BN_MOVING
+        fwd = []
+        if not self._groupable():
+            raise NotImplementedError('evaluation programs need 16-channel-tile geometries')
+
+        def call(fn, what, *args, flops=0.0, tag=''):
+            def launch(st):
+                _hip.check(fn(*args, st), what)
+            launch.what, launch.flops, launch.tag = what, float(flops), tag
+            launch.stream, launch.waits, launch.records = 0, (), None
+            launch.args = args
+            return launch
+
+        depth = {}
+        for b in self.blocks:
+            depth[id(b)] = 0 if b.parent is None else depth[id(b.parent)] + 1
+        # sample lists: a block below a dynamic switch owns one; below a static node it shares its parent's
+        for b in self.blocks:
+            par = b.parent
+            if not routed or par is None:
+                b.ev_list = None
+            elif par.router is not None:
+                b.ev_list = (b.ev_idx, b.ev_cnt)
+            else:
+                b.ev_list = par.ev_list
+
+        def fwd_args(b, i, a):
+            cp = b.conv.params
+            a.a = self._act_of_input(b, i, n, act_mode)
+            if i > 0:
+                a.v, a.Cv = b.sp[i - 1].data_ptr(), b.C[i - 1]
+                a.wv_pack = self.packs[b.pack['w_vert_%i' % (i - 1)][0]:].data_ptr()
+            if i < b.L - 1:
+                a.pool_out = b.sp[i].data_ptr()
+            a.wa_pack = self.packs[b.pack['w_horz_%i' % i][0]:].data_ptr()
+            a.bias = getattr(cp, 'b_%i' % i).data.data_ptr()
+            a.out = b.s[i].data_ptr()
+            a.out_sum = None
+            a.out_nslot = self._nslot(b, i)
+            a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
+            if b.ev_list is not None:
+                a.idx, a.cnt = b.ev_list[0].data_ptr(), b.ev_list[1].data_ptr()
+
+        fl_f = lambda b, i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
+        tag_f = lambda b, i: 'h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])
+
+        def group_launches(members):
+            for c0 in range(0, len(members), 4):
+                grp = members[c0:c0 + 4]
+                arr = (_hip.ConvFwdArgs * len(grp))()
+                for a, (b, i) in zip(arr, grp):
+                    fwd_args(b, i, a)
+                dev_arr = _hip.to_device_table(list(arr), self.dev)
+                keep.extend([arr, dev_arr])
+                fwd.append(call(lib.mpnn_msconv_fwd_group, 'fwd_group', arr, dev_arr.data_ptr(), len(grp),
+                                flops=sum(fl_f(b, i) for b, i in grp), tag=' | '.join(tag_f(b, i) for b, i in grp)))
+
+        # ---- exit records ----
+        dyn = bool(getattr(ϕ, 'dyn_k_cpt', False))
+        MS = self.max_sinks
+        recs = {}
+        for b in self.blocks:
+            if not b.has_exit:
+                continue
+            L1 = b.L - 1
+            e = _hip.ExitEvArgs()
+            e.a = _hip.act(b.s[L1], b.C[L1], act_mode, 0, self._bn(b, L1, with_sum=False), n * b.H[L1] * b.W[L1])
+            e.HW, e.n = b.H[L1] * b.W[L1], n
+            if b.head is not None:
+                lt, ce = b.head.layer.comps[1], b.head.layer.comps[3]
+                leaf = b.head.leaf_id
+                e.w_head, e.b_head, e.n_cls = lt.params.w.data.data_ptr(), lt.params.b.data.data_ptr(), self.n_cls
+                e.y, e.eps_ce = self.y.data_ptr(), float(ce.hypers.ϵ)
+                e.c_err, e.d_cor = self.c_err[leaf * n:].data_ptr(), self.d_cor[leaf * n:].data_ptr()
+            if b.router is not None:
+                rc = b.router.comps
+                l1, bn1, l2, bn2, l3 = rc[1], rc[2], rc[4], rc[5], rc[7]
+                sw = b.node.switch_id
+                D = lambda prm: prm.data.data_ptr()
+                e.w1, e.b1, e.R, e.n_sinks = D(l1.params.w), D(l1.params.b), b.R, len(b.node.layer.sinks)
+                e.extra_col, e.k_cpt, e.alpha_cpt = (1 if dyn else 0), self.k_cpt.data_ptr(), float(_attr(ϕ, 'α_cpt', 0.0))
+                e.g1, e.be1, e.m1, e.v1 = D(bn1.params.γ), D(bn1.params.β), D(bn1.params.m_avg), D(bn1.params.v_avg)
+                e.w2, e.bias2 = D(l2.params.w), D(l2.params.b)
+                e.g2, e.be2, e.m2, e.v2 = D(bn2.params.γ), D(bn2.params.β), D(bn2.params.m_avg), D(bn2.params.v_avg)
+                e.w3, e.bias3 = D(l3.params.w), D(l3.params.b)
+                e.bn_eps = float(bn1.hypers.ϵ)
+                e.r, e.r_stride = self.r[sw * n * MS:].data_ptr(), MS
+                if routed:
+                    for i, sb in enumerate(b.sink_blocks):
+                        if sb is not None:
+                            e.child_idx[i], e.child_cnt[i] = sb.ev_idx.data_ptr(), sb.ev_cnt.data_ptr()
+            if b.ev_list is not None:
+                e.idx, e.cnt = b.ev_list[0].data_ptr(), b.ev_list[1].data_ptr()
+            _hip.check(lib.mpnn_exit_ev_check(C.byref(e)), 'exit_ev record')
+            recs[id(b)] = e
+
+        if not routed:
+            kidx = {h: k for k, h in enumerate(sorted({h for b in self.blocks for h in b.H}, reverse=True))}
+            levels = {}
+            for b in self.blocks:
+                for i in range(b.L):
+                    levels.setdefault(depth[id(b)] + kidx[b.H[i]], []).append((b, i))
+            for d in sorted(levels):
+                group_launches(levels[d])
+            order = [recs[id(b)] for b in self.blocks if id(b) in recs]
+            if order:
+                tab = _hip.to_device_table(order, self.dev)
+                keep.append(tab)
+                fwd.append(call(lib.mpnn_exit_ev, 'exit_ev', tab.data_ptr(), len(order), n))
+        else:
+            by_depth = {}
+            for b in self.blocks:
+                by_depth.setdefault(depth[id(b)], []).append(b)
+            for d in sorted(by_depth):
+                bs = by_depth[d]
+                for i in range(max(b.L for b in bs)):
+                    members = [(b, i) for b in bs if i < b.L]
+                    # a launch holds members that all carry a list, or none (the root block: every sample)
+                    for with_list in (False, True):
+                        part = [(b, i) for b, i in members if (b.ev_list is not None) == with_list]
+                        if part:
+                            group_launches(part)
+                order = [recs[id(b)] for b in bs if id(b) in recs]
+                if order:
+                    tab = _hip.to_device_table(order, self.dev)
+                    keep.append(tab)
+                    fwd.append(call(lib.mpnn_exit_ev, 'exit_ev', tab.data_ptr(), len(order), n))
+
+        ra = self._route_args(n, 'ev', self.loss_ev)
+        fwd.append(call(lib.mpnn_route, 'route', C.byref(ra)))
+        return dict(fwd=fwd, bwd=[], n=n, mode='ev', routed=routed)
+
+    def _route_args(self, n, mode, loss):
+        ϕ, kind = self.net.hypers, self.net._net_kind
+        ra = _hip.RouteArgs()
+        ra.net_type = {'sr': _hip.NET_SR, 'actor': _hip.NET_ACTOR, 'critic': _hip.NET_CRITIC}[kind]
+        ra.n_nodes, ra.n_leaves, ra.n_switches, ra.max_sinks = len(self.nodes), len(self.leaves), len(self.switches), self.max_sinks
+        ra.optimistic = int(bool(getattr(ϕ, 'optimistic', False)))
+        ra.use_cls_err = int(bool(getattr(ϕ, 'use_cls_err', False)))
+        ra.want_grad = 1 if mode == 'tr' else 0
+        ra.nodes, ra.sw_children, ra.node_ops = self.node_tab.data_ptr(), self.kid_tab.data_ptr(), self.node_ops.data_ptr()
+        ra.hyp = self.hyp.data_ptr()
+        ra.k_cpt_vec = self.k_cpt.data_ptr() if bool(getattr(ϕ, 'dyn_k_cpt', False)) else None
+        ra.r, ra.c_err, ra.d_cor = self.r.data_ptr(), self.c_err.data_ptr(), self.d_cor.data_ptr()
+        ra.p_tr, ra.p_ev, ra.w_cerr, ra.dr = self.p_tr.data_ptr(), self.p_ev.data_ptr(), self.w_cerr.data_ptr(), self.dr.data_ptr()
+        ra.node_stat = self.node_stat.data_ptr() if mode == 'tr' else None
+        ra.loss = loss.data_ptr()
+        ra.n, ra.n_total = n, n
+        self._keep.append(ra)
+        return ra
+
     # ------------------------------------------------------------------ running
     def _stage(self, feed):
         net = self.net
         x0 = feed[net.x0]
         n = int(x0.shape[0])
-        self._ensure_capacity(n)
+        self._ensure_capacity(n, feed.get(net.mode, net.mode.default) == 'tr')
 
         def put(dst, src):
             if isinstance(src, torch.Tensor):
@@ -758,7 +969,7 @@ class Engine:
         put(self.y[:n], feed[net.y])
         ϕ = net.hypers
         get = lambda name, default: feed.get(_attr(net, name), _attr(ϕ, name, default))
-        h = self.hyp_host
+        h = self._hyp_stage
         h[_hip.HYP_LR] = float(get('λ_lrn', 0.0))
         h[_hip.HYP_MU] = float(get('μ_lrn', 0.0))
         h[_hip.HYP_TAU] = float(get('τ', 1.0))
@@ -774,7 +985,19 @@ class Engine:
         else:
             h[_hip.HYP_KCPT] = float(getattr(ϕ, 'k_cpt', 0.0))
         if self._hyp_sent is None or not torch.equal(h, self._hyp_sent):
-            self.hyp.copy_(h, non_blocking=True)          # (skipped while the schedule holds them constant)
+            # Upload through a ring of pinned buffers: the copy is asynchronous and, under hipGraph
+            # replay, the host runs many steps ahead of the stream -- rewriting ONE staging buffer in place
+            # would let step t's DMA read the schedule values of step t + k.  A slot is reused only after
+            # the event recorded behind its last copy has completed.
+            k = self._hyp_slot = (self._hyp_slot + 1) % len(self._hyp_ring)
+            buf, ev = self._hyp_ring[k]
+            if ev is not None:
+                ev.synchronize()
+            buf.copy_(h)
+            self.hyp.copy_(buf, non_blocking=True)          # (skipped while the schedule holds them constant)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._hyp_ring[k] = (buf, ev)
             self._hyp_sent = h.clone()
         return n, feed.get(net.mode, net.mode.default)
 
@@ -832,7 +1055,7 @@ class Engine:
         if train:
             self._zarena.zero_()           # (G lives in the same arena)
         else:
-            self.loss.zero_()
+            self._ev_arena.zero_()
 
     def _pack(self):
         _hip.check(self.lib.mpnn_pack_weights(self.P.data_ptr(), self.packs.data_ptr(), self.pack_desc.data_ptr(),
@@ -846,8 +1069,9 @@ class Engine:
             torch.cuda.current_stream().cuda_stream), 'talr_momentum_step')
 
     def _begin(self, train):
-        """mpnn_step_begin: pack the weights and clear the step's accumulators in one launch."""
-        z = self._zarena if train else self.loss
+        """mpnn_step_begin: pack the weights and clear the step's accumulators in one launch
+        (evaluation: loss sums, routed sample counts, r / c_err / d_cor)."""
+        z = self._zarena if train else self._ev_arena
         _hip.check(self.lib.mpnn_step_begin(self.P.data_ptr(), self.packs.data_ptr(), self.pack_desc.data_ptr(),
                                             self.n_pack, z.data_ptr(), z.numel() * z.element_size(),
                                             torch.cuda.current_stream().cuda_stream), 'step_begin')
@@ -858,14 +1082,19 @@ class Engine:
         if train:
             self._launch(prog['bwd'], 1)
 
-    def run(self, feed, train):
+    def run(self, feed, train, routed=False):
         if len(self._event_keep) > 4096:
             torch.cuda.synchronize()
             self._event_keep.clear()
         n, mode = self._stage(feed)
         if train and mode != 'tr':
             raise ValueError("net.train.run needs net.mode: 'tr' in the feed")
-        prog = self.program(mode, n)
+        if not train and mode == 'tr':
+            # The reference would evaluate with batch statistics AND move every BatchNorm's averages as
+            # a side effect (layer_types.py:231-236); no caller does that, and half of it (the conv
+            # moving averages) lives in the backward pass here.
+            raise ValueError("forward-only runs evaluate in mode 'ev'; mode 'tr' belongs to net.train.run")
+        prog = self.program(mode, n, routed)
         do_bwd = train
         if not self.use_graph:
             self._phase_a(prog, do_bwd)
@@ -882,7 +1111,7 @@ class Engine:
         """First call runs eagerly (loads code objects); the second captures
         hipGraphs (phase A = forward+backward, phase B = optimizer, split so a
         data-parallel all-reduce can sit between them); later calls replay."""
-        key = (prog['mode'], n, train)
+        key = (prog['mode'], n, train, prog.get('routed', False))
         g = self._graphs.get(key)
         if g is None:
             self._phase_a(prog, train)

@@ -141,10 +141,16 @@ class Net(metaclass=ABCMeta):
     def _run_train(self, feed):
         return self.engine().run(feed, train=True)
 
-    def eval(self, feed):
-        """Forward pass (+ routing) in the fed mode (default 'ev'); per-layer
-        results are then readable as ``ℓ.p_ev``, ``ℓ.δ_cor`` ... device tensors."""
-        return self.engine().run(feed, train=False)
+    def eval(self, feed, routed=False):
+        """Forward pass + routing in evaluation mode ('ev': BatchNorm moving averages, hard routing);
+        per-layer results are then readable as ``ℓ.p_ev``, ``ℓ.δ_cor`` ... device tensors.
+
+        routed=True runs the ROUTED evaluation: every block only processes the samples its ancestors'
+        routers sent to it (sample lists compacted on the device, no host sync).  ``p_ev`` and every
+        p_ev-weighted statistic (acc, moc, p_cor, p_inc, *_by_cls: all that the reference's figure
+        scripts read) are identical to the dense pass; per-leaf ``c_err`` / ``δ_cor`` and ``router.x``
+        are those of the dense pass where the sample reaches the node and 0 elsewhere."""
+        return self.engine().run(feed, train=False, routed=routed)
 
     def state(self):
         """Per-sample statistics of the last run, keyed like the reference's
