@@ -111,8 +111,10 @@ int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
  * DEVICE copy of it (read by the kernel; uploaded once per plan).  The grid is 1-D, holds exactly
  * the workgroups that have work and is fitted to what is resident at once, shared between the
  * members by work.  A single member on an 8x8 / 4x4 map with >= 64 input channels (multiples of
- * 32 per operand) takes the K-split body (512 threads, two chunks of a 32-channel unit in
- * parallel); results are the same up to fp32 summation order. */
+ * 32 per operand) in TRAINING mode (a.mode == MPNN_ACT_BN_BATCH) takes the K-split body (512
+ * threads, two chunks of a 32-channel unit in parallel); results are the same up to fp32 summation
+ * order.  Evaluation-mode launches always use the one-chunk body, so a conv gives bit-identical
+ * rows whether it runs grouped or alone, on all samples or on a routed sub-batch. */
 int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
                           void *stream);
 

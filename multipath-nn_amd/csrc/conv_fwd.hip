@@ -115,7 +115,9 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
     // a single deep member on a small map: 128-256 workgroups of 4 waves would leave every SIMD with one
     // wave and nothing to overlap -> K-split body (two thread groups per workgroup, 32-channel units)
     static const int ks_env = [] { const char *e = getenv("MPNN_FWD_KSPLIT"); return e ? atoi(e) : 1; }();
-    if (ks_env && !any_idx && count == 1 && q.gk[0] != 0 && !q.small[0] && (hp[0].a.C % 32) == 0 && (hp[0].Cv % 32) == 0 &&
+    // (training launches only: the evaluation path keeps ONE summation order per conv whether it runs
+    // grouped, alone, dense or routed, so routed and dense evaluation agree bit for bit)
+    if (ks_env && !any_idx && hp[0].a.mode == MPNN_ACT_BN_BATCH && count == 1 && q.gk[0] != 0 && !q.small[0] && (hp[0].a.C % 32) == 0 && (hp[0].Cv % 32) == 0 &&
         hp[0].a.C + hp[0].Cv >= 64) {
         const int gy = q.gy[0];
         int gx = hp[0].n_tiles;

@@ -180,7 +180,7 @@ def test_exit_fractions_one_eighth_each(kind):
     net = make(kind, k_cpt=1e-9)
     randomise_routers(net)
     x0, y = batch(64, seed=3)
-    calibrate_exit_fractions(net, x0, y, [1 / 8, 1 / 7, 1 / 6, 1 / 5, 1 / 4, 1 / 3, 1 / 2])
+    calibrate_exit_fractions(net, x0, y, [1 / 8] * 7)
     dense = check_routed_equals_dense(net, x0, y)
     hist = check_vs_oracle(net, x0, y, dense)
     assert np.allclose(hist, 1 / 8), hist
