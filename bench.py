@@ -35,6 +35,43 @@ def synthetic(n, seed, device):
     return x0.to(device), y.to(device)
 
 
+def csrc_sha16():
+    """Hash of the kernel sources and the launch plan: a committed PMC summary is only quoted while it
+    still describes the code that runs (tools/summarize_pmc.py stores the same hash)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'multipath-nn_amd', 'csrc', '*.h*'))) + \
+        [os.path.join(ROOT, 'multipath-nn_amd', 'lib', '_plan.py')]
+    for f in files:
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def set_exit_fractions(net, feed, n, fractions):
+    """Shift the exit-sink bias of every router so that fractions[k] of the batch leaves at exit k
+    (chain nets: sink 0 = the exit's classifier, sink 1 = the next block)."""
+    net.eval(feed)
+    alive = np.ones(n, bool)
+    for k, ℓ in enumerate(net.switches):
+        r = ℓ.router.x.cpu().numpy().astype(np.float64)
+        want = int(round(fractions[k] * n))
+        margin = r[:, 1] - r[:, 0]
+        idx = np.flatnonzero(alive)
+        order = idx[np.argsort(margin[idx], kind='stable')]
+        if want <= 0 or len(idx) == 0:
+            shift = (margin[idx].min() - 1.0) if len(idx) else 0.0
+        elif want >= len(idx):
+            shift = margin[idx].max() + 1.0
+        else:
+            shift = 0.5 * (margin[order[want - 1]] + margin[order[want]])
+        b = ℓ.router.comps[-1].params.b
+        v = b.numpy().copy()
+        v[0] += shift
+        b.assign(v)
+        alive[order[:max(want, 0)]] = False
+
+
 def cpu_baseline(batch, seconds=24.0):
     """The oracle (oracle/ref_net.py, torch-CPU fp32, all host cores) on the same step."""
     import arch_and_hypers as A
@@ -86,6 +123,7 @@ def main():
     ap.add_argument('--streams', action='store_true',
                     help='multi-stream DAG schedule (measured slower under hipGraph: cross-stream edges cost more than the overlap gains)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eval-batch', type=int, default=4096, help='batch of the routed / dense evaluation measurement')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -135,25 +173,46 @@ def main():
         # routed FLOPs/s = images/s x 2 x moc (scripts/train-nets:120), moc from an 'ev' pass
         net.eval({net.x0: eng.x0[:n], net.y: eng.y[:n]})
         moc = float(net.state()[(net, 'moc')].mean())
-        # evaluation mode, forward only (moving-average BatchNorm, hard routing p_ev): dense over the batch
-        # (no compaction: at batch 128 every launch is latency-bound), routed cost from the statistic
+        # Evaluation mode, forward only (moving-average BatchNorm, hard routing p_ev; scripts/lib/desc.py:10-22):
+        # dense at the training batch size, and -- SURVEY 8d "Eval-mode" -- dense vs ROUTED (on-device
+        # per-branch compaction, lib/_plan.py:_program_ev) on a statistics-pass-sized batch with the
+        # router biases set so that 1/8 of the batch leaves at each of the 8 exits.
+        def time_eval(feed_, routed, reps):
+            for _ in range(3):
+                net.eval(feed_, routed=routed)
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(reps):
+                net.eval(feed_, routed=routed)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / reps * 1e3
         ev_feed = {net.x0: eng.x0[:n], net.y: eng.y[:n]}
-        for _ in range(3):
-            net.eval(ev_feed)
-        torch.cuda.synchronize()
-        t_ev = time.perf_counter()
-        for _ in range(100):
-            net.eval(ev_feed)
-        torch.cuda.synchronize()
-        ev_ms = (time.perf_counter() - t_ev) / 100 * 1e3
+        ev_ms = time_eval(ev_feed, False, 100)
         leaves = [nd.layer for nd in eng.leaves]
+        nb_ = args.eval_batch
+        xe, ye = synthetic(nb_, 12345, dev)
+        eng._ensure_capacity(nb_, train=False)
+        eng.x0[:nb_].copy_(xe); eng.y[:nb_].copy_(ye)
+        big = {net.x0: eng.x0[:nb_], net.y: eng.y[:nb_]}
+        set_exit_fractions(net, big, nb_, [1.0 / 8] * 7)
+        d_ms = time_eval(big, False, 20)
+        hist_d = [float(l.p_ev.mean()) for l in leaves]
+        moc_d = float(net.state()[(net, 'moc')].mean())
+        r_ms = time_eval(big, True, 20)
         exit_hist = [float(l.p_ev.mean()) for l in leaves]
-        depth_of = {id(b): k for k, b in enumerate(eng.blocks)}
+        moc_r = float(net.state()[(net, 'moc')].mean())
         blocks_run = sum(h * (k + 1) for k, h in enumerate(exit_hist))       # chain: exit k runs blocks 0..k
-        ev = {'images_per_s_forward_dense': n / (ev_ms * 1e-3), 'ms_per_batch': ev_ms,
-              'exit_histogram': exit_hist, 'skipped_block_fraction': 1.0 - blocks_run / max(1, len(eng.blocks)),
-              'routed_flops_per_s': n / (ev_ms * 1e-3) * 2 * moc, 'compaction': False}
-
+        ev = {'images_per_s_forward_dense': n / (ev_ms * 1e-3), 'ms_per_batch': ev_ms, 'batch': n,
+              'routed': {'batch': nb_, 'compaction': True,
+                         'images_per_s': nb_ / (r_ms * 1e-3), 'ms_per_batch': r_ms,
+                         'images_per_s_dense_same_batch': nb_ / (d_ms * 1e-3), 'ms_per_batch_dense': d_ms,
+                         'speedup_vs_dense': d_ms / r_ms,
+                         'exit_histogram': exit_hist, 'exit_histogram_dense': hist_d,
+                         'skipped_block_fraction': 1.0 - blocks_run / max(1, len(eng.blocks)),
+                         'moc': moc_r, 'moc_dense': moc_d,
+                         'routed_flops_per_s': nb_ / (r_ms * 1e-3) * 2 * moc_r,
+                         'router_state': 'synthetic: exit biases calibrated to 1/8 of the batch per exit'},
+              'compaction': True}
         # dominant kernel FAMILY (one kernel symbol, or the instantiations of one template): in-situ
         # per-launch HIP-event timing on the launch stream, whole steps run eagerly
         ops = eng.time_step_ops('tr', n, reps=20)
@@ -172,13 +231,31 @@ def main():
         # HBM-side traffic of the same kernel family per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # passes of THIS command, summarised by tools/summarize_pmc.py into profiles/ (bench.py cannot run
         # the profiler around itself); null when no summary is committed.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_stale = None, None, None
         try:
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_summary.json')))
             if pm.get('family') == dom_name:
-                traffic, traffic_src = pm['traffic_bytes_per_launch'], pm.get('source')
+                traffic_stale = pm.get('csrc_sha16') != csrc_sha16()
+                traffic_src = '%s; collected %s at source hash %s' % (pm.get('source'), pm.get('collected'), pm.get('csrc_sha16'))
+                if not traffic_stale:               # a summary of OLDER kernels is not this run's traffic
+                    traffic = pm['traffic_bytes_per_launch']
         except Exception:
             pass
+        # steady state outside the headline region: 200 graph replays, one HIP-event pair per step on the
+        # launch stream -> median and mean step time (the driver's 20-step run is not the only evidence)
+        st_ = torch.cuda.current_stream()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(201)]
+        for _ in range(3):
+            net.train.run(feed)
+        evs[0].record(st_)
+        for k in range(200):
+            net.train.run(feed)
+            evs[k + 1].record(st_)
+        torch.cuda.synchronize()
+        per = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(200)])
+        steady = {'steps': 200, 'ms_median': float(np.median(per)), 'ms_mean': float(per.mean()),
+                  'ms_p95': float(np.percentile(per, 95)), 'images_per_s_median': n / (float(np.median(per)) * 1e-3),
+                  'what': 'single-GPU replays after the headline region, HIP events per step'}
         # launch floor: the same number of launches as a training step, each the smallest kernel of the
         # library (a 1-item slab reduction), captured and replayed as one hipGraph
         n_launch = len(ops) + 2                                   # + step_begin + optimizer
@@ -211,12 +288,13 @@ def main():
                        'hip_graph': bool(eng.use_graph), 'streams': eng.n_streams if eng.multi_stream else 1},
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
                          'frac': ach / PEAK_F32_MFMA, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'traffic_stale': traffic_stale,
                          'kernel': symbol, 'launches_per_step': cnt,
                          'kernel_ms': t_ms / cnt, 'kernel_flops': fl / cnt},
             'step_frac_of_mfma_roofline': value / world * F_TRAIN / 1e12 / PEAK_F32_MFMA,
             'conv_kernels': {'tflops': conv_fl / (conv_ms * 1e-3) / 1e12, 'sum_ms': conv_ms,
                              'all_launches_sum_ms': total_ms, 'n_launches': len(ops)},
-            'routed_flops_per_s': value * 2 * moc, 'moc': moc, 'eval': ev,
+            'routed_flops_per_s': value * 2 * moc, 'moc': moc, 'eval': ev, 'steady_state': steady,
             'launch_floor': {'kernels_per_step': n_launch, 'us_per_step': floor_us, 'us_per_kernel': floor_us / n_launch,
                              'what': 'hipGraph of that many 1-workgroup kernels'},
         }

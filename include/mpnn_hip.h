@@ -60,6 +60,12 @@ typedef struct {
     int   nslot;           /* slots of `sum` actually in use (1..MPNN_BN_SLOTS) */
 } mpnn_act;
 
+/* The activation MATERIALISED: y = relu(bn(x)) (identity mode: a copy), [n_pix, C] -- exactly what
+ * the consumers compute while loading (same coefficients, same expression).  The hot path never
+ * needs it (nothing post-ReLU is stored); callers that want a block's output tensor do, and the
+ * parity tests read the ReLU decisions of the device from it.  C % 4 == 0, C <= 256, shift == 0. */
+int mpnn_bn_relu_fwd(const mpnn_act *a, float *y, long n_pix, void *stream);
+
 /* ---- weight packing ------------------------------------------------------
  * HWIO [3][3][Cin][Cout] -> forward pack [9][ceil(Cin/16)][4][Cout][4]
  * (k-interleaved so one 16-byte load feeds four v_mfma_f32_16x16x4_f32) and

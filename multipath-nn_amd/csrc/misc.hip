@@ -141,6 +141,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(const BnBwdP p) {
     }
 }
 
+// mpnn_bn_relu_fwd: y = relu(bn(x)) materialised, with the coefficients (bn_coef) and the expression
+// ((x - m) * (gamma * rstd) + beta, then max 0) every consumer applies while loading.
+__global__ __launch_bounds__(256) void bn_relu_fwd_k(const mpnn_act a, float *__restrict__ y, long n_pix) {
+    __shared__ float tab[256 * 3];
+    const int C = a.C, Q = C >> 2;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float m = 0.f, k = 1.f, b = 0.f;
+        if (a.mode != MPNN_ACT_IDENTITY) { const BnC q = bn_coef(a, c); m = q.m; k = q.gamma * q.rstd; b = q.beta; }
+        tab[c * 3] = m; tab[c * 3 + 1] = k; tab[c * 3 + 2] = b;
+    }
+    __syncthreads();
+    const long total = n_pix * Q;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % Q);
+        const f32x4 x = *(const f32x4 *)(a.x + (size_t)i * 4);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float *cc = tab + (q * 4 + j) * 3;
+            v[j] = a.mode != MPNN_ACT_IDENTITY ? fmaxf((x[j] - cc[0]) * cc[1] + cc[2], 0.f) : x[j];
+        }
+        *(f32x4 *)(y + (size_t)i * 4) = v;
+    }
+}
+
+extern "C" int mpnn_bn_relu_fwd(const mpnn_act *a, float *y, long n_pix, void *stream) {
+    if (!a || !a->x || !y) return MPNN_E_ARG;
+    if (a->C <= 0 || (a->C & 3) || a->C > 256 || a->shift) return MPNN_E_SHAPE;
+    if (n_pix <= 0) return 0;
+    long blocks = (n_pix * (a->C >> 2) + 2047) / 2048;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(bn_relu_fwd_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a, y, n_pix);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
 static int bn_shape_ok(int C) { return C > 0 && (C & 3) == 0 && C <= 256 && (256 % (C >> 2)) == 0; }
 
 extern "C" int mpnn_bn_bwd_reduce(const float *dy, const mpnn_bn_ctx *ctx, float *dz, double *red_out,

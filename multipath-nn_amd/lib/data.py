@@ -100,6 +100,8 @@ class Dataset:
         self._dev = device
         self._x_dev = torch.from_numpy(np.ascontiguousarray(self.x0_tr, dtype=np.float32)).to(device)
         self._y_dev = torch.from_numpy(np.ascontiguousarray(self.y_tr, dtype=np.float32)).to(device)
+        self._x_ts_dev = torch.from_numpy(np.ascontiguousarray(self.x0_ts, dtype=np.float32)).to(device)
+        self._y_ts_dev = torch.from_numpy(np.ascontiguousarray(self.y_ts, dtype=np.float32)).to(device)
         self._draw_host = None
         return self
 
@@ -135,7 +137,15 @@ class Dataset:
         return batch(self.x0_ts, self.y_ts, n)
 
     def training_set(self, n=128):
-        yield from full_set(self.x0_tr, self.y_tr, n)
+        """Full training set in batches of n (scripts/lib/data.py:72-73); device slices once
+        to_device() has made the set resident (no re-upload per statistics pass)."""
+        if getattr(self, '_x_dev', None) is not None:
+            yield from full_set(self._x_dev, self._y_dev, n)
+        else:
+            yield from full_set(self.x0_tr, self.y_tr, n)
 
     def test_set(self, n=128):
-        yield from full_set(self.x0_ts, self.y_ts, n)
+        if getattr(self, '_x_ts_dev', None) is not None:
+            yield from full_set(self._x_ts_dev, self._y_ts_dev, n)
+        else:
+            yield from full_set(self.x0_ts, self.y_ts, n)

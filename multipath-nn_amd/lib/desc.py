@@ -12,12 +12,19 @@ import numpy as np
 __all__ = ['net_desc', 'render_net_desc']
 
 
-def mean_net_state(net, data, hypers):
+def mean_net_state(net, data, hypers, routed=False):
     """One evaluation pass per batch; per-sample statistics are summed on the device and
-    divided by the sample count at the end (desc.py:10-22)."""
+    divided by the sample count at the end (desc.py:10-22).  In 'ev' mode every sample is
+    independent, so the batch size only sets how much work a launch carries: the passes feed
+    thousands of images at a time (the reference's 128 would be 469 latency-bound passes).
+
+    routed=True evaluates each block only on the samples routed to it (Net.eval): acc, moc, p_cor,
+    p_inc and the *_by_cls statistics -- all the reference's figure scripts read -- are unchanged;
+    the log-only per-leaf c_err / p_tr and per-switch x_rte then average over the samples that
+    REACH the node (0 for the others) instead of over all samples."""
     sums, count = None, 0
     for x0, y in data:
-        net.eval({net.x0: x0, net.y: y, **hypers})
+        net.eval({net.x0: x0, net.y: y, **hypers}, routed=routed)
         state = net.state()
         part = {k: v.sum(0).double() for k, v in state.items()}
         sums = part if sums is None else {k: sums[k] + part[k] for k in part}
@@ -33,9 +40,9 @@ def layer_desc(ℓ, stats_tr, stats_ts):
             'sinks': [layer_desc(s, stats_tr, stats_ts) for s in ℓ.sinks]}
 
 
-def net_desc(net, dataset, hypers={}, state=None):
-    stats_tr = mean_net_state(net, dataset.training_set(), hypers)
-    stats_ts = mean_net_state(net, dataset.test_set(), hypers)
+def net_desc(net, dataset, hypers={}, state=None, batch=4096, routed=False):
+    stats_tr = mean_net_state(net, dataset.training_set(batch), hypers, routed)
+    stats_ts = mean_net_state(net, dataset.test_set(batch), hypers, routed)
     pick = lambda st: {k: v for (t, k), v in st.items() if t is net}
     return {'type': type(net).__name__, 'stats_tr': pick(stats_tr), 'stats_ts': pick(stats_ts),
             'root': layer_desc(net.root, stats_tr, stats_ts)}

@@ -40,6 +40,14 @@ def pool2(x):                             # tf.nn.max_pool 2x2/2 'SAME' on even 
     return _nhwc(TF.max_pool2d(_nchw(x), 2))
 
 
+def pool2_forced(x, arg):
+    """2x2/2 max-pool with the window element GIVEN (arg in 0..3 = 2*dy + dx, [n, H/2, W/2, C]):
+    value and gradient go through that element.  Decision-forced comparison (see RefNet.forward)."""
+    n, H, W, C = x.shape
+    win = x.reshape(n, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(n, H // 2, W // 2, C, 4)
+    return torch.gather(win, 4, torch.as_tensor(arg, dtype=torch.int64)[..., None])[..., 0]
+
+
 class RefNet:
     """Evaluates loss, statistics and the TALR-momentum update of a product Net."""
 
@@ -50,6 +58,8 @@ class RefNet:
         self.θ = {}          # id(Param) -> leaf tensor
         self.accum = {}
         self.state = {}      # id(Param) -> tensor for m_avg / v_avg
+        self.forced = {}
+        self._at = (None, None)
 
     # ---- parameters -----------------------------------------------------------
     def load_params(self, values=None):
@@ -72,8 +82,10 @@ class RefNet:
         name = type(ℓ).__name__
         rec = dict(c_err=0.0, c_mod=0.0, n_ops=0)
         θ, ϕ = ℓ.params, ℓ.hypers
+        forced = self.forced
         if name == 'Chain':
-            for c in ℓ.comps:
+            for k, c in enumerate(ℓ.comps):
+                self._at = (id(ℓ), k)            # position of the component being linked (keys of `forced`)
                 x = self._link(c, x, y, mode, out)
             rec['c_err'] = sum(out[id(c)]['c_err'] for c in ℓ.comps)
             rec['c_mod'] = sum(out[id(c)]['c_mod'] for c in ℓ.comps)
@@ -90,7 +102,9 @@ class RefNet:
             xs = list(x)[-L:]
             o = [b[0] + conv_same(xs[0], wh[0])]
             for i in range(1, L):
-                o.append(b[i] + conv_same(xs[i], wh[i]) + conv_same(pool2(o[i - 1]), wv[i - 1]))
+                arg = forced.get(('pool', id(ℓ), i - 1)) if forced else None
+                pooled = pool2(o[i - 1]) if arg is None else pool2_forced(o[i - 1], arg)
+                o.append(b[i] + conv_same(xs[i], wh[i]) + conv_same(pooled, wv[i - 1]))
             rec['c_mod'] = ϕ.k_l2 * (sum((w ** 2).sum() for w in wh) + sum((w ** 2).sum() for w in wv))
             rec['n_ops'] = sum(o[i].shape[1] * o[i].shape[2] * (wh[i].numel() + (wv[i - 1].numel() if i > 0 else 0))
                                for i in range(L))
@@ -110,9 +124,12 @@ class RefNet:
             else:
                 x = γ * (x - self.state[id(θ.m_avg)]) / torch.sqrt(self.state[id(θ.v_avg)] + ϕ.ϵ) + β
         elif name == 'MultiscaleRect':
-            x = [torch.relu(x_i) for x_i in x]
+            masks = forced.get(('relu',) + self._at) if forced else None
+            x = [torch.relu(x_i) if masks is None else x_i * torch.as_tensor(m, dtype=self.dtype)
+                 for x_i, m in zip(x, masks if masks is not None else x)]
         elif name == 'Rect':
-            x = torch.relu(x)
+            m = forced.get(('relu',) + self._at) if forced else None
+            x = torch.relu(x) if m is None else x * torch.as_tensor(m, dtype=self.dtype)
         elif name == 'Select':
             x = x[ϕ.i]
         elif name == 'LinTrans':
@@ -137,7 +154,15 @@ class RefNet:
         return x
 
     # ---- whole graph -------------------------------------------------------------------
-    def forward(self, x0, y, mode='ev', τ=None, ϵ=None, k_cpt=None):
+    def forward(self, x0, y, mode='ev', τ=None, ϵ=None, k_cpt=None, forced=None):
+        """forced: the DISCRETE decisions of another evaluation of the same graph (the product's):
+        {('pool', id(MultiscaleConvMax), i): window arg-max of pre-BN map i,
+         ('relu', id(Chain), k): 0/1 mask (list of masks for MultiscaleRect) of the chain's k-th component}.
+        Max-pool and ReLU then take the given branch (value and gradient) instead of deciding
+        themselves: fp32 and float64 disagree on a near-tie now and then, and ONE flipped element
+        moves some gradient tensors by tens of percent -- with the decisions pinned every tensor must
+        agree to rounding, with no outlier band.  Keys that are absent decide freely."""
+        self.forced = forced or {}
         net, ϕ = self.net, self.net.hypers
         T = lambda a: torch.as_tensor(np.asarray(a, np.float64), dtype=self.dtype)
         x0, y = T(x0), T(y)
@@ -229,7 +254,7 @@ class RefNet:
             p_leaf=np.stack([(R(ℓ)['p_ev']).detach().numpy() for ℓ in leaves]))
 
     # ---- training step -------------------------------------------------------------------
-    def train_step(self, x0, y, λ_lrn, μ_lrn=None, τ=None, k_cpt=None):
+    def train_step(self, x0, y, λ_lrn, μ_lrn=None, τ=None, k_cpt=None, forced=None):
         """One net.train.run: gradients, TALR scaling, momentum update, BN moving
         averages.  Returns the forward result dict (with 'grads' added)."""
         from lib.net_types import params_list_rec
@@ -237,7 +262,7 @@ class RefNet:
         μ = ϕ.μ_lrn if μ_lrn is None else μ_lrn
         for t in self.θ.values():
             t.grad = None
-        res = self.forward(x0, y, 'tr', τ=τ, k_cpt=k_cpt)
+        res = self.forward(x0, y, 'tr', τ=τ, k_cpt=k_cpt, forced=forced)
         res['c_tot'].backward()
         R = lambda ℓ: res['out'][id(ℓ)]
         scale = {}

@@ -4,15 +4,14 @@ identical injected weights and identical batches.
 
 Tolerances (fp32 kernels vs. a float64 oracle; north_star: routing statistics within 1e-3):
   per-sample costs / probabilities : 2e-4 absolute-or-relative
-  gradients, parameter updates      : 2e-3 * max|ref| per tensor (measured: <= 6e-6 when no
-                                      discrete flip occurs).  ONLY IF the test itself finds a
-                                      discrete decision on which fp32 and float64 disagree in that
-                                      forward pass (max-pool arg-max or ReLU side at a near-tie;
-                                      count_flips) may tensors be "flip outliers" within 3e-1.  The oracle run in fp32 against itself in
-                                      float64 shows the same isolated outliers (4.8e-2 on one tensor,
-                                      median 2.7e-6), e.g. one flipped element among the 256 behind a
-                                      4x4-scale BatchNorm beta gradient at batch 16; a property of the
-                                      net, not of the kernels (whose own tests hold 2e-5).
+  gradients, parameter updates      : 1e-4 * max|ref| per tensor, EVERY tensor, no outlier band.  The
+                                      oracle is run DECISION-FORCED: the max-pool arg-max and the ReLU
+                                      side of every element are read back from the device
+                                      (oracle/decisions.py) and the float64 graph differentiates the same
+                                      piecewise-linear branch.  (Left to decide for itself, float64
+                                      disagrees with fp32 on a near-tie now and then, and one flipped
+                                      element moves some gradient tensors by tens of percent -- the free
+                                      run is only used to COUNT such flips, count_flips.)
   BatchNorm moving averages         : 1e-4 relative
 Weights are drawn with a fixed seed so every run checks the same numbers.
 """
@@ -63,6 +62,9 @@ def count_flips(eng, res, n, before):
     return flips
 
 
+TOL = 1e-4          # gradients / updates, relative to the tensor's max |reference|
+
+
 def rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.abs(a - b).max() / (1e-12 + np.abs(b).max())
@@ -82,6 +84,7 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3):
         perturb_routers(net)
     ref = RefNet(net)
     lr = 0.05
+    worst = {'grad': 0.0, 'update': 0.0}
     for t in range(steps):
         x0, y = batch(n, c0, seed=t)
         feed = {net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: lr, **feeds(net, t)}
@@ -101,7 +104,8 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3):
         before = {id(p): p.data.clone() for p in net._all_params}
         net.train.run(feed)
         torch.cuda.synchronize()
-        res = ref.train_step(x0, y, lr, **kw)
+        from oracle.decisions import from_product
+        res = ref.train_step(x0, y, lr, forced=from_product(net, n, before), **kw)
         R = lambda ℓ: res['out'][id(ℓ)]
         for ℓ in net.layers:
             assert np.abs(ℓ.p_tr.cpu().numpy() - R(ℓ)['p_tr'].detach().numpy()).max() < 2e-4, ('p_tr', ℓ.name, t)
@@ -113,15 +117,14 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3):
         for ℓ in net.switches:
             rx = R(ℓ.router)['x'].detach().numpy()
             assert np.abs(ℓ.router.x.cpu().numpy() - rx).max() < 2e-4 * (1 + np.abs(rx).max()), ('router.x', t)
-        bad, outliers, n_checked = [], [], 0
+        bad, n_checked = [], 0
 
         def judge(kind, p, err, scale, floor):
             nonlocal n_checked
             n_checked += 1
-            if err <= 2e-3 * scale + floor:
-                return
-            (outliers if err <= 3e-1 * scale + floor else bad).append(
-                (kind, p.owner.name, p.name, float(err), float(scale)))
+            worst[kind] = max(worst[kind], float((err - floor) / (scale + 1e-30)))
+            if err > TOL * scale + floor:
+                bad.append((kind, p.owner.name, p.name, float(err), float(scale)))
         for p in net._all_params:
             v0 = before[id(p)].cpu().numpy().astype(np.float64)
             d = p.data.cpu().numpy().astype(np.float64) - v0
@@ -139,10 +142,7 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3):
             # 1e-6 floor: conv biases ahead of BatchNorm have an exactly-zero true gradient
             judge('grad', p, np.abs(g - g_ref).max(), scale, 1e-6)
             judge('update', p, np.abs(d - d_ref).max(), np.abs(d_ref).max(), 1e-7)
-        assert not bad, (t, bad[:8])
-        if outliers:      # only legitimate when a discrete decision differs between fp32 and float64
-            flips = count_flips(eng, res, n, before)
-            assert flips > 0, (t, 'no max-pool / ReLU flip, yet', len(outliers), 'tensors beyond 2e-3', outliers[:8])
+        assert not bad, (t, len(bad), 'of', n_checked, bad[:8])
     # evaluation pass: moving-average BatchNorm, hard routing, statistics
     x0, y = batch(n, c0, seed=99)
     feed = {net.x0: x0, net.y: y, **{k: v for k, v in feeds(net, 0).items()}}
@@ -211,6 +211,12 @@ def test_full_batch_128():
     """The benchmark's batch size (arch_and_hypers.py:35)."""
     import arch_and_hypers as A
     run_case(A.cr_chain(k_cpt=1e-9), 128, lambda net, t: {net.τ: 0.1}, steps=1)
+
+
+def test_bench_config_ac_chain_kcpt0_batch_128():
+    """Exactly what bench.py times: ac_chain(k_cpt=0), batch 128, tau and learning rate at t = 0."""
+    import arch_and_hypers as A
+    run_case(A.ac_chain(k_cpt=0.0), 128, lambda net, t: {net.τ: A.τ_ds(0)}, steps=2)
 
 
 def test_batch_of_one_eval():

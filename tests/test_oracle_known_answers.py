@@ -4,6 +4,7 @@ generated from the reference's one importable module (tests/golden/make_data_gol
 import os
 
 import numpy as np
+import pytest
 
 import arch_and_hypers as A
 from oracle import np_ops as O
@@ -122,3 +123,56 @@ def test_oracle_net_gradients_match_numpy_ops():
         assert np.allclose(dwh[i] + 2 * conv.hypers.k_l2 * wh[i], G(getattr(conv.params, 'w_horz_%i' % i)), atol=1e-11)
     for i in range(3):
         assert np.allclose(dwv[i] + 2 * conv.hypers.k_l2 * wv[i], G(getattr(conv.params, 'w_vert_%i' % i)), atol=1e-11)
+
+
+@pytest.mark.parametrize('kind', ['actor', 'critic'])
+def test_route_ref_agrees_with_whole_net_oracle(kind):
+    """oracle/route_ref.py (the kernel-level oracle of mpnn_route, on bare tables) against the
+    whole-net restatement oracle/ref_net.py on a shipped chain: same p_tr / p_ev / loss and the same
+    gradients w.r.t. the router outputs and the leaf errors."""
+    import torch
+    import arch_and_hypers as A
+    from oracle.ref_net import RefNet
+    from oracle.route_ref import Tree, route
+    mk = A.ac_chain if kind == 'actor' else A.cr_chain
+    net = mk(k_cpt=8e-9)((32, 32, 3), (10,))
+    rng = np.random.default_rng(3)
+    vals = {}
+    for p in net._all_params:
+        k, scale = p.init
+        vals[id(p)] = ((scale * rng.standard_normal(p.size)) if k == 'normal' else
+                       (np.ones(p.size) if k == 'ones' else np.zeros(p.size))).reshape(p.shape)
+    for ℓ in net.layers:
+        if ℓ.router is not None:
+            w = ℓ.router.comps[-1].params.w
+            vals[id(w)] = rng.standard_normal(w.shape) * 0.5
+    ref = RefNet(net)
+    ref.load_params(vals)
+    n = 6
+    x0 = rng.random((n, 32, 32, 3))
+    y = np.eye(10)[rng.integers(0, 10, n)]
+    τ = 0.6
+    res = ref.forward(x0, y, 'tr', τ=τ)
+    R = lambda ℓ: res['out'][id(ℓ)]
+    layers = list(net.layers)
+    index = {id(ℓ): i for i, ℓ in enumerate(layers)}
+    tree = Tree([dict(sinks=[index[id(s)] for s in ℓ.sinks]) for ℓ in layers])
+    rs = [R(layers[i].router)['x'] for i in tree.switches]
+    for t in rs:
+        t.retain_grad()
+    ce = [R(layers[i])['c_err'] for i in tree.leaves]
+    for t in ce:
+        t.retain_grad()
+    res['c_tot'].backward()
+    ops = [float(R(ℓ)['n_ops'] + (R(ℓ.router)['n_ops'] if ℓ.router is not None else 0)) for ℓ in layers]
+    ϕ = net.hypers
+    out = route(kind, tree, [t.detach().numpy() for t in rs], np.stack([t.detach().numpy() for t in ce]),
+                np.stack([R(layers[i])['δ_cor'].numpy() for i in tree.leaves]), ops, τ=τ, ϵ=ϕ.ϵ, k_cpt=ϕ.k_cpt,
+                k_dec=getattr(ϕ, 'k_dec', 0.0), k_cre=getattr(ϕ, 'k_cre', 0.0))
+    for i, ℓ in enumerate(layers):
+        assert np.allclose(out['p_tr'][i], R(ℓ)['p_tr'].detach().numpy(), rtol=1e-12, atol=1e-15)
+        assert np.array_equal(out['p_ev'][i], R(ℓ)['p_ev'].numpy())
+    for k, t in enumerate(rs):
+        assert np.allclose(out['dr'][k], t.grad.numpy(), rtol=1e-9, atol=1e-15)
+    for k, t in enumerate(ce):
+        assert np.allclose(out['w_cerr'][k], t.grad.numpy(), rtol=1e-9, atol=1e-15)

@@ -5,7 +5,8 @@ wide coalesced loads on gfx950 and is doubled.
 
     python tools/summarize_pmc.py <dir with *counter_collection.csv> <family: bwd_scale|fwd_group> [out.json]
 """
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, time, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 d, family = sys.argv[1], sys.argv[2]
 sym = {'bwd_scale': 'bwd_scale_k<', 'fwd_group': 'fwd_group_k('}[family]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -27,6 +28,7 @@ write = 1024 * sum(tot['WRITE_SIZE']) / max(1, len(tot['WRITE_SIZE']))
 summary = {'family': family, 'fetch_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
            'traffic_bytes_per_launch': fetch + write, 'launches_fetch_pass': len(tot['FETCH_SIZE']),
            'launches_write_pass': len(tot['WRITE_SIZE']),
+           'collected': time.strftime('%Y-%m-%d'), 'csrc_sha16': __import__('bench').csrc_sha16(),
            'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py`; KiB x 1024, FETCH_SIZE x 2 (gfx950)'}
 print(json.dumps(summary))
 if len(sys.argv) > 3:
