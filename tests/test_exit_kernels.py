@@ -32,10 +32,12 @@ def close(a, b, tol, what):
     assert err <= tol * (1 + np.abs(b).max()), (what, err, np.abs(b).max())
 
 
-def gclose(a, b, what, tol=1e-4):
+def gclose(a, b, what, tol=1e-4, floor=1e-6):
+    """floor: some gradients are analytically zero (a bias ahead of a BatchNorm) and come out as
+    fp32 rounding noise of the terms that cancel."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     err = np.abs(a - b).max()
-    assert err <= tol * np.abs(b).max() + 1e-7, (what, err, np.abs(b).max())
+    assert err <= tol * np.abs(b).max() + floor, (what, err, np.abs(b).max())
 
 
 def bn_relu(x, g, b, eps=1e-6):

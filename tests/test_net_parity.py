@@ -143,6 +143,7 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3):
             judge('grad', p, np.abs(g - g_ref).max(), scale, 1e-6)
             judge('update', p, np.abs(d - d_ref).max(), np.abs(d_ref).max(), 1e-7)
         assert not bad, (t, len(bad), 'of', n_checked, bad[:8])
+    print('worst relative error over %d steps: gradients %.2e, updates %.2e (tolerance %.0e)' % (steps, worst['grad'], worst['update'], TOL))
     # evaluation pass: moving-average BatchNorm, hard routing, statistics
     x0, y = batch(n, c0, seed=99)
     feed = {net.x0: x0, net.y: y, **{k: v for k, v in feeds(net, 0).items()}}
