@@ -4,7 +4,7 @@ Same public names as the reference's ``scripts/arch_and_hypers.py`` (``arch``,
 ``k_cpts``, ``batch_size``, ``n_iter``, ``t_log``, ``λ_lrn``, ``τ_cr``, ``τ_ds``,
 ``router``, ``pyr``, ``rcm``, ``reg``, ``sr_chain``, ``ac_chain``, ``cr_chain``,
 ``ac_tree``, ``cr_tree``); the reference's own file also runs unchanged on top of
-``lib/`` (tests/test_dropin_reference_spec.py).  Values: reference
+``lib/`` (tests/test_host_cpu.py::test_reference_spec_file_drops_in_unchanged).  Values: reference
 arch_and_hypers.py:12-39; builders :45-70; constructors :76-139.
 """
 from lib.layer_types import (

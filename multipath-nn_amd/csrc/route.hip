@@ -27,9 +27,13 @@
 // per-thread arrays have compile-time bounds so nothing lives in scratch.
 #include "common.h"
 
-#define RB 64     // samples per workgroup
 #define MSK MPNN_MAX_SINKS
 
+// RB = samples per workgroup (the LDS rows): 64 for the chains; 32 / 16 for trees whose tables
+// (47 blocks + 47 leaves, 39 switches: arch_and_hypers.py:99-127) would not fit 160 KB at 64.  The
+// working wave always has 64 lanes: lanes >= RB repeat lane RB-1's sample (same inputs, same
+// arithmetic, identical LDS writes) and keep out of every global write and sum.
+template <int RB>
 __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = a.n, NN = a.n_nodes, MS = a.max_sinks;
@@ -89,13 +93,14 @@ __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
         }
     }
     __syncthreads();
-    const int wave = threadIdx.x / RB;             // 0: tree walks; 1: TALR node statistics; 2, 3: done
-    const int t = threadIdx.x & (RB - 1);
+    const int wave = threadIdx.x >> 6;             // 0: tree walks; 1: TALR node statistics; 2, 3: done
+    const int lane_t = threadIdx.x & 63;
+    const int t = lane_t < RB ? lane_t : RB - 1;
     const int s = blockIdx.x * RB + t;
-    const bool live = s < n;
+    const bool in_range = s < n, live = in_range && lane_t < RB;
     const float inv_n = 1.f / (float)a.n_total;
     const float tau = a.hyp[MPNN_HYP_TAU], eps = a.hyp[MPNN_HYP_EPS];
-    const float k_cpt = a.k_cpt_vec ? (live ? a.k_cpt_vec[s] : 0.f) : a.hyp[MPNN_HYP_KCPT];
+    const float k_cpt = a.k_cpt_vec ? (in_range ? a.k_cpt_vec[s] : 0.f) : a.hyp[MPNN_HYP_KCPT];
     const float k_dec = a.hyp[MPNN_HYP_KDEC], k_cre = a.hyp[MPNN_HYP_KCRE];
     const float inv_tau = 1.f / tau;
     const float eps_unit = eps / (float)ND[5];    // eps / n_leaves(root)
@@ -239,10 +244,22 @@ extern "C" int mpnn_route(const mpnn_route_args *args, void *stream) {
     if (!args || !args->nodes || !args->p_tr || !args->p_ev) return MPNN_E_ARG;
     if (args->n_nodes > MPNN_MAX_NODES || args->max_sinks > MPNN_MAX_SINKS) return MPNN_E_SHAPE;
     if (args->n <= 0) return 0;
-    const size_t lds = (size_t)(3 * args->n_nodes + 2 * args->n_switches * args->max_sinks + args->n_switches + 2 * args->n_leaves) * RB * 4
-                       + (size_t)(args->n_nodes * 9 + 4 + args->n_switches) * 4;
-    if (lds > 160 * 1024) return MPNN_E_SHAPE;
-    hipLaunchKernelGGL(route_k, dim3((args->n + RB - 1) / RB), dim3(256), lds, (hipStream_t)stream, *args);
+    const size_t per = (size_t)(3 * args->n_nodes + 2 * args->n_switches * args->max_sinks + args->n_switches + 2 * args->n_leaves) * 4;
+    const size_t fix = (size_t)(args->n_nodes * 9 + 4 + args->n_switches) * 4;
+    const size_t cap = 160 * 1024;
+    const hipStream_t st = (hipStream_t)stream;
+    const int n = args->n;
+    static bool raised = false;
+    if (!raised) {                                  // (more than the default 64 KB of dynamic LDS)
+        hipFuncSetAttribute((const void *)route_k<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        hipFuncSetAttribute((const void *)route_k<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        hipFuncSetAttribute((const void *)route_k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        raised = true;
+    }
+    if (per * 64 + fix <= cap)      hipLaunchKernelGGL(route_k<64>, dim3((n + 63) / 64), dim3(256), per * 64 + fix, st, *args);
+    else if (per * 32 + fix <= cap) hipLaunchKernelGGL(route_k<32>, dim3((n + 31) / 32), dim3(256), per * 32 + fix, st, *args);
+    else if (per * 16 + fix <= cap) hipLaunchKernelGGL(route_k<16>, dim3((n + 15) / 16), dim3(256), per * 16 + fix, st, *args);
+    else return MPNN_E_SHAPE;
     MPNN_LAUNCH_CHECK();
     return 0;
 }

@@ -466,6 +466,9 @@ class Engine:
             prog = self._progs[key] = self._program_ev(n, routed)
             return prog
         lib, keep = self.lib, self._keep
+        if self.multi_stream and any(len(b.children) > 1 for b in self.blocks):
+            raise NotImplementedError('the multi-stream schedule serialises nothing between sibling blocks that '
+                                      'accumulate into one gradient map: tree nets run on the single-stream schedule')
         act_mode = _hip.ACT_BN_BATCH if mode == 'tr' else _hip.ACT_BN_MOVING
         net, kind = self.net, self.net._net_kind
         ϕ = net.hypers
