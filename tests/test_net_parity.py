@@ -70,7 +70,7 @@ def rel(a, b):
     return np.abs(a - b).max() / (1e-12 + np.abs(b).max())
 
 
-def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3):
+def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL):
     """Teacher-forced: before every step the oracle is re-synchronised from the product's
     parameters, momentum accumulators and BatchNorm state, so each step checks one
     forward + backward + TALR/momentum update from IDENTICAL state.  (A free-running
@@ -123,7 +123,7 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3):
             nonlocal n_checked
             n_checked += 1
             worst[kind] = max(worst[kind], float((err - floor) / (scale + 1e-30)))
-            if err > TOL * scale + floor:
+            if err > tol * scale + floor:
                 bad.append((kind, p.owner.name, p.name, float(err), float(scale)))
         for p in net._all_params:
             v0 = before[id(p)].cpu().numpy().astype(np.float64)
@@ -143,7 +143,7 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3):
             judge('grad', p, np.abs(g - g_ref).max(), scale, 1e-6)
             judge('update', p, np.abs(d - d_ref).max(), np.abs(d_ref).max(), 1e-7)
         assert not bad, (t, len(bad), 'of', n_checked, bad[:8])
-    print('worst relative error over %d steps: gradients %.2e, updates %.2e (tolerance %.0e)' % (steps, worst['grad'], worst['update'], TOL))
+    print('worst relative error over %d steps: gradients %.2e, updates %.2e (tolerance %.0e)' % (steps, worst['grad'], worst['update'], tol))
     # evaluation pass: moving-average BatchNorm, hard routing, statistics
     x0, y = batch(n, c0, seed=99)
     feed = {net.x0: x0, net.y: y, **{k: v for k, v in feeds(net, 0).items()}}
