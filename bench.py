@@ -167,6 +167,23 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     value = n * world / (dt / args.steps)
+    # data parallel: the collective by itself -- each gradient bucket's all-reduce, timed with HIP events
+    # on the launch stream (what the overlap has to hide; 0.3-1.3 MB per bucket over xGMI)
+    ar = None
+    if world > 1:
+        ar = {}
+        st_c = torch.cuda.current_stream()
+        for name, (lo, hi) in eng.dp_buckets.items():
+            view = eng.G[lo:hi]
+            for _ in range(3):
+                dist.all_reduce(view)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st_c)
+            for _ in range(20):
+                dist.all_reduce(view)
+            e1.record(st_c)
+            e1.synchronize()
+            ar[name] = {'bytes': (hi - lo) * 4, 'us': e0.elapsed_time(e1) / 20 * 1e3}
 
     out = None
     if rank == 0:
@@ -284,7 +301,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': 'cifar10-ac: ac_chain(k_cpt=0) 8-block actor-routed chain, 32x32x3, 10 classes',
-                       'global_batch': n * world, 'per_gpu_batch': n, 'parallelism': 'dp%d' % world,
+                       'global_batch': n * world, 'per_gpu_batch': n, 'parallelism': 'dp%d' % world, 'rccl_ranks': (dist.get_world_size() if world > 1 else 1),
+                       'allreduce': ar,
                        'hip_graph': bool(eng.use_graph), 'streams': eng.n_streams if eng.multi_stream else 1},
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
                          'frac': ach / PEAK_F32_MFMA, 'traffic': traffic, 'traffic_source': traffic_src,

@@ -613,6 +613,27 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                     }
             }
         }
+        // dgrad-horz: likewise the producer's conv sums (ReLU mask, xhat) and the exit's dX of the tile's
+        // output pixels: requested before the last unit's MFMAs instead of in the epilogue.
+        [[maybe_unused]] float h_sp[MT][4][NT], h_ex[MT][4][NT];
+        if constexpr (EPI == EPI_DGH_BN) {
+            if ((!more || t2 != t) && !(p.dbg & 4)) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int img, ty, tx;
+                        mtile_pix<GK>(wm * MT + mt, g * 4 + r, img, ty, tx);
+                        const int n = n0 + img < p.n ? n0 + img : 0, y = y0 + ty, x = x0 + tx;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + cw + nt * 16;
+                            h_sp[mt][r][nt] = p.sprev[idx];
+                            h_ex[mt][r][nt] = p.extra ? p.extra[idx] : 0.f;
+                        }
+                    }
+            }
+        }
         // ----------------------------- MFMAs of unit u -----------------------------
         if (!(p.dbg & 1)) {
             const f32x4 *wl = b_once ? wtile[0] : wtile[u & 1];
@@ -708,12 +729,11 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                             p.out[idx] = val;
                         } else if (EPI == EPI_DGH_BN) {
                             const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
-                            if (p.extra) val += p.extra[idx];
                             const float *e = cE + cl * 5;
-                            const float d = p.sprev[idx] - e[0];
+                            const float d = h_sp[mt][r][nt] - e[0];
                             const float yv = d * e[2] + e[3];
-                            const float dz = yv > 0.f ? val : 0.f;
-                            p.out[idx] = p.acc_out ? p.out[idx] + dz : dz;
+                            const float dz = yv > 0.f ? val + h_ex[mt][r][nt] : 0.f;
+                            p.out[idx] = p.acc_out ? p.out[idx] + dz : dz;      // (tree nets: siblings' earlier sum)
                             s1[nt] += dz; s2[nt] += dz * (d * e[1]);
                         } else {  // EPI_DGV: val = d(pooled fine map) at coarse pixel (y, x)
                             const float *e = cE + cl * 5;

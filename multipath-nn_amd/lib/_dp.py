@@ -15,15 +15,19 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None):
+def init(backend=None, force=False):
     """Initialise torch.distributed from the torchrun environment (RANK, WORLD_SIZE,
     LOCAL_RANK, MASTER_ADDR/PORT).  backend defaults to nccl (= RCCL on ROCm) when a
-    GPU is visible, gloo otherwise."""
+    GPU is visible, gloo otherwise.  force: create the process group even for one rank
+    (tests exercise the RCCL code path on a single GPU that way)."""
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world == 1:
+    if world == 1 and not force:
         return 0, 1
+    if force:
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     if backend == 'nccl':
@@ -33,18 +37,41 @@ def init(backend=None):
 
 
 def allreduce_sum(flat):
-    """The one data-path collective of a step."""
+    """Blocking all-reduce (sum) of a flat tensor."""
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
-def attach(net):
-    """Make ``net.train.run`` data-parallel over the initialised process group."""
+def allreduce_async(flat):
+    """All-reduce (sum) of one gradient bucket, asynchronous: with RCCL the collective is queued on
+    the process group's own stream behind everything already on the compute stream, the caller keeps
+    queueing the rest of the backward pass, and ``handle.wait()`` later makes the compute stream wait
+    for it (a stream dependency, the host does not block).  xGMI is point to point (7 links of
+    ~153 GB/s per GPU) and a bucket is 0.3-1.3 MB, so each all-reduce is latency- not bandwidth-bound:
+    three buckets, two of them hidden behind the remaining backward pass."""
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def sync_state(net):
+    """BatchNorm moving averages are per-replica state (every rank normalises with the statistics of
+    its own 128 images, the reference's per-batch semantics, and its averages drift apart by sampling
+    noise).  Before anything that READS them -- the statistics pass, a checkpoint -- the ranks agree on
+    their mean, so every rank evaluates the same function and rank 0's file is not one replica's view."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return net
     eng = net.engine()
+    dist.all_reduce(eng.S, op=dist.ReduceOp.SUM)
+    eng.S.div_(dist.get_world_size())
+    return net
+
+
+def attach(net, force=False):
+    """Make ``net.train.run`` data-parallel over the initialised process group."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        return net
+    eng = net.engine()
     eng.world = dist.get_world_size()
-    eng.allreduce = allreduce_sum
+    eng.allreduce = allreduce_async
     eng._graphs.clear()                        # graphs captured so far folded the optimizer into the step
     for buf in (eng.P, eng.S, eng.A):          # identical replicas to start from
         dist.broadcast(buf, src=0)

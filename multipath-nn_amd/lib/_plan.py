@@ -226,13 +226,49 @@ class Engine:
                 owner[id(p)] = (nd.idx, 0)
             for p in params_list_rec(nd.layer.router):
                 owner[id(p)] = (nd.idx, 1)
-        self.trainable = [p for p in self.net._all_params if p.trainable]
+        # Flat layout in the order the BACKWARD pass finishes the gradients, so that data-parallel
+        # training can all-reduce contiguous buckets while later gradients are still being computed:
+        #   class 0: exit parameters (heads + routers): final after mpnn_lin_bwd, before the trunk backward
+        #   class 1: conv weights / biases, deepest block first (the order the trunk backward runs)
+        #   class 2: BatchNorm gamma / beta of the blocks (written by the launch that ends the backward)
+        rev = {id(b): k for k, b in enumerate(reversed(self.blocks))}
+
+        def ready_class(p):
+            nd = self.nodes[owner[id(p)][0]]
+            if owner[id(p)][1] or nd.kind != 'block':
+                return (0, 0)
+            if type(p.owner).__name__ == 'MultiscaleConvMax':
+                return (1, rev[id(nd.block)])
+            return (2, 0)
+        self.trainable = sorted((p for p in self.net._all_params if p.trainable), key=ready_class)
         self.state_params = [p for p in self.net._all_params if not p.trainable]
-        off = 0
+        off, cls_end, blk_end = 0, {0: 0, 1: 0, 2: 0}, {}
         for p in self.trainable:
             p.offset, p.node, p.is_router = off, *owner[id(p)]
             off += p.size
+            c = ready_class(p)
+            for k in range(c[0], 3):
+                cls_end[k] = off
+            if c[0] == 1:
+                blk_end[c[1]] = off
         self.n_params = off
+        # gradient buckets [lo, hi) in floats of G (the TALR node statistics ride in the last one):
+        # exits | conv of the blocks the backward finishes first (>= 40 % of the conv floats) | the rest
+        conv_lo, conv_hi = cls_end[0], cls_end[1]
+        cut, self.dp_cut_block = conv_hi, None
+        for k in sorted(blk_end):
+            if blk_end[k] - conv_lo >= 0.4 * (conv_hi - conv_lo) and blk_end[k] < conv_hi:
+                cut, self.dp_cut_block = blk_end[k], k          # k: index in reversed(self.blocks)
+                break
+        end = off + 2 * len(self.nodes)
+        self.dp_buckets = {}                                   # name -> (lo, hi); markers of the same names in the program
+        if conv_lo > 0:
+            self.dp_buckets['exit'] = (0, conv_lo)
+        if self.dp_cut_block is not None:
+            self.dp_buckets['mid'] = (conv_lo, cut)
+            self.dp_buckets['end'] = (cut, end)
+        else:
+            self.dp_buckets['end'] = (conv_lo, end)
         soff = 0
         for p in self.state_params:
             p.offset = soff
@@ -458,7 +494,8 @@ class Engine:
         """Launch lists of one (mode, batch size).  routed ('ev' only): the routed evaluation -- every
         block runs on the sample list its parent's router produced on the device (see _program_ev)."""
         routed = bool(routed) and mode != 'tr' and bool(self.switches) and self.net._net_kind != 'sr'
-        key = (mode, n, self.multi_stream, self.group_fwd, routed)
+        dp = mode == 'tr' and self.allreduce is not None and not self.multi_stream
+        key = (mode, n, self.multi_stream, self.group_fwd, routed, dp)
         if key in self._progs:
             return self._progs[key]
         self._ensure_capacity(n, mode == 'tr')
@@ -482,10 +519,10 @@ class Engine:
             launch.args = args
             return launch
 
-        def marker(kind):                     # 'fork' / 'join' of the side streams
+        def marker(kind, tag=''):             # 'fork' / 'join' of the side streams; 'bucket': a gradient range is final
             def launch(st):
                 pass
-            launch.what, launch.flops, launch.tag = kind, 0.0, ''
+            launch.what, launch.flops, launch.tag = kind, 0.0, tag
             launch.stream, launch.waits, launch.records = 0, (), None
             return launch
 
@@ -644,9 +681,12 @@ class Engine:
         if n_exit:
             bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
             bwd.append(call(lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
+        if dp and 'exit' in self.dp_buckets:
+            bwd.append(marker('bucket', 'exit'))       # head + router gradients are final: their all-reduce starts here
         bwd.append(marker('fork'))
         dz_written = set()
-        for b in reversed(self.blocks):
+        mid_items = None
+        for kb, b in enumerate(reversed(self.blocks)):
             cp = b.conv.params
             L1 = b.L - 1
             # coarsest scale without a child block: its dy is the exit's dX alone
@@ -749,6 +789,12 @@ class Engine:
                                     C.byref(h) if h is not None else None, C.byref(v) if v is not None else None,
                                     C.byref(wgrad_args(i)), flops=fl,
                                     tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])))
+                if dp and kb == self.dp_cut_block:
+                    first = len(slab_plan['table']) // 6
+                    if first:
+                        mid_items = (len(bwd), first)
+                        bwd.append(None)                      # mpnn_slab_reduce of the items so far (filled in below)
+                    bwd.append(marker('bucket', 'mid'))
             else:
                 for i in range(L1, 0, -1):
                     bwd.append(call(lib.mpnn_msconv_dgrad_vert, 'dgrad_vert', C.byref(vert_args(i)), flops=fl_v(i),
@@ -770,14 +816,24 @@ class Engine:
                 setattr(a, field, slab[off:].data_ptr())
             tab = torch.tensor(slab_plan['table'], dtype=torch.int32, device=self.dev)
             keep += [slab, tab]
+            n_items, first = len(slab_plan['table']) // 6, 0
+            if mid_items is not None:
+                # data parallel: the conv gradients of the blocks the backward finished first are reduced
+                # from their slabs at the bucket boundary (their all-reduce then overlaps the rest of the
+                # backward pass); the launch that ends the backward takes the remaining items
+                pos, first = mid_items
+                bwd[pos] = call(lib.mpnn_slab_reduce, 'slab_reduce', slab.data_ptr(), self.G.data_ptr(),
+                                tab.data_ptr(), first)
             # slab reduction + BatchNorm finalisation (moving averages, dgamma/dbeta): one launch
             bwd.append(call(lib.mpnn_backward_finish, 'backward_finish', slab.data_ptr(), self.G.data_ptr(),
-                            tab.data_ptr(), len(slab_plan['table']) // 6, self.dsum.data_ptr(), self.dred.data_ptr(),
+                            tab[6 * first:].data_ptr(), n_items - first, self.dsum.data_ptr(), self.dred.data_ptr(),
                             self.S.data_ptr(), self.bn_table.data_ptr(), self.n_bn, self.bn_decay, n))
         else:
             bwd.append(call(lib.mpnn_bn_finalize, 'bn_finalize', self.dsum.data_ptr(), self.dred.data_ptr(),
                             self.S.data_ptr(), self.G.data_ptr(), self.bn_table.data_ptr(), self.n_bn,
                             self.bn_decay, n))
+        if dp:
+            bwd.append(marker('bucket', 'end'))
         return prog
 
     # ------------------------------------------------------------------ evaluation programs
@@ -1079,11 +1135,51 @@ class Engine:
                                             self.n_pack, z.data_ptr(), z.numel() * z.element_size(),
                                             torch.cuda.current_stream().cuda_stream), 'step_begin')
 
+    def _sections(self, prog, train):
+        """The step as a list of (launches, bucket) sections: a section ends where a gradient bucket
+        becomes final (data-parallel programs; bucket = name in self.dp_buckets), the last one has
+        bucket None.  Single-process programs are one section."""
+        ops = list(prog['fwd']) + (list(prog['bwd']) if train else [])
+        out, cur = [], []
+        for op in ops:
+            if op.what == 'bucket':
+                out.append((cur, op.tag))
+                cur = []
+            else:
+                cur.append(op)
+        if cur or not out:
+            out.append((cur, None))
+        return out
+
+    def _reduce_bucket(self, name):
+        lo, hi = self.dp_buckets[name]
+        return self.allreduce(self.G[lo:hi])
+
+    @staticmethod
+    def _wait(handles):
+        for h in handles:
+            if hasattr(h, 'wait'):
+                h.wait()
+
     def _phase_a(self, prog, train):
+        """Everything of a step except the optimizer (eager launches).  Data parallel: the all-reduce
+        of each gradient bucket is issued as soon as its section is queued -- lib/_dp.py returns an
+        asynchronous handle, so the collective runs on RCCL's stream beside the rest of the backward
+        pass; all handles are waited for (a stream-level dependency) before the optimizer."""
         self._begin(train)
-        self._launch(prog['fwd'], 0)
-        if train:
-            self._launch(prog['bwd'], 1)
+        if not (train and self.allreduce is not None):
+            self._launch(prog['fwd'], 0)
+            if train:
+                self._launch(prog['bwd'], 1)
+            return
+        handles = []
+        for k, (ops, bucket) in enumerate(self._sections(prog, train)):
+            self._launch(ops, k)
+            if bucket is not None:
+                handles.append(self._reduce_bucket(bucket))
+        if not any(op.what == 'bucket' for op in prog['bwd']):       # (multi-stream schedule: one bucket, the whole of G)
+            handles.append(self.allreduce(self.G))
+        self._wait(handles)
 
     def run(self, feed, train, routed=False):
         if len(self._event_keep) > 4096:
@@ -1102,8 +1198,6 @@ class Engine:
         if not self.use_graph:
             self._phase_a(prog, do_bwd)
             if do_bwd:
-                if self.allreduce is not None:
-                    self.allreduce(self.G)
                 self._opt(n)
         else:
             self._run_graphed(prog, do_bwd, n)
@@ -1119,30 +1213,44 @@ class Engine:
         if g is None:
             self._phase_a(prog, train)
             if train:
-                if self.allreduce is not None:
-                    self.allreduce(self.G)
                 self._opt(n)
             self._graphs[key] = 'warm'
             return
+        dp = train and self.allreduce is not None
         if g == 'warm':
             torch.cuda.synchronize()
-            single = train and self.allreduce is None      # one process: nothing sits between the phases
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                self._phase_a(prog, train)
-                if single:
-                    self._opt(n)
-            gb = None
-            if train and not single:
+            if not dp:                                     # one process: ONE graph per step
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    self._phase_a(prog, train)
+                    if train:
+                        self._opt(n)
+                g = self._graphs[key] = ([(ga, None)], None)
+            else:
+                # data parallel: one graph per section (the step up to the point where a gradient bucket
+                # is final), the bucket's all-reduce issued between the replays, and a graph for the optimizer
+                secs = []
+                for k, (ops, bucket) in enumerate(self._sections(prog, train)):
+                    gk = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gk):
+                        if k == 0:
+                            self._begin(train)
+                        self._launch(ops, k)
+                    secs.append((gk, bucket))
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb):
                     self._opt(n)
-            g = self._graphs[key] = (ga, gb)
-        ga, gb = g
-        ga.replay()
-        if train and gb is not None:
-            if self.allreduce is not None:
-                self.allreduce(self.G)
+                g = self._graphs[key] = (secs, gb)
+        secs, gb = g
+        handles = []
+        for gk, bucket in secs:
+            gk.replay()
+            if bucket is not None:
+                handles.append(self._reduce_bucket(bucket))
+        if dp:
+            if not any(b is not None for _, b in secs):
+                handles.append(self.allreduce(self.G))
+            self._wait(handles)
             gb.replay()
 
     def time_step_ops(self, mode, n, reps=10):

@@ -77,17 +77,76 @@ def test_two_ranks_match_hand_summed_gradients():
     xb, yb = _batch(1)
     ea.world = eb.world = 2
     box = {}
-    eb.allreduce = lambda G: box.__setitem__('gb', G.clone()) or G.add_(box['ga'])
-    ea.allreduce = lambda G: box.__setitem__('ga', G.clone()) or G
+    # the engine hands the collective one gradient BUCKET at a time (a view into G): b's "collective"
+    # adds a's gradients of the same range
+    def add_a(view):
+        lo = (view.data_ptr() - eb.G.data_ptr()) // 4
+        return view.add_(box['ga'][lo:lo + view.numel()])
+    eb.allreduce = add_a
+    ea.allreduce = lambda view: view
+    assert list(eb.dp_buckets) == ['exit', 'mid', 'end']
     for _ in range(3):
-        # rank a: forward+backward only (its hook records ga, leaves G); finish its step after b's G is known
+        # rank a: forward+backward only; finish its step after b's G is known
         prog = ea.program('tr', N)
+        assert [op.tag for op in prog['bwd'] if op.what == 'bucket'] == ['exit', 'mid', 'end']
         ea._stage(_feed(net_a, xa, ya)); ea._phase_a(prog, True); box['ga'] = ea.G.clone()
-        net_b.train.run(_feed(net_b, xb, yb))          # b: G_b + G_a, optimizer with 1/world
-        ea.G.add_(box['gb']); ea._opt(N)
+        net_b.train.run(_feed(net_b, xb, yb))          # b: G_b + G_a bucket by bucket, optimizer with 1/world
+        ea.G.copy_(eb.G); ea._opt(N)
     torch.cuda.synchronize()
     pa, pb = ea.P.cpu().numpy(), eb.P.cpu().numpy()
     scale = np.abs(pa).max()
     assert np.abs(pa - pb).max() <= 1e-6 * scale
     # (three steps of a net that amplifies fp32 summation-order differences: 3e-5 observed)
     assert np.abs(p0 - pa).max() <= 3e-4 * scale, np.abs(p0 - pa).max()
+
+
+def _rccl_one_rank(port, out):
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    net = _net()
+    from lib import _dp
+    assert _dp.init('nccl', force=True) == (0, 1)
+    _dp.attach(net, force=True)
+    eng = net.engine()
+    assert eng.allreduce is _dp.allreduce_async
+    x0, y = _batch(0)
+    for _ in range(4):                       # eager, capture (one graph per bucket section), two replays
+        net.train.run(_feed(net, x0, y))
+    _dp.sync_state(net)
+    torch.cuda.synchronize()
+    key = [k for k in eng._graphs if k[0] == 'tr'][0]
+    secs, gb = eng._graphs[key]
+    out['sections'] = [b for _, b in secs]
+    out['P'] = eng.P.cpu().numpy().copy()
+    dist.destroy_process_group()
+
+
+def test_rccl_path_on_one_gpu_matches_single_process():
+    """The real collective backend (nccl = RCCL) with ONE rank: process-group init, asynchronous
+    bucket all-reduces issued between the section graphs, stream-level waits, optimizer graph.  A
+    one-rank sum is the identity, so the parameters must equal a plain single-process run."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_one_rank, args=(29547, out), nprocs=1, join=True)
+    assert out['sections'] == ['exit', 'mid', 'end']
+    net = _net()
+    x0, y = _batch(0)
+    for _ in range(4):
+        net.train.run(_feed(net, x0, y))
+    torch.cuda.synchronize()
+    ref = net.engine().P.cpu().numpy()
+    assert np.abs(out['P'] - ref).max() <= 1e-6 * np.abs(ref).max()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs of one node')
+def test_two_gpus_over_rccl_torchrun(tmp_path):
+    """torchrun, one process per GPU, RCCL over xGMI: replicas stay bit-identical, the bench runs."""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+            '--master-addr', '127.0.0.1', '--master-port', '29561']
+    subprocess.check_call(base + [os.path.join(ROOT, 'tests', 'dp_nccl_worker.py')], env=env, cwd=str(tmp_path))
+    out = subprocess.check_output(base + [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5',
+                                          '--no-cpu-baseline'], env=env, cwd=str(tmp_path)).decode()
+    import json
+    line = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['rccl_ranks'] == 2 and line['value'] > 0

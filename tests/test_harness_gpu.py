@@ -153,3 +153,61 @@ def test_device_augmentation_matches_reference_fixtures():
     xd, yd = ds.augmented_training_batch_device(16, 2)
     assert np.abs(xd.cpu().numpy() - xh.astype(np.float32)).max() <= 1e-7
     assert np.array_equal(yd.cpu().numpy(), yh.astype(np.float32))
+
+
+def _resolve(obj, keys):
+    for k in keys:
+        obj = obj[k]
+    return obj
+
+
+def test_files_written_by_the_cli_serve_the_reference_consumers(tmp_path):
+    """SURVEY 8 f3.  tests/golden/access_paths.json holds every dictionary access path the
+    reference's figure scripts (scripts/make-routing-hists:14-28, make-acc-eff-plots:25-27,
+    make-nlds, make-pres-figs, make-videos) and its loader (scripts/lib/serdes.py:21-60) take into
+    `<i>-stats.npy`, `<i>-stats/<t>.npy` and `<i>.npy` (extracted from the reference tree by
+    tests/golden/make_access_paths.py).  Every path must resolve on the files THIS build's
+    train-nets writes -- both with the dense and with the routed statistics pass -- and the
+    routing histogram the reference computes from them must be a distribution."""
+    import json
+    paths = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'access_paths.json'), encoding='utf-8'))
+    for extra in ([], ['--routed-stats', '--stats-batch', '100']):
+        out = str(tmp_path / ('nets' + str(len(extra))))
+        cmd = [sys.executable, os.path.join(ROOT, 'multipath-nn_amd', 'train-nets'), 'cifar10-ac', '--synthetic',
+               '--iters', '2', '--log-every', '2', '--nets', '3', '--out', out] + extra
+        subprocess.check_call(cmd, cwd=str(tmp_path))
+        base = os.path.join(out, 'cifar10-ac')
+        files = [os.path.join(base, '0003-stats.npy'), os.path.join(base, '0003-stats', '00000002.npy')]
+        for f in files:
+            log = np.load(f, allow_pickle=True)[()]                  # the consumers' np.load(p)[()]
+            blocks = [_resolve(log, ['root', 'sinks', 0])]
+            while len(blocks[-1]['sinks']) > 1:                      # their `ℓ = ℓ['sinks'][1]` walk down the chain
+                blocks.append(blocks[-1]['sinks'][1])
+            assert len(blocks) == 8
+            for script, chains in paths['stats'].items():
+                for c in chains:
+                    if c['var'] in ('net', 'log'):
+                        _resolve(log, c['keys'])
+                    else:                                            # a block descriptor
+                        for b in blocks[:-1] if c['keys'] == ['sinks', 1] else blocks:
+                            v = _resolve(b, c['keys'])
+                            if c['keys'][-1].__class__ is str and c['keys'][-1].endswith('_by_cls'):
+                                assert len(v) == 10
+            # get_p_ev of make-routing-hists:14-28
+            p_ev = [b['sinks'][0]['stats_ts']['p_cor'] + b['sinks'][0]['stats_ts']['p_inc'] for b in blocks]
+            assert abs(sum(p_ev) - 1) < 1e-6 and min(p_ev) >= 0
+            assert 0 <= log['stats_ts']['acc'] <= 1 and 1368608 - 1 <= log['stats_ts']['moc'] <= 20699872 + 1
+        # the saved net: every key scripts/lib/serdes.py reads back, on every layer record
+        rec = np.load(os.path.join(base, '0003.npy'), allow_pickle=True)[()]
+        layer_keys = {c['keys'][0] for c in paths['net']} - {'root'}
+        assert {'type', 'root', 'hypers', 'params'} <= set(rec)
+        stack, n_layers = [rec['root']], 0
+        while stack:
+            r = stack.pop()
+            if r is None:
+                continue
+            n_layers += 1
+            assert layer_keys <= set(r), (layer_keys - set(r))
+            assert all(isinstance(v, np.ndarray) for v in r['params'].values())
+            stack += list(r['sinks']) + list(r['comps']) + [r['router']]
+        assert n_layers > 100
