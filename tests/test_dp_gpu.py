@@ -100,7 +100,7 @@ def test_two_ranks_match_hand_summed_gradients():
     assert np.abs(p0 - pa).max() <= 3e-4 * scale, np.abs(p0 - pa).max()
 
 
-def _rccl_one_rank(port, out):
+def _rccl_one_rank(_idx, port, out):
     os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     net = _net()
     from lib import _dp
