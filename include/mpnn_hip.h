@@ -42,6 +42,7 @@ extern "C" {
 #define MPNN_ACT_IDENTITY 0   /* raw values (pyramid input, gradients)      */
 #define MPNN_ACT_BN_BATCH 1   /* relu(bn(x)) with batch statistics ('tr')   */
 #define MPNN_ACT_BN_MOVING 2  /* relu(bn(x)) with moving averages  ('ev')   */
+#define MPNN_ACT_RELU 3       /* relu(x): the `Rect` after a plain `Conv` (layer_types.py:76-79) */
 
 /* An activation as its consumer sees it: pre-activation values plus the
  * BatchNorm + ReLU to apply on load.  Replaces BatchNorm.link / Rect.link /
@@ -215,6 +216,35 @@ int mpnn_wgrad_tiles(int n, int H, int W);
 int mpnn_slab_reduce(const float *slabs, float *grads, const int *table, int n_items,
                      void *stream);
 
+/* ---- single-scale Conv (scripts/lib/layer_types.py:55-74) ---------------------
+ * y = b + conv2d_same(act(x), w) with supp x supp filters, supp = 3 (the direct 3x3 MFMA body of
+ * the multiscale path) or supp = 1 (a GEMM over pixels, [n*H*W, Cin] x [Cin, Cout]).
+ *   fwd  : w = the forward pack (supp 3, mpnn_pack_weights) or the HWIO tensor itself = [Cin][Cout] (supp 1)
+ *   dgrad: dx = conv^T(g, w) [* (relu_src > 0): the producer's Rect]; w = the backward pack (supp 3) or
+ *          [Cin][Cout] (supp 1); `scratch` (supp 3 with relu_src): 2*Cin doubles, overwritten
+ *   wgrad: dw = act(x)^T (*) g, db = sum g.  supp 3: as mpnn_msconv_wgrad (n_split > 1: dw / db point into
+ *          a slab, split_stride apart, then mpnn_slab_reduce); supp 1: ADDED into (caller-zeroed) dw / db.
+ * Limits: supp 3 as the multiscale entry points; supp 1: Cin, Cout <= 256. */
+typedef struct {
+    mpnn_act a;  const float *w;  const float *bias;  float *out;
+    int n, H, W, Cout;  int supp;
+} mpnn_conv_nhwc_fwd_args;
+int mpnn_conv_nhwc_fwd(const mpnn_conv_nhwc_fwd_args *args, void *stream);
+typedef struct {
+    const float *g;  int Cg;  const float *w;
+    const float *relu_src;               /* [n,H,W,Cin] pre-activation of the producer, or NULL     */
+    double *scratch;
+    float *dx;
+    int n, H, W, Cin;  int supp;
+} mpnn_conv_nhwc_dgrad_args;
+int mpnn_conv_nhwc_dgrad(const mpnn_conv_nhwc_dgrad_args *args, void *stream);
+typedef struct {
+    mpnn_act a;  const float *g;  float *dw;  float *db;
+    long split_stride;  int n_split;
+    int n, H, W, Cout;  int supp;
+} mpnn_conv_nhwc_wgrad_args;
+int mpnn_conv_nhwc_wgrad(const mpnn_conv_nhwc_wgrad_args *args, void *stream);
+
 /* ---- exit head + router, first affine map ----------------------------------
  * y_k = flatten(act(a)) @ w_k + b_k [+ alpha_cpt * k_cpt[n] * w_k[K]] for up to
  * two weight sets sharing the input: the LogReg head's LinTrans and the
@@ -376,16 +406,17 @@ int mpnn_bn_finalize(const double *sums, const double *reds, float *state, float
                      const int *table, int n_bn, float decay, int n_img, void *stream);
 
 /* ---- TALR + L2 + momentum (net_types.py:24-37, tf.train.MomentumOptimizer) --
- * For every trainable element: g = grad + 2*k_l2*pbar_node*(w - 0);
+ * For every trainable element: g = grad + 2*k_l2*pbar_node*(w - w_eq)  (w_eq: the identity part of a
+ * `res` layer, layer_types.py:46,52,65-72: seg[5] = offset of the tensor's w_eq in `w_eq`, or -1 = zero);
  * g *= s_node (* alpha_rtr for router params), s_node = 1/sqrt(mean p_tr^2);
  * accum = mu*accum + g; w -= lr*accum.  seg table: 6 ints per work item
- * (offset, count, node, is_router, l2_bits (float as int), reserved).
+ * (offset, count, node, is_router, l2_bits (float as int), w_eq offset or -1).
  * grad_scale multiplies the raw gradients (1/world_size after an all-reduce
  * sum); inv_n = 1 / (samples behind node_stat). */
 int mpnn_talr_momentum_step(float *params, float *accum, const float *grads,
                             const int *seg, int n_seg, const float *node_stat,
                             const float *hyp, int talr, float inv_n, float grad_scale,
-                            void *stream);
+                            const float *w_eq, void *stream);
 
 /* ---- training-batch assembly (scripts/lib/data.py:10-34) -------------------
  * x_out[i] = rand_shift(rand_flip(x_src[j_i])), y_out[i] = y_src[j_i] for a dataset resident in

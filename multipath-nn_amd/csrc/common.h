@@ -98,8 +98,8 @@ __device__ __forceinline__ double slot_sum(const double *base, int C2, int idx, 
 
 __device__ __forceinline__ BnC bn_coef(const mpnn_act &b, int c) {
     BnC k;
-    k.gamma = b.gamma[c];
-    k.beta = b.beta[c];
+    k.gamma = b.mode == MPNN_ACT_RELU ? 1.f : b.gamma[c];
+    k.beta = b.mode == MPNN_ACT_RELU ? 0.f : b.beta[c];
     if (b.mode == MPNN_ACT_BN_BATCH) {
         const double inv = 1.0 / (double)b.cnt;
         double s1, s2;
@@ -109,6 +109,8 @@ __device__ __forceinline__ BnC bn_coef(const mpnn_act &b, int c) {
         var = var < 0.0 ? 0.0 : var;
         k.m = (float)mean;
         k.rstd = rsqrtf((float)var + b.eps);
+    } else if (b.mode == MPNN_ACT_RELU) {          // plain ReLU: identity coefficients (gamma / beta are not read)
+        k.m = 0.f;  k.rstd = 1.f;  k.gamma = 1.f;  k.beta = 0.f;
     } else {
         k.m = b.m_avg[c];
         k.rstd = rsqrtf(b.v_avg[c] + b.eps);

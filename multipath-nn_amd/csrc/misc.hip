@@ -236,9 +236,10 @@ __global__ __launch_bounds__(256) void talr_momentum_k(float *__restrict__ param
                                                        const float *__restrict__ grads, const int *__restrict__ seg,
                                                        const float *__restrict__ node_stat,
                                                        const float *__restrict__ hyp, int talr, float inv_n,
-                                                       float grad_scale) {
+                                                       float grad_scale, const float *__restrict__ w_eq) {
     const int *s = seg + blockIdx.x * 6;
     const int off = s[0], cnt = s[1], node = s[2], is_router = s[3];
+    const float *eq = (w_eq && s[5] >= 0) ? w_eq + s[5] : nullptr;      // identity part of a `res` layer
     const float l2 = __int_as_float(s[4]);
     const float lr = hyp[MPNN_HYP_LR], mu = hyp[MPNN_HYP_MU];
     const float pbar = node_stat[node * 2] * inv_n;                   // mean p_tr over the batch
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void talr_momentum_k(float *__restrict__ param
     for (int i = threadIdx.x; i < cnt; i += 256) {
         const float w = params[off + i];
         float g = grads[off + i] * grad_scale;
-        if (l2 != 0.f) g += 2.f * l2 * pbar * w;
+        if (l2 != 0.f) g += 2.f * l2 * pbar * (w - (eq ? eq[i] : 0.f));
         g *= scale;
         const float a = mu * accum[off + i] + g;
         accum[off + i] = a;
@@ -260,10 +261,10 @@ __global__ __launch_bounds__(256) void talr_momentum_k(float *__restrict__ param
 
 extern "C" int mpnn_talr_momentum_step(float *params, float *accum, const float *grads, const int *seg, int n_seg,
                                        const float *node_stat, const float *hyp, int talr, float inv_n,
-                                       float grad_scale, void *stream) {
+                                       float grad_scale, const float *w_eq, void *stream) {
     if (n_seg <= 0) return 0;
     hipLaunchKernelGGL(talr_momentum_k, dim3(n_seg), dim3(256), 0, (hipStream_t)stream, params, accum, grads, seg,
-                       node_stat, hyp, talr, inv_n, grad_scale);
+                       node_stat, hyp, talr, inv_n, grad_scale, w_eq);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

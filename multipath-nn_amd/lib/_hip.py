@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MPNN_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'libmpnn_hip.so')
 
-ACT_IDENTITY, ACT_BN_BATCH, ACT_BN_MOVING = 0, 1, 2
+ACT_IDENTITY, ACT_BN_BATCH, ACT_BN_MOVING, ACT_RELU = 0, 1, 2, 3
 NET_SR, NET_ACTOR, NET_CRITIC = 0, 1, 2
 HYP_LR, HYP_MU, HYP_TAU, HYP_EPS, HYP_KCPT, HYP_KDEC, HYP_KCRE, HYP_ARTR, HYP_N = 0, 1, 2, 3, 4, 5, 6, 7, 16
 MAX_NODES, MAX_SINKS = 128, 4
@@ -92,6 +92,21 @@ class ExitEvArgs(C.Structure):
                 ('child_idx', P * 4), ('child_cnt', P * 4)]
 
 
+class ConvNhwcFwdArgs(C.Structure):
+    _fields_ = [('a', Act), ('w', P), ('bias', P), ('out', P), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int),
+                ('Cout', C.c_int), ('supp', C.c_int)]
+
+
+class ConvNhwcDgradArgs(C.Structure):
+    _fields_ = [('g', P), ('Cg', C.c_int), ('w', P), ('relu_src', P), ('scratch', P), ('dx', P),
+                ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('supp', C.c_int)]
+
+
+class ConvNhwcWgradArgs(C.Structure):
+    _fields_ = [('a', Act), ('g', P), ('dw', P), ('db', P), ('split_stride', C.c_long), ('n_split', C.c_int),
+                ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int), ('supp', C.c_int)]
+
+
 class RouteArgs(C.Structure):
     _fields_ = [('net_type', C.c_int), ('n_nodes', C.c_int), ('n_leaves', C.c_int), ('n_switches', C.c_int),
                 ('max_sinks', C.c_int), ('optimistic', C.c_int), ('use_cls_err', C.c_int), ('want_grad', C.c_int),
@@ -128,7 +143,10 @@ _SIGS = {
     'mpnn_exit_ev_check': [C.POINTER(ExitEvArgs)],
     'mpnn_compact_by_branch': [P, C.c_int, P, P, P],
     'mpnn_bn_finalize': [P, P, P, P, P, C.c_int, C.c_float, C.c_int, P],
-    'mpnn_talr_momentum_step': [P, P, P, P, C.c_int, P, P, C.c_int, C.c_float, C.c_float, P],
+    'mpnn_talr_momentum_step': [P, P, P, P, C.c_int, P, P, C.c_int, C.c_float, C.c_float, P, P],
+    'mpnn_conv_nhwc_fwd': [C.POINTER(ConvNhwcFwdArgs), P],
+    'mpnn_conv_nhwc_dgrad': [C.POINTER(ConvNhwcDgradArgs), P],
+    'mpnn_conv_nhwc_wgrad': [C.POINTER(ConvNhwcWgradArgs), P],
 }
 
 EXPORTS = sorted(_SIGS) + ['mpnn_version']

@@ -287,13 +287,17 @@ class Engine:
         for p in self.state_params:
             p.data = self.S[p.offset:p.offset + p.size]
         # optimizer work items
-        seg = []
+        # `res` layers (layer_types.py:46,52,65-72): L2 pulls towards w_eq, the identity part of the init
+        seg, eqs, eq_off = [], [], 0
         for p in self.trainable:
             l2 = np.float32(p.l2).view(np.int32)
+            has_eq = bool(p.l2) and p.eq is not None
             for s in range(0, p.size, OPT_CHUNK):
-                seg += [p.offset + s, min(OPT_CHUNK, p.size - s), p.node, p.is_router, int(l2), 0]
-            if p.l2 and p.eq is not None:
-                raise NotImplementedError('residual (w_eq) L2 terms are outside the hot path')
+                seg += [p.offset + s, min(OPT_CHUNK, p.size - s), p.node, p.is_router, int(l2), eq_off + s if has_eq else -1]
+            if has_eq:
+                eqs.append(np.asarray(p.eq, np.float32).reshape(-1))
+                eq_off += p.size
+        self.w_eq = torch.from_numpy(np.concatenate(eqs)).to(dev) if eqs else None
         self.n_seg = len(seg) // 6
         self.seg = torch.tensor(seg, dtype=torch.int32, device=dev)
         # weight packs
@@ -1125,6 +1129,7 @@ class Engine:
         _hip.check(self.lib.mpnn_talr_momentum_step(
             self.P.data_ptr(), self.A.data_ptr(), self.G.data_ptr(), self.seg.data_ptr(), self.n_seg,
             self.node_stat.data_ptr(), self.hyp.data_ptr(), talr, 1.0 / (n * self.world), 1.0 / self.world,
+            self.w_eq.data_ptr() if self.w_eq is not None else None,
             torch.cuda.current_stream().cuda_stream), 'talr_momentum_step')
 
     def _begin(self, train):

@@ -135,7 +135,9 @@ class Net(metaclass=ABCMeta):
     def engine(self):
         if self._engine is None:
             from lib._plan import Engine          # imports the HIP library; raises if missing
-            self._engine = Engine(self, self._device)
+            from lib._plan_conv import ConvEngine, is_conv_net
+            # (a statically-routed chain of single-scale Conv layers has its own, simpler plan)
+            self._engine = (ConvEngine if is_conv_net(self) else Engine)(self, self._device)
         return self._engine
 
     def _run_train(self, feed):

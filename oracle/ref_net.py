@@ -110,6 +110,12 @@ class RefNet:
                                for i in range(L))
             rec['pre_bn'] = o
             x = o
+        elif name == 'Conv':                                   # layer_types.py:55-74
+            w, b = self.V(θ.w), self.V(θ.b)
+            x = conv_same(x, w) + b
+            w_eq = torch.tensor(θ.w.eq, dtype=self.dtype) if θ.w.eq is not None else 0
+            rec['c_mod'] = ϕ.k_l2 * ((w - w_eq) ** 2).sum()
+            rec['n_ops'] = x.shape[1] * x.shape[2] * w.numel()
         elif name == 'MultiscaleBatchNorm':
             x = [self._link(c, x_i, y, mode, out) for c, x_i in zip(ℓ.comps, x)]
         elif name == 'BatchNorm':

@@ -387,6 +387,8 @@ def test_talr_momentum_step(talr):
     lib = _hip.load()
     rng = np.random.default_rng(3 + talr)
     sizes = [(5000, 0, 0, 1e-4), (37, 1, 1, 1e-4), (16, 2, 0, 0.0), (2049, 3, 1, 1e-4)]     # (count, node, is_router, l2)
+    eq = rng.standard_normal(2049).astype(np.float32)       # the last tensor is a `res` layer: L2 pulls towards w_eq
+    eqd = dev(eq)
     n_nodes, n = 4, 128
     total = sum(s[0] for s in sizes)
     P, A, G = (rng.standard_normal(total).astype(np.float32) for _ in range(3))
@@ -398,12 +400,13 @@ def test_talr_momentum_step(talr):
     seg, off = [], 0
     want_P, want_A = P.astype(np.float64).copy(), A.astype(np.float64).copy()
     for cnt, node, rt, l2 in sizes:
+        has_eq = cnt == 2049
         for s0 in range(0, cnt, 2048):
-            seg += [off + s0, min(2048, cnt - s0), node, rt, int(np.float32(l2).view(np.int32)), 0]
+            seg += [off + s0, min(2048, cnt - s0), node, rt, int(np.float32(l2).view(np.int32)), s0 if has_eq else -1]
         pbar = stat[node, 0] / (n * world)
         sc = (1 / np.sqrt(stat[node, 1] / (n * world)) * (artr if rt else 1.0)) if talr else 1.0
         sl = slice(off, off + cnt)
-        g = (G[sl].astype(np.float64) / world + 2 * np.float64(np.float32(l2)) * pbar * P[sl]) * sc   # net_types.py:24-37 + layer_types.py:52
+        g = (G[sl].astype(np.float64) / world + 2 * np.float64(np.float32(l2)) * pbar * (P[sl] - (eq if has_eq else 0))) * sc   # net_types.py:24-37 + layer_types.py:52
         want_A[sl] = mu * A[sl] + g
         want_P[sl] = P[sl] - lr * want_A[sl]
         off += cnt
@@ -411,7 +414,7 @@ def test_talr_momentum_step(talr):
     segd, statd, hypd = dev(np.array(seg, np.int32), torch.int32), dev(stat), dev(hyp)
     _hip.check(lib.mpnn_talr_momentum_step(Pd.data_ptr(), Ad.data_ptr(), Gd.data_ptr(), segd.data_ptr(), len(seg) // 6,
                                            statd.data_ptr(), hypd.data_ptr(), talr, 1.0 / (n * world), 1.0 / world,
-                                           stream()), 'talr_momentum_step')
+                                           eqd.data_ptr(), stream()), 'talr_momentum_step')
     torch.cuda.synchronize()
     close(Ad.cpu().numpy(), want_A, 1e-6, 'accumulators')
     close(Pd.cpu().numpy(), want_P, 1e-6, 'parameters')
