@@ -113,7 +113,7 @@ class ConvEngine:
         # one zero arena: loss | reduction scratch | G (+ node statistics)
         self.cmax = max(self.C)
         zb = 32 + 16 * self.cmax * 16
-        self._zarena = torch.zeros(zb + 4 * (off + 4), dtype=torch.uint8, device=dev)
+        self._zarena = torch.zeros(zb + (4 * (off + 4) + 15) // 16 * 16, dtype=torch.uint8, device=dev)
         self.loss = self._zarena[:32].view(torch.float64)
         self.scratch = self._zarena[32:zb].view(torch.float64)
         self.G = self._zarena[zb:].view(torch.float32)[:off + 4]
