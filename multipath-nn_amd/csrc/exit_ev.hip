@@ -193,7 +193,8 @@ __global__ __launch_bounds__(EV_WAVES * 64) void exit_ev_k(const mpnn_exit_ev_ar
         int base = 0;
         if (lane == 0) base = atomicAdd(a.child_cnt[i], (int)__popcll(m));
         base = __shfl(base, 0);
-        if (mine && arg == i) a.child_idx[i][base + __popcll(m & ((1ull << lane) - 1ull))] = my;
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (mine && arg == i && pos < a.n) a.child_idx[i][pos] = my;       // (a list holds at most n samples: counts not cleared by the caller must not write past it)
     }
 }
 

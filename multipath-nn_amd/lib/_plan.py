@@ -244,6 +244,10 @@ class Engine:
         self.state_params = [p for p in self.net._all_params if not p.trainable]
         off, cls_end, blk_end = 0, {0: 0, 1: 0, 2: 0}, {}
         for p in self.trainable:
+            # every tensor starts on a 16-byte boundary: the kernels that stream gradients (slab reduction:
+            # float4 loads and stores) take a 4x slower scalar path for a misaligned destination, and one
+            # 10-float head bias would misalign everything behind it
+            off = (off + 3) // 4 * 4
             p.offset, p.node, p.is_router = off, *owner[id(p)]
             off += p.size
             c = ready_class(p)
@@ -251,6 +255,7 @@ class Engine:
                 cls_end[k] = off
             if c[0] == 1:
                 blk_end[c[1]] = off
+        off = (off + 3) // 4 * 4
         self.n_params = off
         # gradient buckets [lo, hi) in floats of G (the TALR node statistics ride in the last one):
         # exits | conv of the blocks the backward finishes first (>= 40 % of the conv floats) | the rest

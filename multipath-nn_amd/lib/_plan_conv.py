@@ -106,8 +106,10 @@ class ConvEngine:
         self.state_params = []
         off = 0
         for p in self.trainable:
+            off = (off + 3) // 4 * 4               # 16-byte aligned tensors (float4 paths of the slab reduction)
             p.offset, p.node, p.is_router = off, owner[id(p)], 0
             off += p.size
+        off = (off + 3) // 4 * 4
         self.n_params = off
         self.P, self.A = torch.zeros(off, device=dev), torch.zeros(off, device=dev)
         # one zero arena: loss | reduction scratch | G (+ node statistics)
