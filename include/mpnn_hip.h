@@ -36,7 +36,9 @@ extern "C" {
  * thousands of workgroups do not serialise on one address; readers add the
  * slots.  A statistics buffer is [MPNN_BN_SLOTS][2*C] doubles of which the
  * first `nslot` are used (few slots for layers with few workgroups: every
- * consumer workgroup re-adds them in its prologue). */
+ * consumer workgroup re-adds them in its prologue).  MPNN_BN_SLOTS is the CAPACITY callers size
+ * the buffers for; every record carries the number actually used (mpnn_act.nslot, out_nslot,
+ * red_nslot: the engine uses 8 everywhere, lib/_plan.py:_nslot -- measured best). */
 #define MPNN_BN_SLOTS 16
 
 #define MPNN_ACT_IDENTITY 0   /* raw values (pyramid input, gradients)      */

@@ -874,7 +874,8 @@ template <int GK, int MT, int NT, int WM, int WN, int EPI>
 static int conv_launch_cfg(ConvP &p, bool small_a, hipStream_t st) {
     constexpr int CT = WN * NT * 16;
     p.n_tiles = conv_grid_x<GK>(p.n, p.H, p.W);
-    { const char *e = getenv("MPNN_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+    static const int dbg_env = [] { const char *e = getenv("MPNN_CONV_DBG"); return e ? atoi(e) : 0; }();   // (read once)
+    p.dbg = dbg_env;
     const int gy = p.Cout / CT;
     const int gx = conv_cap_gx(p.n_tiles, gy);
     dim3 grid(gx, gy), block(256);

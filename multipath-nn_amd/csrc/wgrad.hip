@@ -446,16 +446,21 @@ __device__ __forceinline__ void slab_item(const float *__restrict__ slabs, float
     if (i < cnt) {
         if (vec && i + 4 <= cnt) {
             const float *base = slabs + src + i;
-            f32x4 a[8];
+            f32x4 a[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < 16; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             int sl = s0;
-            for (; sl + 8 <= s1; sl += 8) {
+            for (; sl + 16 <= s1; sl += 16) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a[u] += *(const f32x4 *)(base + (size_t)(sl + u) * stride);
+                for (int u = 0; u < 16; ++u) a[u] += *(const f32x4 *)(base + (size_t)(sl + u) * stride);
+            }
+            for (; sl + 4 <= s1; sl += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] += *(const f32x4 *)(base + (size_t)(sl + u) * stride);
             }
             for (; sl < s1; ++sl) a[0] += *(const f32x4 *)(base + (size_t)sl * stride);
-            tot = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+            tot = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+                  (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
         } else {
             for (int j = 0; j < 4 && i + j < cnt; ++j) {
                 float acc = 0.f;
