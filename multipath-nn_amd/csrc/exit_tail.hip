@@ -16,6 +16,10 @@
 #define TS 4           // max sinks
 #define TC 16          // max classes
 #define CHUNK 128      // samples held in LDS
+// LDS pitch of a per-sample row of TR floats.  17, not 16: in the per-sample phases lane s reads
+// row s, and with a pitch of 16 floats the 64 lanes of a wave fall on 4 banks (16-way conflicts:
+// every LDS access of those phases took 16 passes -- 3.6 us per phase in the phase trace).
+#define TP 17
 
 // Sum over samples of f(s, c) for channel c < TR; totals land in out[c] (LDS).
 template <typename F>
@@ -43,10 +47,10 @@ __device__ void bn_stats(const float *x, int n, int R, int mode, float eps, floa
                          float *v_avg, float m_old, float v_old, float *scratch, float *mean, float *rstd) {
     const int tid = threadIdx.x;
     if (mode == MPNN_ACT_BN_BATCH) {
-        chan_reduce(n, scratch, mean, [&](int s, int c) { return x[s * TR + c]; });
+        chan_reduce(n, scratch, mean, [&](int s, int c) { return x[s * TP + c]; });
         if (tid < TR) mean[tid] /= (float)n;
         __syncthreads();
-        chan_reduce(n, scratch, rstd, [&](int s, int c) { const float d = x[s * TR + c] - mean[c]; return d * d; });
+        chan_reduce(n, scratch, rstd, [&](int s, int c) { const float d = x[s * TP + c] - mean[c]; return d * d; });
         if (tid < R) {
             const float var = rstd[tid] / (float)n;
             m_avg[tid] = decay * m_old + (1.f - decay) * mean[tid];
@@ -86,8 +90,8 @@ __device__ __forceinline__ void stage_rows(float *dst, const float *src, int row
     }
 #pragma unroll
     for (int k = 0; k < CHUNK * TR / 256; ++k) {
-        const int i = threadIdx.x + k * 256;
-        if (i < rows * TR) dst[i] = v[k];
+        const int i = threadIdx.x + k * 256, s = i / TR, c = i & (TR - 1);
+        if (s < rows) dst[s * TP + c] = v[k];
     }
 }
 
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
     __shared__ float scratch[256];
     __shared__ float bnp[4 * TR];                 // mean1, rstd1, mean2, rstd2
     __shared__ float w2s[TR * TR], w3s[TR * TS], vec[5 * TR + TS];
-    __shared__ float h1s[CHUNK * TR], h2s[CHUNK * TR];
+    __shared__ float h1s[CHUNK * TP], h2s[CHUNK * TP];
 
     // The router's inputs and parameters are requested FIRST; the head (softmax, cross-entropy: its own
     // loads, exp/log, stores) runs while they fly.
@@ -148,13 +152,13 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
         float a1[TR];
 #pragma unroll
         for (int c = 0; c < TR; ++c)
-            a1[c] = fmaxf(vec[c] * (h1s[s * TR + c] - bnp[c]) * bnp[TR + c] + vec[TR + c], 0.f);
+            a1[c] = fmaxf(vec[c] * (h1s[s * TP + c] - bnp[c]) * bnp[TR + c] + vec[TR + c], 0.f);
 #pragma unroll
         for (int j = 0; j < TR; ++j) {
             float h = vec[2 * TR + j];
 #pragma unroll
             for (int c = 0; c < TR; ++c) h += a1[c] * w2s[c * TR + j];
-            h2s[s * TR + j] = h;
+            h2s[s * TP + j] = h;
             if (j < R) a.h2[s * R + j] = h;
         }
     }
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
         float a2[TR];
 #pragma unroll
         for (int c = 0; c < TR; ++c)
-            a2[c] = fmaxf(vec[3 * TR + c] * (h2s[s * TR + c] - bnp[2 * TR + c]) * bnp[3 * TR + c] + vec[4 * TR + c], 0.f);
+            a2[c] = fmaxf(vec[3 * TR + c] * (h2s[s * TP + c] - bnp[2 * TR + c]) * bnp[3 * TR + c] + vec[4 * TR + c], 0.f);
 #pragma unroll
         for (int i = 0; i < TS; ++i) {
             float r = vec[5 * TR + i];
@@ -191,31 +195,55 @@ extern "C" int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int coun
 }
 
 // ------------------------------- backward -----------------------------------
+// Sums over the batch as MFMA contractions: D[i][j] = sum_s A[s][i] * B[s][j] over the (<= 128) samples
+// held in LDS, 16 x 16 outputs per wave, four samples per v_mfma_f32_16x16x4_f32.  (The first version
+// looped over the samples in a handful of threads: four phases of 1.5-5 us each on the critical path.)
+// fa(s, i) / fb(s, j): the operands (any expression over LDS rows); rows s >= n contribute zero.
+template <typename FA, typename FB>
+__device__ __forceinline__ f32x4 contract(int n, FA fa, FB fb) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int it = 0; it < CHUNK / 4; ++it) {
+        const int s = 4 * it + g;
+        const bool ok = s < n;
+        const float av = ok ? fa(s, li) : 0.f, bv = ok ? fb(s, li) : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    mfma_drain();
+    return acc;                                    // D[row = 4g + r][col = li] = acc[r]
+}
+
 __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_args *__restrict__ tab) {
     const mpnn_exit_tail_bwd_args &b = tab[blockIdx.x];
     const mpnn_exit_tail_args &a = b.f;
     const int tid = threadIdx.x, n = a.n;
+    const int lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     trace_stamp(0); trace_note(6, 13);
 
     const int R = a.R, S = a.n_sinks;
     __shared__ float w2s[TR * TR], w3s[TR * TS], vec[4 * TR], bnp[4 * TR];
     __shared__ float red[4 * TR];                 // dbeta2, dgamma2, dbeta1, dgamma1
-    __shared__ float rowA[CHUNK * TR], rowB[CHUNK * TR];
-    __shared__ float h1s[CHUNK * TR], h2s[CHUNK * TR], drs[CHUNK * TS];
+    __shared__ float rowA[CHUNK * TP], rowB[CHUNK * TP], rowC[CHUNK * TP];
+    __shared__ float h1s[CHUNK * TP], h2s[CHUNK * TP], drs[CHUNK * TS];
     // ONE memory round trip for everything the kernel reads: the head's operands go to registers
     // first, then the router tail's inputs are requested; head arithmetic and stores follow.
-    const bool has_head = a.z && b.dz && tid < n;       // (n <= CHUNK <= 256: one sample per thread)
+    // The head's backward (one sample per thread) runs on waves 2-3 while waves 0-1 carry the first
+    // per-sample phase of the router tail: the two halves of the exit are independent.
+    const int hs = tid - 128;                            // the head sample of this thread (waves 2, 3)
+    const bool has_head = a.z && b.dz && hs >= 0 && hs < n;
     float hz[TC], hy[TC], hw = 0.f;
     {
         const int nc = a.n_cls;
 #pragma unroll
         for (int k = 0; k < TC; ++k) {
             const bool ok = has_head && k < nc;
-            hz[k] = a.z ? a.z[ok ? (size_t)tid * nc + k : 0] : 0.f;
-            hy[k] = a.y ? a.y[ok ? (size_t)tid * nc + k : 0] : 0.f;
+            hz[k] = a.z ? a.z[ok ? (size_t)hs * nc + k : 0] : 0.f;
+            hy[k] = a.y ? a.y[ok ? (size_t)hs * nc + k : 0] : 0.f;
             if (!ok) { hz[k] = 0.f; hy[k] = 0.f; }
         }
-        if (has_head) hw = b.w_cerr[tid];
+        if (has_head) hw = b.w_cerr[hs];
     }
     const bool has_router = a.h1 && n <= CHUNK;
     if (has_router) {
@@ -228,8 +256,8 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
             const float v = b.dr[ok ? (size_t)s * a.r_stride + k : 0];
             if (i < n * TS) drs[i] = ok ? v : 0.f;
         }
-        for (int i = tid; i < TR * TR; i += 256) { const int c = i / TR, j = i & (TR - 1); w2s[i] = (c < R && j < R) ? a.w2[c * R + j] : 0.f; }
-        for (int i = tid; i < TR * TS; i += 256) { const int c = i / TS, k = i & (TS - 1); w3s[i] = (c < R && k < S) ? a.w3[c * S + k] : 0.f; }
+        { const int c = tid / TR, j = tid & (TR - 1); w2s[tid] = (c < R && j < R) ? a.w2[c * R + j] : 0.f; }
+        if (tid < TR * TS) { const int c = tid / TS, k = tid & (TS - 1); w3s[tid] = (c < R && k < S) ? a.w3[c * S + k] : 0.f; }
         if (tid < TR) {
             const bool ok = tid < R;
             vec[tid] = ok ? a.g1[tid] : 0.f; vec[TR + tid] = ok ? a.b1[tid] : 0.f;
@@ -238,120 +266,114 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
             bnp[2 * TR + tid] = ok ? a.bn_save[2 * R + tid] : 0.f; bnp[3 * TR + tid] = ok ? a.bn_save[3 * R + tid] : 0.f;
         }
     }
-    if (a.z && b.dz && n > 256) return;              // (never: the host rejects n > CHUNK)
-    if (has_head) {
+    auto head_bwd = [&]() {
+        if (!has_head) return;
         const int nc = a.n_cls;
-        {
-            const int s = tid;
-            float p[TC], gp[TC];
-            float (&z)[TC] = hz, (&y)[TC] = hy;
-            head_softmax(z, nc, p);
-            const float w = hw;
-            float dot = 0.f;
+        float p[TC], gp[TC];
+        head_softmax(hz, nc, p);
+        float dot = 0.f;
 #pragma unroll
-            for (int k = 0; k < TC; ++k) {
-                const float q = a.eps_ce / (float)nc + (1.f - a.eps_ce) * p[k];
-                gp[k] = k < nc ? -w * y[k] * (1.f - a.eps_ce) / q : 0.f;
-                dot += gp[k] * p[k];
-            }
-#pragma unroll
-            for (int k = 0; k < TC; ++k) if (k < nc) b.dz[(size_t)s * nc + k] = p[k] * (gp[k] - dot);
+        for (int k = 0; k < TC; ++k) {
+            const float q = a.eps_ce / (float)nc + (1.f - a.eps_ce) * p[k];
+            gp[k] = k < nc ? -hw * hy[k] * (1.f - a.eps_ce) / q : 0.f;
+            dot += gp[k] * p[k];
         }
-    }
-    if (!has_router) return;
+#pragma unroll
+        for (int k = 0; k < TC; ++k) if (k < nc) b.dz[(size_t)hs * nc + k] = p[k] * (gp[k] - dot);
+    };
+    if (!has_router) { head_bwd(); return; }
     __syncthreads();
     trace_stamp(1);
     const float inv_n = 1.f / (float)n;
+    auto xh2 = [&](int s, int c) { return (h2s[s * TP + c] - bnp[2 * TR + c]) * bnp[3 * TR + c]; };
+    auto xh1 = [&](int s, int c) { return (h1s[s * TP + c] - bnp[c]) * bnp[TR + c]; };
 
-    // ---- phase A: per-sample a2, masked dL/d(bn2 out); dW3, dbias3, dbeta2, dgamma2 ----
+    // ---- phase A: per-sample a2 and the masked dL/d(bn2 out) (waves 0-1); the head on waves 2-3 ----
+    head_bwd();
     if (tid < n) {
 #pragma unroll
         for (int c = 0; c < TR; ++c) {
-            const float xh = (h2s[tid * TR + c] - bnp[2 * TR + c]) * bnp[3 * TR + c];
-            const float a2 = fmaxf(vec[2 * TR + c] * xh + vec[3 * TR + c], 0.f);
+            const float a2 = fmaxf(vec[2 * TR + c] * xh2(tid, c) + vec[3 * TR + c], 0.f);
             float da = 0.f;
 #pragma unroll
             for (int i = 0; i < TS; ++i) da += drs[tid * TS + i] * w3s[c * TS + i];
-            rowA[tid * TR + c] = a2;
-            rowB[tid * TR + c] = a2 > 0.f ? da : 0.f;
+            rowA[tid * TP + c] = a2;
+            rowB[tid * TP + c] = a2 > 0.f ? da : 0.f;
         }
     }
     __syncthreads();
-    if (tid < TR * TS) {                           // dW3[c][i] = sum_s a2[s][c] * dr[s][i]
-        const int c = tid / TS, i = tid & (TS - 1);
-        float t = 0.f;
-        for (int s = 0; s < n; ++s) t += rowA[s * TR + c] * drs[s * TS + i];
-        if (c < R && i < S) b.dw3[c * S + i] = t;
-    } else if (tid >= 128 && tid < 128 + TR) {     // dbeta2, dgamma2
-        const int c = tid - 128;
-        float t0 = 0.f, t1 = 0.f;
-        for (int s = 0; s < n; ++s) {
-            const float d = rowB[s * TR + c];
-            t0 += d; t1 += d * (h2s[s * TR + c] - bnp[2 * TR + c]) * bnp[3 * TR + c];
-        }
-        red[c] = t0; red[TR + c] = t1;
-        if (c < R) { b.db2[c] = t0; b.dg2[c] = t1; }
-    } else if (tid >= 192 && tid < 192 + TS) {     // dbias3
-        const int i = tid - 192;
-        float t = 0.f;
-        for (int s = 0; s < n; ++s) t += drs[s * TS + i];
-        if (i < S) b.dbias3[i] = t;
+    // dW3 = a2^T dr | dbias3 = sum dr | dbeta2 = sum d, dgamma2 = sum d * xhat2: one wave each
+    if (wave == 0) {
+        const f32x4 d = contract(n, [&](int s, int i) { return rowA[s * TP + i]; },
+                                 [&](int s, int j) { return j < TS ? drs[s * TS + j] : 0.f; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int c = 4 * g + r; if (c < R && li < S) b.dw3[c * S + li] = d[r]; }
+    } else if (wave == 1) {
+        const f32x4 d = contract(n, [&](int, int i) { return i == 0 ? 1.f : 0.f; },
+                                 [&](int s, int j) { return j < TS ? drs[s * TS + j] : 0.f; });
+        if (g == 0 && li < S) b.dbias3[li] = d[0];
+    } else if (wave == 2) {
+        const f32x4 d = contract(n, [&](int, int i) { return i == 0 ? 1.f : 0.f; },
+                                 [&](int s, int j) { return rowB[s * TP + j]; });
+        if (g == 0) { red[li] = d[0]; if (li < R) b.db2[li] = d[0]; }
+    } else {
+        const f32x4 d = contract(n, [&](int, int i) { return i == 0 ? 1.f : 0.f; },
+                                 [&](int s, int j) { return rowB[s * TP + j] * xh2(s, j); });
+        if (g == 0) { red[TR + li] = d[0]; if (li < R) b.dg2[li] = d[0]; }
     }
     __syncthreads();
     trace_stamp(2);
 
-    // ---- phase B: dh2 (BN2 backward), a1; dW2 ----
+    // ---- phase B: dh2 (BatchNorm-2 backward) and a1 ----
     if (tid < n) {
 #pragma unroll
         for (int c = 0; c < TR; ++c) {
-            const float xh = (h2s[tid * TR + c] - bnp[2 * TR + c]) * bnp[3 * TR + c];
-            const float dh2 = vec[2 * TR + c] * bnp[3 * TR + c] * (rowB[tid * TR + c] - red[c] * inv_n - xh * red[TR + c] * inv_n);
-            rowB[tid * TR + c] = dh2;
-            rowA[tid * TR + c] = fmaxf(vec[c] * (h1s[tid * TR + c] - bnp[c]) * bnp[TR + c] + vec[TR + c], 0.f);   // a1
+            const float dh2 = vec[2 * TR + c] * bnp[3 * TR + c] * (rowB[tid * TP + c] - red[c] * inv_n - xh2(tid, c) * red[TR + c] * inv_n);
+            rowB[tid * TP + c] = dh2;
+            rowA[tid * TP + c] = fmaxf(vec[c] * xh1(tid, c) + vec[TR + c], 0.f);   // a1
         }
     }
     __syncthreads();
-    {                                              // dW2[c][j] = sum_s a1[s][c] * dh2[s][j]; 256 threads = 16 x 16
-        const int c = tid / TR, j = tid & (TR - 1);
-        float t = 0.f;
-        for (int s = 0; s < n; ++s) t += rowA[s * TR + c] * rowB[s * TR + j];
-        if (c < R && j < R) b.dw2[c * R + j] = t;
+    // dW2 = a1^T dh2 | dbias2 = sum dh2 (waves 0, 1); waves 2, 3: per-sample masked dL/d(bn1 out) -> rowC
+    if (wave == 0) {
+        const f32x4 d = contract(n, [&](int s, int i) { return rowA[s * TP + i]; }, [&](int s, int j) { return rowB[s * TP + j]; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int c = 4 * g + r; if (c < R && li < R) b.dw2[c * R + li] = d[r]; }
+    } else if (wave == 1) {
+        const f32x4 d = contract(n, [&](int, int i) { return i == 0 ? 1.f : 0.f; }, [&](int s, int j) { return rowB[s * TP + j]; });
+        if (g == 0 && li < R) b.dbias2[li] = d[0];
+    } else {
+        const int s = tid - 128;
+        if (s < n) {
+            float dh2[TR];
+#pragma unroll
+            for (int j = 0; j < TR; ++j) dh2[j] = rowB[s * TP + j];
+#pragma unroll
+            for (int c = 0; c < TR; ++c) {
+                float da1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < TR; ++j) da1 += dh2[j] * w2s[c * TR + j];
+                rowC[s * TP + c] = rowA[s * TP + c] > 0.f ? da1 : 0.f;
+            }
+        }
     }
     __syncthreads();
     trace_stamp(3);
-    // ---- phase C: masked dL/d(bn1 out) overwrites rowA; dbias2, dbeta1, dgamma1 ----
-    if (tid < n) {
-        float dh2[TR];
-#pragma unroll
-        for (int j = 0; j < TR; ++j) dh2[j] = rowB[tid * TR + j];
-#pragma unroll
-        for (int c = 0; c < TR; ++c) {
-            float da1 = 0.f;
-#pragma unroll
-            for (int j = 0; j < TR; ++j) da1 += dh2[j] * w2s[c * TR + j];
-            rowA[tid * TR + c] = rowA[tid * TR + c] > 0.f ? da1 : 0.f;
-        }
-    }
-    __syncthreads();
-    if (tid < TR) {
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-        for (int s = 0; s < n; ++s) {
-            t0 += rowB[s * TR + tid];
-            const float d = rowA[s * TR + tid];
-            t1 += d; t2 += d * (h1s[s * TR + tid] - bnp[tid]) * bnp[TR + tid];
-        }
-        red[2 * TR + tid] = t1; red[3 * TR + tid] = t2;
-        if (tid < R) { b.dbias2[tid] = t0; b.db1[tid] = t1; b.dg1[tid] = t2; }
+    // dbeta1 = sum d1, dgamma1 = sum d1 * xhat1
+    if (wave == 0) {
+        const f32x4 d = contract(n, [&](int, int i) { return i == 0 ? 1.f : 0.f; }, [&](int s, int j) { return rowC[s * TP + j]; });
+        if (g == 0) { red[2 * TR + li] = d[0]; if (li < R) b.db1[li] = d[0]; }
+    } else if (wave == 1) {
+        const f32x4 d = contract(n, [&](int, int i) { return i == 0 ? 1.f : 0.f; }, [&](int s, int j) { return rowC[s * TP + j] * xh1(s, j); });
+        if (g == 0) { red[3 * TR + li] = d[0]; if (li < R) b.dg1[li] = d[0]; }
     }
     __syncthreads();
     trace_stamp(4);
-    // ---- phase D: dh1 (BN1 backward) ----
+    // ---- phase D: dh1 (BatchNorm-1 backward) ----
     for (int i = tid; i < n * TR; i += 256) {
         const int s = i / TR, c = i & (TR - 1);
-        if (c < R) {
-            const float xh1 = (h1s[i] - bnp[c]) * bnp[TR + c];
-            b.dh1[s * R + c] = vec[c] * bnp[TR + c] * (rowA[i] - red[2 * TR + c] * inv_n - xh1 * red[3 * TR + c] * inv_n);
-        }
+        if (c < R)
+            b.dh1[s * R + c] = vec[c] * bnp[TR + c] * (rowC[s * TP + c] - red[2 * TR + c] * inv_n - xh1(s, c) * red[3 * TR + c] * inv_n);
     }
     trace_stamp(5);
 }

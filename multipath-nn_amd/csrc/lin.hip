@@ -35,28 +35,44 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
     const bool valid = row < a.n;
     const int M0 = a.w[0] ? a.M[0] : 0, M1 = a.w[1] ? a.M[1] : 0;
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    for (int kb = wid; kb < (K >> 4); kb += LF_WAVES) {
-        const int k = kb * 16 + 4 * g;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        float b0[4], b1[4];
-        if (valid) x = *(const f32x4 *)(a.a.x + (size_t)row * K + k);
+    // LF_UN 16-feature blocks per iteration, ALL their loads issued before the first MFMA: a wave's K
+    // share is a chain of dependent memory round trips (one per iteration), 8 of them at K = 2048 with
+    // one block per iteration -- two with four.
+    constexpr int LF_UN = 4;
+    const int nkb = K >> 4;
+    const float *xrow = a.a.x + (size_t)(valid ? row : 0) * K;
+    for (int kb = wid * LF_UN; kb < nkb; kb += LF_WAVES * LF_UN) {
+        f32x4 x[LF_UN];
+        float b0[LF_UN][4], b1[LF_UN][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            b0[j] = li < M0 ? a.w[0][(size_t)(k + j) * M0 + li] : 0.f;
-            b1[j] = li < M1 ? a.w[1][(size_t)(k + j) * M1 + li] : 0.f;
-        }
-        if (valid && bn) {
-            const int c = k % C;
+        for (int u = 0; u < LF_UN; ++u) {
+            const int kk = kb + u < nkb ? kb + u : kb;          // (past the end: a repeat of the first block, masked below)
+            const int k = kk * 16 + 4 * g;
+            x[u] = *(const f32x4 *)(xrow + k);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float *cc = cA + (c + j) * 3;
-                x[j] = fmaxf((x[j] - cc[0]) * cc[1] + cc[2], 0.f);
+                b0[u][j] = li < M0 ? a.w[0][(size_t)(k + j) * M0 + li] : 0.f;
+                b1[u][j] = li < M1 ? a.w[1][(size_t)(k + j) * M1 + li] : 0.f;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], b0[j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j], b1[j], acc1, 0, 0, 0);
+        for (int u = 0; u < LF_UN; ++u) {
+            const bool on = valid && kb + u < nkb;
+            const int k = (kb + u) * 16 + 4 * g;
+            if (bn) {
+                const int c = k % C;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float *cc = cA + (c + j) * 3;
+                    x[u][j] = fmaxf((x[u][j] - cc[0]) * cc[1] + cc[2], 0.f);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xv = on ? x[u][j] : 0.f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, b0[u][j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, b1[u][j], acc1, 0, 0, 0);
+            }
         }
     }
     trace_stamp(4);
