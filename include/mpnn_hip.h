@@ -355,7 +355,8 @@ int mpnn_exit_ev_check(const mpnn_exit_ev_args *host_record);
  * and SRNet's loss (net_types.py:93-95).  One thread per sample walks the
  * routing tree given as a device table `nodes` (8 ints per node, DFS preorder:
  * parent, sink_index, n_sinks, switch_id (-1: none), leaf_id (-1: none),
- * n_leaves, reserved, reserved), `sw_children` [n_switches][max_sinks] node
+ * n_leaves, depth (root = 0), rank of the node when all nodes are sorted by
+ * (depth, preorder index) -- the kernel walks the tree one LEVEL at a time), `sw_children` [n_switches][max_sinks] node
  * ids, and `node_ops` (n_ops + router.n_ops per node).
  *   outputs: p_tr, p_ev [n_nodes][n]; w_cerr [n_leaves][n] = dL/dc_err;
  *            dr [n_switches][n][max_sinks] = dL/dr; node_stat [n_nodes][2] =

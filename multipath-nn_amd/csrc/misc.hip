@@ -365,6 +365,7 @@ int mpnn_trace_install_dgrad(void *buf);
 int mpnn_trace_install_wgrad(void *buf);
 int mpnn_trace_install_lin(void *buf);
 int mpnn_trace_install_tail(void *buf);
+int mpnn_trace_install_route(void *buf);
 
 extern "C" int mpnn_debug_set_trace(unsigned long long *buf) {
     int rc = mpnn_trace_install_fwd(buf);
@@ -372,6 +373,7 @@ extern "C" int mpnn_debug_set_trace(unsigned long long *buf) {
     if (!rc) rc = mpnn_trace_install_wgrad(buf);
     if (!rc) rc = mpnn_trace_install_lin(buf);
     if (!rc) rc = mpnn_trace_install_tail(buf);
+    if (!rc) rc = mpnn_trace_install_route(buf);
     return rc;
 }
 

@@ -37,6 +37,7 @@ template <int RB>
 __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = a.n, NN = a.n_nodes, MS = a.max_sinks;
+    trace_stamp(0); trace_note(6, 14);
     float *P = lds;                               // p_tr per node            [NN][RB]
     float *V = P + NN * RB;                       // actor: V ; critic: c_ev  [NN][RB]
     float *O = V + NN * RB;                       // critic: c_opt            [NN][RB]
@@ -48,18 +49,35 @@ __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
     float *SM = OPS + ((NN + 3) & ~3);            // softmax(r / tau)         [n_switches*MS][RB]
     int *ARG = (int *)(SM + a.n_switches * MS * RB);   // arg-max sink       [n_switches][RB]
     int *SWN = ARG + a.n_switches * RB;           // sinks of each switch     [n_switches]
+    int *LV = SWN + a.n_switches;                 // nodes in (depth, preorder) order   [NN]
+    int *LS = LV + NN;                            // first LV slot of each depth level   [NN + 2]
     {
         const int s0 = blockIdx.x * RB;
         const int rows_r = a.n_switches * MS, rows = rows_r + 2 * a.n_leaves;
-        for (int i = threadIdx.x; i < rows * RB; i += 256) {
-            const int row = i / RB, t = i - row * RB, s = s0 + t;
-            float v = 0.f;
-            if (s < n) {
-                if (row < rows_r) v = a.r[((size_t)(row / MS) * n + s) * MS + (row % MS)];
-                else if (row < rows_r + a.n_leaves) v = a.c_err[(size_t)(row - rows_r) * n + s];
-                else v = a.d_cor[(size_t)(row - rows_r - a.n_leaves) * n + s];
+        // Eight loads in flight per thread, from clamped addresses with no branch around them (a rolled
+        // loop with one conditional load per iteration is one dependent memory round trip per iteration:
+        // 8 of them = most of this kernel's time before).
+        const int total = rows * RB;
+        for (int base = 0; base < total; base += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + threadIdx.x + u * 256;
+                const int ic = i < total ? i : 0;
+                const int row = ic / RB, t = ic - row * RB, s = s0 + t;
+                const bool ok = i < total && s < n;
+                const int sc = ok ? s : 0;
+                const float *src = row < rows_r ? a.r + ((size_t)(row / MS) * n + sc) * MS + (row % MS)
+                                 : row < rows_r + a.n_leaves ? a.c_err + (size_t)(row - rows_r) * n + sc
+                                                             : a.d_cor + (size_t)(row - rows_r - a.n_leaves) * n + sc;
+                v[u] = *src;
+                v[u] = ok ? v[u] : 0.f;
             }
-            RIN[i] = v;                            // RIN, CE, DC are contiguous
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + threadIdx.x + u * 256;
+                if (i < total) RIN[i] = v[u];      // RIN, CE, DC are contiguous
+            }
         }
         for (int i = threadIdx.x; i < NN * 8; i += 256) ND[i] = a.nodes[i];
         for (int i = threadIdx.x; i < NN; i += 256) {
@@ -67,8 +85,17 @@ __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
             if (sw >= 0) SWN[sw] = a.nodes[i * 8 + 2];
         }
         for (int i = threadIdx.x; i < NN; i += 256) OPS[i] = a.node_ops[i];
+        // level lists from the table's depth (nd[6]) and rank in (depth, preorder) order (nd[7])
+        for (int i = threadIdx.x; i < NN + 2; i += 256) LS[i] = NN;
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < NN; i += 256) {
+        const int d = a.nodes[i * 8 + 6], rk = a.nodes[i * 8 + 7];
+        LV[rk] = i;
+        atomicMin(&LS[d], rk);
+    }
+    __syncthreads();
+    trace_stamp(1);
     // softmax(r / tau) and arg-max (first index on ties) of EVERY (switch, sample), by all four waves:
     // the serial tree walks below only read them (they used to recompute them up to three times per
     // node inside the one working wave).
@@ -93,7 +120,10 @@ __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
         }
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6;             // 0: tree walks; 1: TALR node statistics; 2, 3: done
+    trace_stamp(2);
+    const int wave = threadIdx.x >> 6;
+    int D = 0;                                     // deepest level
+    for (int d = 0; d < NN; ++d) if (LS[d] < NN) D = d;
     const int lane_t = threadIdx.x & 63;
     const int t = lane_t < RB ? lane_t : RB - 1;
     const int s = blockIdx.x * RB + t;
@@ -115,137 +145,149 @@ __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
         arg = ARG[sw * RB + t];
     };
 
-    // ---- top-down: p_tr, p_ev (DFS preorder: parents first); own cost terms ----
-    float pev_par = 1.f;
-    if (wave == 0)
-    for (int j = 0; j < NN; ++j) {
-        const int *nd = ND + j * 8;
-        const int par = nd[0], si = nd[1], leaf = nd[4];
-        float ptr = 1.f, pev = 1.f;
-        if (par >= 0) {
-            const int *pn = ND + par * 8;
-            const int psw = pn[3], pns = pn[2];
-            const float pp = P[par * RB + t], ppe = O[par * RB + t];   // O doubles as p_ev storage top-down
-            if (dyn && psw >= 0 && pns >= 2) {
-                float sm[MSK]; int arg;
-                soft(psw, pns, sm, arg);
-                float mine = 0.f;
-#pragma unroll
-                for (int i = 0; i < MSK; ++i) if (i == si) mine = sm[i];
-                ptr = (pp - eps_unit * (float)pn[5]) * mine + eps_unit * (float)nd[5];
-                pev = arg == si ? ppe : 0.f;
-            } else { ptr = pp; pev = ppe; }
-        }
-        P[j * RB + t] = ptr;
-        O[j * RB + t] = pev;
-        if (live) { a.p_tr[(size_t)j * n + s] = ptr; a.p_ev[(size_t)j * n + s] = pev; }
-        // own terms of the bottom-up recursions
-        const float cerr = leaf >= 0 ? CE[leaf * RB + t] : 0.f;
-        const float dcor = leaf >= 0 ? DC[leaf * RB + t] : 1.f;
-        const float ops = OPS[j];
-        const float w = type == MPNN_NET_SR ? 1.f : ptr;
-        if (leaf >= 0 && live && a.w_cerr) a.w_cerr[(size_t)leaf * n + s] = w * inv_n;
-        l_err += w * cerr;
-        if (type == MPNN_NET_ACTOR) { l_cpt += ptr * k_cpt * ops; V[j * RB + t] = cerr + k_cpt * ops; }
-        else if (type == MPNN_NET_CRITIC) {
-            const float ce = a.use_cls_err ? (leaf >= 0 ? 1.f - dcor : 0.f) : cerr;
-            V[j * RB + t] = ce + k_cpt * ops;      // c_ev accumulator (children pushed below)
-        }
-    }
-    (void)pev_par;
-
-    __syncthreads();                               // p_tr of every node is in LDS
-    if (wave >= 2) return;
-    // ---- node statistics for TALR: sum p_tr, sum p_tr^2 (wave 1, beside the bottom-up walk) ----
-    if (wave == 1) {
-        if (!a.node_stat) return;
-        for (int j = 0; j < NN; ++j) {
-            const float p = live ? P[j * RB + t] : 0.f;
-            const float s1 = wave_sum_f(p), s2 = wave_sum_f(p * p);
-            if (t == 0) { atomicAdd(a.node_stat + j * 2, s1); atomicAdd(a.node_stat + j * 2 + 1, s2); }
-        }
-        return;
-    }
-
-    // ---- bottom-up (reverse preorder: children first); each node pushes into its parent ----
-    if (type == MPNN_NET_CRITIC)
-        for (int j = 0; j < NN; ++j) O[j * RB + t] = V[j * RB + t];     // c_opt starts from the same own term
-    if (type != MPNN_NET_SR) {
-        for (int j = NN - 1; j >= 0; --j) {
+    // ---- top-down, one tree LEVEL at a time: p_tr, p_ev; own cost terms ----
+    // The nodes of a level only depend on the level above, so the four waves take them in parallel (the
+    // chains have two nodes per level: nine steps instead of a 17-node serial walk in one wave).
+    for (int d = 0; d <= D; ++d) {
+        for (int kq = LS[d] + wave; kq < LS[d + 1]; kq += 4) {
+            const int j = LV[kq];
             const int *nd = ND + j * 8;
-            const int par = nd[0], si = nd[1], ns = nd[2], sw = nd[3];
-            const float p = P[j * RB + t];
-            if (sw >= 0 && ns >= 2) {              // dynamic switch: children are final
-                const float *r = RIN + (sw * MS) * RB + t;
-                const int *kids = a.sw_children + sw * MS;
-                float sm[MSK]; int arg;
-                soft(sw, ns, sm, arg);
-                if (type == MPNN_NET_ACTOR) {
-                    const float eps_l = eps_unit * (float)nd[5];
-                    float u[MSK], ubar = 0.f, r2 = 0.f, v = V[j * RB + t];
-#pragma unroll
-                    for (int i = 0; i < MSK; ++i) {
-                        u[i] = 0.f;
-                        if (i < ns) {
-                            const float vc = V[kids[i] * RB + t];
-                            v += sm[i] * vc;
-                            u[i] = (p - eps_l) * vc;
-                            ubar += sm[i] * u[i];
-                            r2 += r[i * RB] * r[i * RB];
-                        }
-                    }
-                    V[j * RB + t] = v;
-                    l_aux += p * k_dec * r2;
-                    if (a.want_grad && live) {
-#pragma unroll
-                        for (int i = 0; i < MSK; ++i)
-                            if (i < ns)
-                                a.dr[((size_t)sw * n + s) * MS + i] =
-                                    (sm[i] * (u[i] - ubar) * inv_tau + 2.f * k_dec * p * r[i * RB]) * inv_n;
-                    }
-                } else {
-                    float cev = V[j * RB + t], mn = 0.f, cre = 0.f;
-#pragma unroll
-                    for (int i = 0; i < MSK; ++i) {
-                        if (i < ns) {
-                            const float kev = V[kids[i] * RB + t], kopt = O[kids[i] * RB + t];
-                            mn = i == 0 ? kopt : fminf(mn, kopt);
-                            if (i == arg) cev += kev;
-                            const float d = r[i * RB] + (a.optimistic ? kopt : kev);
-                            cre += d * d;
-                            if (a.want_grad && live) a.dr[((size_t)sw * n + s) * MS + i] = p * 2.f * k_cre * d * inv_n;
-                        }
-                    }
-                    V[j * RB + t] = cev;
-                    O[j * RB + t] += mn;
-                    l_aux += p * k_cre * cre;
-                }
-            }
-            // push into a STATIC parent (a dynamic parent reads its children itself)
+            const int par = nd[0], si = nd[1], leaf = nd[4];
+            float ptr = 1.f, pev = 1.f;
             if (par >= 0) {
                 const int *pn = ND + par * 8;
-                if (!(pn[3] >= 0 && pn[2] >= 2)) {
-                    V[par * RB + t] += V[j * RB + t];
-                    if (type == MPNN_NET_CRITIC) O[par * RB + t] += O[j * RB + t];
+                const int psw = pn[3], pns = pn[2];
+                const float pp = P[par * RB + t], ppe = O[par * RB + t];   // O doubles as p_ev storage top-down
+                if (dyn && psw >= 0 && pns >= 2) {
+                    float sm[MSK]; int arg;
+                    soft(psw, pns, sm, arg);
+                    float mine = 0.f;
+#pragma unroll
+                    for (int i = 0; i < MSK; ++i) if (i == si) mine = sm[i];
+                    ptr = (pp - eps_unit * (float)pn[5]) * mine + eps_unit * (float)nd[5];
+                    pev = arg == si ? ppe : 0.f;
+                } else { ptr = pp; pev = ppe; }
+            }
+            P[j * RB + t] = ptr;
+            O[j * RB + t] = pev;
+            if (live) { a.p_tr[(size_t)j * n + s] = ptr; a.p_ev[(size_t)j * n + s] = pev; }
+            // own terms of the bottom-up recursions
+            const float cerr = leaf >= 0 ? CE[leaf * RB + t] : 0.f;
+            const float dcor = leaf >= 0 ? DC[leaf * RB + t] : 1.f;
+            const float ops = OPS[j];
+            const float w = type == MPNN_NET_SR ? 1.f : ptr;
+            if (leaf >= 0 && live && a.w_cerr) a.w_cerr[(size_t)leaf * n + s] = w * inv_n;
+            l_err += w * cerr;
+            if (type == MPNN_NET_ACTOR) { l_cpt += ptr * k_cpt * ops; V[j * RB + t] = cerr + k_cpt * ops; }
+            else if (type == MPNN_NET_CRITIC) {
+                const float ce = a.use_cls_err ? (leaf >= 0 ? 1.f - dcor : 0.f) : cerr;
+                V[j * RB + t] = ce + k_cpt * ops;      // c_ev accumulator (children pushed below)
+            }
+        }
+        __syncthreads();
+    }
+    trace_stamp(3);
+    // ---- node statistics for TALR: sum p_tr, sum p_tr^2 (every wave its share of the nodes) ----
+    if (a.node_stat) {
+        for (int j = wave; j < NN; j += 4) {
+            const float p = live ? P[j * RB + t] : 0.f;
+            const float s1 = wave_sum_f(p), s2 = wave_sum_f(p * p);
+            if (lane_t == 0) { atomicAdd(a.node_stat + j * 2, s1); atomicAdd(a.node_stat + j * 2 + 1, s2); }
+        }
+    }
+    if (type == MPNN_NET_CRITIC) {
+        for (int j = wave; j < NN; j += 4) O[j * RB + t] = V[j * RB + t];     // c_opt starts from the same own term
+        __syncthreads();
+    }
+
+    // ---- bottom-up, deepest level first; each node pushes into its (static) parent ----
+    if (type != MPNN_NET_SR) {
+        for (int d = D; d >= 0; --d) {
+            for (int kq = LS[d] + wave; kq < LS[d + 1]; kq += 4) {
+                const int j = LV[kq];
+                const int *nd = ND + j * 8;
+                const int par = nd[0], ns = nd[2], sw = nd[3];
+                const float p = P[j * RB + t];
+                if (sw >= 0 && ns >= 2) {              // dynamic switch: children are final
+                    const float *r = RIN + (sw * MS) * RB + t;
+                    const int *kids = a.sw_children + sw * MS;
+                    float sm[MSK]; int arg;
+                    soft(sw, ns, sm, arg);
+                    if (type == MPNN_NET_ACTOR) {
+                        const float eps_l = eps_unit * (float)nd[5];
+                        float u[MSK], ubar = 0.f, r2 = 0.f, v = V[j * RB + t];
+#pragma unroll
+                        for (int i = 0; i < MSK; ++i) {
+                            u[i] = 0.f;
+                            if (i < ns) {
+                                const float vc = V[kids[i] * RB + t];
+                                v += sm[i] * vc;
+                                u[i] = (p - eps_l) * vc;
+                                ubar += sm[i] * u[i];
+                                r2 += r[i * RB] * r[i * RB];
+                            }
+                        }
+                        V[j * RB + t] = v;
+                        l_aux += p * k_dec * r2;
+                        if (a.want_grad && live) {
+#pragma unroll
+                            for (int i = 0; i < MSK; ++i)
+                                if (i < ns)
+                                    a.dr[((size_t)sw * n + s) * MS + i] =
+                                        (sm[i] * (u[i] - ubar) * inv_tau + 2.f * k_dec * p * r[i * RB]) * inv_n;
+                        }
+                    } else {
+                        float cev = V[j * RB + t], mn = 0.f, cre = 0.f;
+#pragma unroll
+                        for (int i = 0; i < MSK; ++i) {
+                            if (i < ns) {
+                                const float kev = V[kids[i] * RB + t], kopt = O[kids[i] * RB + t];
+                                mn = i == 0 ? kopt : fminf(mn, kopt);
+                                if (i == arg) cev += kev;
+                                const float dd = r[i * RB] + (a.optimistic ? kopt : kev);
+                                cre += dd * dd;
+                                if (a.want_grad && live) a.dr[((size_t)sw * n + s) * MS + i] = p * 2.f * k_cre * dd * inv_n;
+                            }
+                        }
+                        V[j * RB + t] = cev;
+                        O[j * RB + t] += mn;
+                        l_aux += p * k_cre * cre;
+                    }
+                }
+                // push into a STATIC parent (a dynamic parent reads its children itself; a static node has
+                // at most one sink, so nobody else writes the parent's slot in this level)
+                if (par >= 0) {
+                    const int *pn = ND + par * 8;
+                    if (!(pn[3] >= 0 && pn[2] >= 2)) {
+                        V[par * RB + t] += V[j * RB + t];
+                        if (type == MPNN_NET_CRITIC) O[par * RB + t] += O[j * RB + t];
+                    }
                 }
             }
-            (void)si;
+            __syncthreads();
         }
     }
 
+    trace_stamp(4);
     if (a.loss) {
         const double e = wave_sum_d(live ? (double)l_err : 0.0), c = wave_sum_d(live ? (double)l_cpt : 0.0);
-        const double x = wave_sum_d(live ? (double)l_aux : 0.0), cnt = wave_sum_d(live ? 1.0 : 0.0);
-        if (t == 0) { atomicAdd(a.loss, e); atomicAdd(a.loss + 1, c); atomicAdd(a.loss + 2, x); atomicAdd(a.loss + 3, cnt); }
+        const double x = wave_sum_d(live ? (double)l_aux : 0.0), cnt = wave_sum_d((live && wave == 0) ? 1.0 : 0.0);
+        if (lane_t == 0) {
+            atomicAdd(a.loss, e); atomicAdd(a.loss + 1, c); atomicAdd(a.loss + 2, x);
+            if (wave == 0) atomicAdd(a.loss + 3, cnt);
+        }
     }
+    trace_stamp(5);
 }
+
+int mpnn_trace_install_route(void *buf) { return mpnn_trace_install(buf); }
 
 extern "C" int mpnn_route(const mpnn_route_args *args, void *stream) {
     if (!args || !args->nodes || !args->p_tr || !args->p_ev) return MPNN_E_ARG;
     if (args->n_nodes > MPNN_MAX_NODES || args->max_sinks > MPNN_MAX_SINKS) return MPNN_E_SHAPE;
     if (args->n <= 0) return 0;
     const size_t per = (size_t)(3 * args->n_nodes + 2 * args->n_switches * args->max_sinks + args->n_switches + 2 * args->n_leaves) * 4;
-    const size_t fix = (size_t)(args->n_nodes * 9 + 4 + args->n_switches) * 4;
+    const size_t fix = (size_t)(args->n_nodes * 11 + 8 + args->n_switches) * 4;
     const size_t cap = 160 * 1024;
     const hipStream_t st = (hipStream_t)stream;
     const int n = args->n;

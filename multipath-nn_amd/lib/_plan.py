@@ -351,10 +351,14 @@ class Engine:
         self.bn_decay = float(self.blocks[0].bns[0].hypers.d) if self.blocks else 0.9
         # routing tables
         nodes, ops = [], []
+        for nd in self.nodes:                                   # (DFS preorder: a parent comes before its children)
+            nd.depth = 0 if nd.parent < 0 else self.nodes[nd.parent].depth + 1
+        order = sorted(range(len(self.nodes)), key=lambda j: (self.nodes[j].depth, j))
+        rank = {j: k for k, j in enumerate(order)}
         for nd in self.nodes:
             ℓ = nd.layer
             nodes += [nd.parent, nd.sink_index, len(ℓ.sinks), getattr(nd, 'switch_id', -1),
-                      getattr(nd, 'leaf_id', -1), n_leaves(ℓ), 0, 0]
+                      getattr(nd, 'leaf_id', -1), n_leaves(ℓ), nd.depth, rank[nd.idx]]
             ops.append(float(ℓ.n_ops + (ℓ.router.n_ops if ℓ.router is not None else 0)))
         kids = []
         for nd in self.switches:

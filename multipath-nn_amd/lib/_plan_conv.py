@@ -149,7 +149,7 @@ class ConvEngine:
         self.n_pack = len(desc) // 6
         self.packs = torch.zeros(max(poff, 1), device=dev)
         self.pack_desc = torch.tensor(desc if desc else [0] * 6, dtype=torch.int32, device=dev)
-        self.node_tab = torch.tensor([-1, 0, 1, -1, -1, 1, 0, 0, 0, 0, 0, -1, 0, 1, 0, 0], dtype=torch.int32, device=dev)
+        self.node_tab = torch.tensor([-1, 0, 1, -1, -1, 1, 0, 0, 0, 0, 0, -1, 0, 1, 1, 1], dtype=torch.int32, device=dev)
         self.kid_tab = torch.zeros(2, dtype=torch.int32, device=dev)
         self.node_ops = torch.tensor(self.node_ops_host, dtype=torch.float32, device=dev)
         self.hyp = torch.zeros(_hip.HYP_N, device=dev)

@@ -42,10 +42,13 @@ class Tree:
         for i, nd in enumerate(self.nodes):
             for k, c in enumerate(nd['sinks']):
                 par[c] = (i, k)
-        tab = []
+        tab, depth = [], {}
+        for i in range(len(self.nodes)):
+            depth[i] = 0 if par[i][0] < 0 else depth[par[i][0]] + 1
+        rank = {j: k for k, j in enumerate(sorted(depth, key=lambda j: (depth[j], j)))}
         for i, nd in enumerate(self.nodes):
             tab += [par[i][0], par[i][1], len(nd['sinks']), nd.get('switch_id', -1) if len(nd['sinks']) > 1 else -1,
-                    nd.get('leaf_id', -1) if not nd['sinks'] else -1, self.n_leaves(i), 0, 0]
+                    nd.get('leaf_id', -1) if not nd['sinks'] else -1, self.n_leaves(i), depth[i], rank[i]]
         kids = []
         for i in self.switches:
             row = list(self.nodes[i]['sinks'])
