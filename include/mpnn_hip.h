@@ -84,6 +84,7 @@ int mpnn_pack_weights(const float *params, float *packs, const int *desc,
  * tensor) in the same kernel -- one launch instead of a pack and two memsets. */
 int mpnn_step_begin(const float *params, float *packs, const int *desc, int n_desc,
                     void *zero, long zero_bytes, void *stream);
+/* (n_desc == 0: clear only -- the packs are kept current by mpnn_talr_momentum_step.) */
 
 /* ---- multiscale conv block, forward --------------------------------------
  * One scale of MultiscaleConvMax.link (layer_types.py:181-185):
@@ -412,14 +413,19 @@ int mpnn_bn_finalize(const double *sums, const double *reds, float *state, float
  * For every trainable element: g = grad + 2*k_l2*pbar_node*(w - w_eq)  (w_eq: the identity part of a
  * `res` layer, layer_types.py:46,52,65-72: seg[5] = offset of the tensor's w_eq in `w_eq`, or -1 = zero);
  * g *= s_node (* alpha_rtr for router params), s_node = 1/sqrt(mean p_tr^2);
- * accum = mu*accum + g; w -= lr*accum.  seg table: 6 ints per work item
- * (offset, count, node, is_router, l2_bits (float as int), w_eq offset or -1).
+ * accum = mu*accum + g; w -= lr*accum.  seg table: MPNN_SEG_INTS ints per work item
+ * (offset, count, node, is_router, l2_bits (float as int), w_eq offset or -1,
+ *  then for 3x3 conv weights: offset of the tensor in `params`, Cin, Cout, forward-pack offset,
+ *  backward-pack offset (-1: none) in `packs`; Cin = 0 for every other tensor; reserved).
+ * packs != NULL: every updated conv weight is also written to its slots of the weight packs
+ * (mpnn_pack_weights' layout), so the next step needs no packing launch.
  * grad_scale multiplies the raw gradients (1/world_size after an all-reduce
  * sum); inv_n = 1 / (samples behind node_stat). */
 int mpnn_talr_momentum_step(float *params, float *accum, const float *grads,
                             const int *seg, int n_seg, const float *node_stat,
                             const float *hyp, int talr, float inv_n, float grad_scale,
-                            const float *w_eq, void *stream);
+                            const float *w_eq, float *packs, void *stream);
+#define MPNN_SEG_INTS 12
 
 /* ---- training-batch assembly (scripts/lib/data.py:10-34) -------------------
  * x_out[i] = rand_shift(rand_flip(x_src[j_i])), y_out[i] = y_src[j_i] for a dataset resident in

@@ -15,6 +15,7 @@ __global__ __launch_bounds__(256) void pack_k(const float *__restrict__ params, 
         const long b = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         for (long i = b * 256 + threadIdx.x; i < zero_vec; i += nb * 256) zero[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (!desc) return;                                 // (clear only: the packs are kept current by the optimizer)
     const int *d = desc + blockIdx.x * 6;
     const int src = d[0], fwd = d[1], bwd = d[2], Cin = d[3], Cout = d[4];
     const int tap = blockIdx.y;
@@ -58,8 +59,16 @@ extern "C" int mpnn_pack_weights(const float *params, float *packs, const int *d
 
 extern "C" int mpnn_step_begin(const float *params, float *packs, const int *desc, int n_desc,
                                void *zero, long zero_bytes, void *stream) {
-    if (n_desc <= 0) return MPNN_E_ARG;
+    if (n_desc < 0 || (n_desc == 0 && !zero)) return MPNN_E_ARG;
     if (zero && (((size_t)zero & 15) || (zero_bytes & 15) || zero_bytes < 0)) return MPNN_E_ARG;
+    if (n_desc == 0) {                                 // clear only
+        long wgs = (zero_bytes / 16 + 1023) / 1024;
+        wgs = wgs < 1 ? 1 : (wgs > 2048 ? 2048 : wgs);
+        hipLaunchKernelGGL(pack_k, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, params, packs, (const int *)nullptr,
+                           (f32x4 *)zero, zero_bytes / 16);
+        MPNN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(pack_k, dim3(n_desc, 9, 8), dim3(256), 0, (hipStream_t)stream, params, packs, desc,
                        (f32x4 *)zero, zero ? zero_bytes / 16 : 0L);
     MPNN_LAUNCH_CHECK();
@@ -236,10 +245,17 @@ __global__ __launch_bounds__(256) void talr_momentum_k(float *__restrict__ param
                                                        const float *__restrict__ grads, const int *__restrict__ seg,
                                                        const float *__restrict__ node_stat,
                                                        const float *__restrict__ hyp, int talr, float inv_n,
-                                                       float grad_scale, const float *__restrict__ w_eq) {
-    const int *s = seg + blockIdx.x * 6;
+                                                       float grad_scale, const float *__restrict__ w_eq,
+                                                       float *__restrict__ packs) {
+    const int *s = seg + blockIdx.x * MPNN_SEG_INTS;
     const int off = s[0], cnt = s[1], node = s[2], is_router = s[3];
     const float *eq = (w_eq && s[5] >= 0) ? w_eq + s[5] : nullptr;      // identity part of a `res` layer
+    // conv weights: the updated value also goes to its slots of the k-interleaved forward pack and of the
+    // transposed, tap-flipped backward pack (mpnn_pack_weights' layout), so the next step starts with
+    // current packs and no packing launch
+    const int tbase = s[6], Cin = s[7], Cout = s[8], fwd = s[9], bwd = s[10];
+    const bool emit = packs && Cin > 0;
+    const int per_f = ((Cin + 15) >> 4) * 16 * Cout, per_b = ((Cout + 15) >> 4) * 16 * Cin, cc = Cin * Cout;
     const float l2 = __int_as_float(s[4]);
     const float lr = hyp[MPNN_HYP_LR], mu = hyp[MPNN_HYP_MU];
     const float pbar = node_stat[node * 2] * inv_n;                   // mean p_tr over the batch
@@ -255,16 +271,22 @@ __global__ __launch_bounds__(256) void talr_momentum_k(float *__restrict__ param
         g *= scale;
         const float a = mu * accum[off + i] + g;
         accum[off + i] = a;
-        params[off + i] = w - lr * a;
+        const float wn = w - lr * a;
+        params[off + i] = wn;
+        if (emit) {
+            const int e = off + i - tbase, tap = e / cc, rem = e - tap * cc, ci = rem / Cout, co = rem - ci * Cout;
+            if (fwd >= 0) packs[fwd + tap * per_f + ((ci >> 2) * Cout + co) * 4 + (ci & 3)] = wn;
+            if (bwd >= 0) packs[bwd + (8 - tap) * per_b + ((co >> 2) * Cin + ci) * 4 + (co & 3)] = wn;
+        }
     }
 }
 
 extern "C" int mpnn_talr_momentum_step(float *params, float *accum, const float *grads, const int *seg, int n_seg,
                                        const float *node_stat, const float *hyp, int talr, float inv_n,
-                                       float grad_scale, const float *w_eq, void *stream) {
+                                       float grad_scale, const float *w_eq, float *packs, void *stream) {
     if (n_seg <= 0) return 0;
     hipLaunchKernelGGL(talr_momentum_k, dim3(n_seg), dim3(256), 0, (hipStream_t)stream, params, accum, grads, seg,
-                       node_stat, hyp, talr, inv_n, grad_scale, w_eq);
+                       node_stat, hyp, talr, inv_n, grad_scale, w_eq, packs);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

@@ -75,4 +75,5 @@ def attach(net, force=False):
     eng._graphs.clear()                        # graphs captured so far folded the optimizer into the step
     for buf in (eng.P, eng.S, eng.A):          # identical replicas to start from
         dist.broadcast(buf, src=0)
+    eng.invalidate_packs()
     return net

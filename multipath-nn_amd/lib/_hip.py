@@ -14,6 +14,7 @@ NET_SR, NET_ACTOR, NET_CRITIC = 0, 1, 2
 HYP_LR, HYP_MU, HYP_TAU, HYP_EPS, HYP_KCPT, HYP_KDEC, HYP_KCRE, HYP_ARTR, HYP_N = 0, 1, 2, 3, 4, 5, 6, 7, 16
 MAX_NODES, MAX_SINKS = 128, 4
 BN_SLOTS = 16                  # MPNN_BN_SLOTS
+SEG_INTS = 12                  # MPNN_SEG_INTS
 
 P = C.c_void_p
 
@@ -143,7 +144,7 @@ _SIGS = {
     'mpnn_exit_ev_check': [C.POINTER(ExitEvArgs)],
     'mpnn_compact_by_branch': [P, C.c_int, P, P, P],
     'mpnn_bn_finalize': [P, P, P, P, P, C.c_int, C.c_float, C.c_int, P],
-    'mpnn_talr_momentum_step': [P, P, P, P, C.c_int, P, P, C.c_int, C.c_float, C.c_float, P, P],
+    'mpnn_talr_momentum_step': [P, P, P, P, C.c_int, P, P, C.c_int, C.c_float, C.c_float, P, P, P],
     'mpnn_conv_nhwc_fwd': [C.POINTER(ConvNhwcFwdArgs), P],
     'mpnn_conv_nhwc_dgrad': [C.POINTER(ConvNhwcDgradArgs), P],
     'mpnn_conv_nhwc_wgrad': [C.POINTER(ConvNhwcWgradArgs), P],

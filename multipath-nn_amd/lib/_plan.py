@@ -292,21 +292,8 @@ class Engine:
         for p in self.state_params:
             p.data = self.S[p.offset:p.offset + p.size]
         # optimizer work items
-        # `res` layers (layer_types.py:46,52,65-72): L2 pulls towards w_eq, the identity part of the init
-        seg, eqs, eq_off = [], [], 0
-        for p in self.trainable:
-            l2 = np.float32(p.l2).view(np.int32)
-            has_eq = bool(p.l2) and p.eq is not None
-            for s in range(0, p.size, OPT_CHUNK):
-                seg += [p.offset + s, min(OPT_CHUNK, p.size - s), p.node, p.is_router, int(l2), eq_off + s if has_eq else -1]
-            if has_eq:
-                eqs.append(np.asarray(p.eq, np.float32).reshape(-1))
-                eq_off += p.size
-        self.w_eq = torch.from_numpy(np.concatenate(eqs)).to(dev) if eqs else None
-        self.n_seg = len(seg) // 6
-        self.seg = torch.tensor(seg, dtype=torch.int32, device=dev)
         # weight packs
-        desc, poff = [], 0
+        desc, poff, pack_of = [], 0, {}
         for b in self.blocks:
             b.pack = {}
             for i in range(b.L):
@@ -317,11 +304,30 @@ class Engine:
                     fs = 9 * ((ci + 15) // 16) * 16 * co
                     bs = 9 * ((co + 15) // 16) * 16 * ci if ci % 16 == 0 else 0
                     desc += [p.offset, poff, poff + fs if bs else -1, ci, co, 0]
+                    pack_of[id(p)] = (p.offset, ci, co, poff, poff + fs if bs else -1)
                     b.pack[name] = (poff, poff + fs if bs else None)
                     poff += fs + bs
         self.n_pack = len(desc) // 6
         self.packs = torch.zeros(max(poff, 1), device=dev)
         self.pack_desc = torch.tensor(desc, dtype=torch.int32, device=dev)
+        # `res` layers (layer_types.py:46,52,65-72): L2 pulls towards w_eq, the identity part of the init
+        seg, eqs, eq_off = [], [], 0
+        for p in self.trainable:
+            l2 = np.float32(p.l2).view(np.int32)
+            has_eq = bool(p.l2) and p.eq is not None
+            pk = pack_of.get(id(p), (0, 0, 0, -1, -1))     # conv weights: the optimizer also refreshes their packs
+            for s in range(0, p.size, OPT_CHUNK):
+                seg += [p.offset + s, min(OPT_CHUNK, p.size - s), p.node, p.is_router, int(l2), eq_off + s if has_eq else -1,
+                        pk[0], pk[1], pk[2], pk[3], pk[4], 0]
+            if has_eq:
+                eqs.append(np.asarray(p.eq, np.float32).reshape(-1))
+                eq_off += p.size
+        self.w_eq = torch.from_numpy(np.concatenate(eqs)).to(dev) if eqs else None
+        self.n_seg = len(seg) // _hip.SEG_INTS
+        for p in self.trainable:
+            p._on_assign = self.invalidate_packs
+        self._packs_fresh = False
+        self.seg = torch.tensor(seg, dtype=torch.int32, device=dev)
         # fp64 BatchNorm arenas + finalize table
         doff, tab = 0, []
         for b in self.blocks:
@@ -394,6 +400,7 @@ class Engine:
         self.P.copy_(torch.from_numpy(P))
         self.S.copy_(torch.from_numpy(S))
         self.A.zero_()
+        self.invalidate_packs()
 
     # ------------------------------------------------------------------ buffers
     def _ensure_capacity(self, n, train=True):
@@ -1138,16 +1145,25 @@ class Engine:
         _hip.check(self.lib.mpnn_talr_momentum_step(
             self.P.data_ptr(), self.A.data_ptr(), self.G.data_ptr(), self.seg.data_ptr(), self.n_seg,
             self.node_stat.data_ptr(), self.hyp.data_ptr(), talr, 1.0 / (n * self.world), 1.0 / self.world,
-            self.w_eq.data_ptr() if self.w_eq is not None else None,
+            self.w_eq.data_ptr() if self.w_eq is not None else None, self.packs.data_ptr(),
             torch.cuda.current_stream().cuda_stream), 'talr_momentum_step')
 
     def _begin(self, train):
         """mpnn_step_begin: pack the weights and clear the step's accumulators in one launch
         (evaluation: loss sums, routed sample counts, r / c_err / d_cor)."""
         z = self._zarena if train else self._ev_arena
-        _hip.check(self.lib.mpnn_step_begin(self.P.data_ptr(), self.packs.data_ptr(), self.pack_desc.data_ptr(),
-                                            self.n_pack, z.data_ptr(), z.numel() * z.element_size(),
+        fresh = self._packs_fresh                  # (always true inside a captured graph: run() packs eagerly first)
+        _hip.check(self.lib.mpnn_step_begin(self.P.data_ptr(), self.packs.data_ptr(),
+                                            None if fresh else self.pack_desc.data_ptr(), 0 if fresh else self.n_pack,
+                                            z.data_ptr(), z.numel() * z.element_size(),
                                             torch.cuda.current_stream().cuda_stream), 'step_begin')
+        self._packs_fresh = True
+
+    def invalidate_packs(self):
+        """The parameters were written from outside a training step (initialisation, Param.assign, a
+        checkpoint, a broadcast): the weight packs are rebuilt before the next run.  Inside training the
+        optimizer kernel keeps them current.  Call this after writing ``eng.P`` directly."""
+        self._packs_fresh = False
 
     def _sections(self, prog, train):
         """The step as a list of (launches, bucket) sections: a section ends where a gradient bucket
@@ -1200,6 +1216,9 @@ class Engine:
             torch.cuda.synchronize()
             self._event_keep.clear()
         n, mode = self._stage(feed)
+        if not self._packs_fresh:                  # (eager, outside any captured graph)
+            self._pack()
+            self._packs_fresh = True
         if train and mode != 'tr':
             raise ValueError("net.train.run needs net.mode: 'tr' in the feed")
         if not train and mode == 'tr':

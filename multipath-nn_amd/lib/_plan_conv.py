@@ -128,11 +128,11 @@ class ConvEngine:
             l2 = int(np.float32(p.l2).view(np.int32))
             has_eq = bool(p.l2) and p.eq is not None
             for s in range(0, p.size, OPT_CHUNK):
-                seg += [p.offset + s, min(OPT_CHUNK, p.size - s), p.node, 0, l2, eq_off + s if has_eq else -1]
+                seg += [p.offset + s, min(OPT_CHUNK, p.size - s), p.node, 0, l2, eq_off + s if has_eq else -1, 0, 0, 0, -1, -1, 0]
             if has_eq:
                 eqs.append(np.asarray(p.eq, np.float32).reshape(-1))
                 eq_off += p.size
-        self.n_seg = len(seg) // 6
+        self.n_seg = len(seg) // _hip.SEG_INTS
         self.seg = torch.tensor(seg, dtype=torch.int32, device=dev)
         self.w_eq = torch.from_numpy(np.concatenate(eqs)).to(dev) if eqs else None
         # weight packs of the 3x3 stages
@@ -322,7 +322,7 @@ class ConvEngine:
             self._chk(lib.mpnn_conv_nhwc_dgrad(C.byref(d), st), 'conv_nhwc_dgrad')
         self._chk(lib.mpnn_talr_momentum_step(self.P.data_ptr(), self.A.data_ptr(), self.G.data_ptr(), self.seg.data_ptr(),
                                               self.n_seg, self.node_stat.data_ptr(), self.hyp.data_ptr(), 0, 1.0 / n, 1.0,
-                                              self.w_eq.data_ptr() if self.w_eq is not None else None, st), 'talr_momentum_step')
+                                              self.w_eq.data_ptr() if self.w_eq is not None else None, None, st), 'talr_momentum_step')
 
     def state(self):
         net, n = self.net, self.last_n

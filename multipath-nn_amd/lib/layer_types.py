@@ -76,6 +76,9 @@ class Param:
         import torch
         v = torch.as_tensor(np.asarray(value, np.float32).reshape(-1))
         self.data.copy_(v.to(self.data.device))
+        hook = getattr(self, '_on_assign', None)
+        if hook is not None:                       # (the engine rebuilds its weight packs before the next run)
+            hook()
 
     def __repr__(self):
         return 'Param(%s%s)' % (self.name, self.shape)

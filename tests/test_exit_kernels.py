@@ -402,7 +402,8 @@ def test_talr_momentum_step(talr):
     for cnt, node, rt, l2 in sizes:
         has_eq = cnt == 2049
         for s0 in range(0, cnt, 2048):
-            seg += [off + s0, min(2048, cnt - s0), node, rt, int(np.float32(l2).view(np.int32)), s0 if has_eq else -1]
+            seg += [off + s0, min(2048, cnt - s0), node, rt, int(np.float32(l2).view(np.int32)), s0 if has_eq else -1,
+                    0, 0, 0, -1, -1, 0]
         pbar = stat[node, 0] / (n * world)
         sc = (1 / np.sqrt(stat[node, 1] / (n * world)) * (artr if rt else 1.0)) if talr else 1.0
         sl = slice(off, off + cnt)
@@ -412,9 +413,9 @@ def test_talr_momentum_step(talr):
         off += cnt
     Pd, Ad, Gd = dev(P), dev(A), dev(G)
     segd, statd, hypd = dev(np.array(seg, np.int32), torch.int32), dev(stat), dev(hyp)
-    _hip.check(lib.mpnn_talr_momentum_step(Pd.data_ptr(), Ad.data_ptr(), Gd.data_ptr(), segd.data_ptr(), len(seg) // 6,
+    _hip.check(lib.mpnn_talr_momentum_step(Pd.data_ptr(), Ad.data_ptr(), Gd.data_ptr(), segd.data_ptr(), len(seg) // _hip.SEG_INTS,
                                            statd.data_ptr(), hypd.data_ptr(), talr, 1.0 / (n * world), 1.0 / world,
-                                           eqd.data_ptr(), stream()), 'talr_momentum_step')
+                                           eqd.data_ptr(), None, stream()), 'talr_momentum_step')
     torch.cuda.synchronize()
     close(Ad.cpu().numpy(), want_A, 1e-6, 'accumulators')
     close(Pd.cpu().numpy(), want_P, 1e-6, 'parameters')

@@ -51,7 +51,7 @@ def test_training_step_is_repeatable():
     P0, A0, S0 = eng.P.clone(), eng.A.clone(), eng.S.clone()
     outs = []
     for rep in range(4):
-        eng.P.copy_(P0); eng.A.copy_(A0); eng.S.copy_(S0)
+        eng.P.copy_(P0); eng.A.copy_(A0); eng.S.copy_(S0); eng.invalidate_packs()
         net.train.run(feed)
         torch.cuda.synchronize()
         outs.append((eng.G.clone(), eng.P.clone(), [s.clone() for b in eng.blocks for s in b.s]))
@@ -104,3 +104,32 @@ def test_training_memorises_fixed_batches_and_stays_finite():
     net.eval({net.x0: xs[0], net.y: ys[0]})
     acc = float(net.state()[(net, 'acc')].mean())
     assert acc > 0.9, acc
+
+
+def test_optimizer_keeps_the_weight_packs_current():
+    """mpnn_talr_momentum_step writes every updated conv weight into its slots of the forward and backward
+    packs: after training steps (eager and graph replay) the packs must equal what mpnn_pack_weights
+    builds from the parameters, bit for bit; a Param.assign makes the engine rebuild them."""
+    import arch_and_hypers as A
+    net = A.ac_chain(k_cpt=1e-8, seed=3)((32, 32, 3), (10,))
+    eng = net.engine()
+    rng = np.random.default_rng(0)
+    x0 = rng.random((32, 32, 32, 3)).astype(np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 32)]
+    for t in range(5):
+        net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.05, net.τ: 1.0})
+    torch.cuda.synchronize()
+    assert eng._packs_fresh
+    kept = eng.packs.clone()
+    eng._pack()
+    torch.cuda.synchronize()
+    assert torch.equal(kept, eng.packs)
+    w = eng.blocks[3].conv.params.w_horz_0
+    w.assign(w.numpy() * 0.5)
+    assert not eng._packs_fresh
+    net.eval({net.x0: x0, net.y: y})
+    torch.cuda.synchronize()
+    kept = eng.packs.clone()
+    eng._pack()
+    torch.cuda.synchronize()
+    assert eng._packs_fresh and torch.equal(kept, eng.packs)

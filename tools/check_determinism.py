@@ -13,14 +13,14 @@ for _ in range(3): net.train.run(feed(net))
 P0, A0, S0 = eng.P.clone(), eng.A.clone(), eng.S.clone()
 outs = []
 for rep in range(3):
-    eng.P.copy_(P0); eng.A.copy_(A0); eng.S.copy_(S0)
+    eng.P.copy_(P0); eng.A.copy_(A0); eng.S.copy_(S0); eng.invalidate_packs()
     net.train.run(feed(net)); torch.cuda.synchronize()
     outs.append((eng.P.clone(), eng.G.clone()))
 for r in (1, 2):
     print('same engine rep', r, 'max|dP| %.3e  max|dG| %.3e' % ((outs[r][0] - outs[0][0]).abs().max().item(), (outs[r][1] - outs[0][1]).abs().max().item()))
 # (2) fresh engine loaded with the same state
 net2, eng2 = fresh()
-eng2.P.copy_(P0); eng2.A.copy_(A0); eng2.S.copy_(S0)
+eng2.P.copy_(P0); eng2.A.copy_(A0); eng2.S.copy_(S0); eng2.invalidate_packs()
 net2.train.run(feed(net2)); torch.cuda.synchronize()
 d = (eng2.G - outs[0][1]).abs()
 print('fresh engine: max|dP| %.3e  max|dG| %.3e' % ((eng2.P - outs[0][0]).abs().max().item(), d.max().item()))

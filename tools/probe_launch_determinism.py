@@ -28,7 +28,7 @@ def fwd_only(group, reps=4):
     st = torch.cuda.current_stream()
     out = []
     for rep in range(reps):
-        eng.P.copy_(P0); eng.A.copy_(A0); eng.S.copy_(S0)
+        eng.P.copy_(P0); eng.A.copy_(A0); eng.S.copy_(S0); eng.invalidate_packs()
         eng._zero(True); eng._pack()
         per = []
         for op in ops:

@@ -25,7 +25,7 @@ feed = {net.x0: xs[0], net.y: ys[0], net.mode: 'tr', net.λ_lrn: 0.01, net.τ: 1
 ref = None
 worst = 0.0
 for rep in range(200):
-    eng.P.copy_(P0); eng.A.copy_(A0); eng.S.copy_(S0)
+    eng.P.copy_(P0); eng.A.copy_(A0); eng.S.copy_(S0); eng.invalidate_packs()
     net.train.run(feed); torch.cuda.synchronize()
     s = [b.s[i].clone() for b in eng.blocks for i in range(b.L)]
     if ref is None:
