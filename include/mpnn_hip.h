@@ -405,7 +405,9 @@ int mpnn_compact_by_branch(const float *p_ev, int n, int *idx_out, int *count_ou
  * launch.  table: 8 ints per BN: sum_off (doubles; same offset in `reds`; each
  * a [SLOTS][2*C] block of which table[7] slots are in use),
  * mavg_off, vavg_off (floats in `state`), C, pixels per image, gamma_goff,
- * beta_goff (floats in `grads`; -1: no gradient), nslot. */
+ * beta_goff (floats in `grads`), nslot.  gamma_goff = -1 marks a BatchNorm whose output
+ * nobody consumes: no gradients and -- as in the reference, whose tf.assign of the
+ * averages only executes when the output is needed -- no moving-average update. */
 int mpnn_bn_finalize(const double *sums, const double *reds, float *state, float *grads,
                      const int *table, int n_bn, float decay, int n_img, void *stream);
 

@@ -129,9 +129,14 @@ __device__ __forceinline__ void bn_finalize_body(const double *__restrict__ sums
         const double mean = slot_sum(sums + t[0], 2 * C, c, t[7]) * inv;
         double var = slot_sum(sums + t[0], 2 * C, C + c, t[7]) * inv - mean * mean;
         var = var < 0.0 ? 0.0 : var;
-        float *m = state + t[1] + c, *v = state + t[2] + c;
-        *m = decay * *m + (1.f - decay) * (float)mean;
-        *v = decay * *v + (1.f - decay) * (float)var;
+        // A BatchNorm whose output nobody consumes (t[5] < 0: a scale the child block drops and no exit
+        // reads) keeps its moving averages: in the reference the two tf.assign hang off the OUTPUT by
+        // control dependency (layer_types.py:233-236) and TensorFlow never executes an unfetched output.
+        if (t[5] >= 0) {
+            float *m = state + t[1] + c, *v = state + t[2] + c;
+            *m = decay * *m + (1.f - decay) * (float)mean;
+            *v = decay * *v + (1.f - decay) * (float)var;
+        }
         if (reds && grads && t[5] >= 0) {
             grads[t[6] + c] = (float)slot_sum(reds + t[0], 2 * C, c, t[7]);          // dbeta  = sum dz
             grads[t[5] + c] = (float)slot_sum(reds + t[0], 2 * C, C + c, t[7]);      // dgamma = sum dz * xhat

@@ -6,8 +6,11 @@ data: class names, hypers, tree links) and re-evaluates it the way the
 reference builds its graph, with torch-CPU tensors and torch autograd standing
 in for TensorFlow ops and ``tf.gradients``.  Each operator below is
 cross-checked against the hand-written float64 NumPy forms in ``np_ops``
-(tests/test_oracle_vs_torch.py), and known answers KA1..KA6 of SURVEY.md 8c are
-checked in tests/test_oracle_known_answers.py.
+(tests/test_oracle_vs_torch.py), known answers KA1..KA6 of SURVEY.md 8c are
+checked in tests/test_oracle_known_answers.py, and tests/test_ref_graph_golden.py
+holds it to vectors that the reference's OWN graph-assembly code produced over a
+stand-in for its TensorFlow calls (that pins the Python on top of the operators,
+not TensorFlow's operator semantics: hence still "unpinned").
 
 Reference lines followed (paths relative to /root/reference/scripts):
   lib/layer_types.py: LinTrans :39-53, Rect :76-79, Softmax :81-84,
@@ -269,6 +272,9 @@ class RefNet:
         for t in self.θ.values():
             t.grad = None
         res = self.forward(x0, y, 'tr', τ=τ, k_cpt=k_cpt, forced=forced)
+        bns = [(k, r['x']) for k, r in res['out'].items() if 'new_avg' in r and getattr(r['x'], 'requires_grad', False)]
+        reach = torch.autograd.grad(res['c_tot'], [x for _, x in bns], allow_unused=True, retain_graph=True) if bns else []
+        used_bn = {k for (k, _), g in zip(bns, reach) if g is not None}       # BatchNorms whose output reaches the loss
         res['c_tot'].backward()
         R = lambda ℓ: res['out'][id(ℓ)]
         scale = {}
@@ -291,11 +297,15 @@ class RefNet:
                 t -= λ_lrn * self.accum[id(p)]
             for rec_id, rec in res['out'].items():
                 pass
-            # BN moving averages
+            # BN moving averages.  TensorFlow only executes what the fetched op needs: the two tf.assign
+            # of a BatchNorm hang off its OUTPUT by control dependency (layer_types.py:233-236), so a
+            # BatchNorm whose output feeds nothing that reaches the loss -- a scale the child block drops
+            # (negative indexing, :163) and no exit reads (Select(-1)) -- never moves its averages.
+            # (Found by running the reference's own graph code: tests/test_ref_graph_golden.py.)
             def upd(ℓ):
                 if ℓ is None:
                     return
-                if type(ℓ).__name__ == 'BatchNorm' and 'new_avg' in res['out'].get(id(ℓ), {}):
+                if type(ℓ).__name__ == 'BatchNorm' and 'new_avg' in res['out'].get(id(ℓ), {}) and id(ℓ) in used_bn:
                     m, v = res['out'][id(ℓ)]['new_avg']
                     self.state[id(ℓ.params.m_avg)], self.state[id(ℓ.params.v_avg)] = m, v
                 for c in ℓ.comps:

@@ -1,0 +1,144 @@
+"""Generates tests/golden/ref_graph_golden.npz by running the REFERENCE'S OWN graph-assembly code
+(/root/reference/scripts/lib/{layer_types,net_types}.py and scripts/arch_and_hypers.py, imported
+unmodified) on top of tests/golden/tf_standin.py, a float64 torch stand-in for the TensorFlow calls
+they make.  Run in the build container (the reference tree does not travel):
+
+    python tests/golden/make_ref_graph_golden.py
+
+What the vectors pin and what they do not: see the header of tf_standin.py -- the reference's Python
+(scale selection, routing probabilities, epsilon floors, hard routing, critic costs, stop-gradients,
+cost assembly, TALR scales, the k_cpt column, Momentum wiring) YES; TensorFlow's operator semantics
+NO (the stand-in implements them from the same assumptions as oracle/np_ops.py).
+
+Inputs are not stored: tests/test_ref_graph_golden.py regenerates weights and batches from the same
+seeded legacy numpy streams (`case_inputs`, `param_value` below are imported by the test).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference/scripts'
+
+CASES = {
+    'ac': dict(ctor='ac_chain', hypers=dict(k_cpt=1.6e-8), tau=0.7, n=4),
+    'ac_notalr_nokdec': dict(ctor='ac_chain', hypers=dict(k_cpt=4e-9, talr=False, k_dec=0.0), tau=1.0, n=3),
+    'ac_dyn': dict(ctor='ac_chain', hypers=dict(dyn_k_cpt=True), tau=0.8, n=4, dyn=True),
+    'cr': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9), tau=0.05, n=4),
+    'cr_opt_cls': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9, optimistic=True, use_cls_err=True), tau=0.1, n=3),
+    'sr3': dict(ctor='sr_chain', args=(3,), hypers={}, tau=None, n=3),
+}
+K_CPTS = [0.0, 1e-9, 2e-9, 4e-9, 8e-9, 1.6e-8, 3.2e-8, 6.4e-8]
+LR = 0.05
+
+
+def param_value(name, shape, rng):
+    """Injected parameter values (both sides draw them in the same order from the same stream)."""
+    shape = tuple(shape)
+    if name.startswith('w'):
+        fan = max(1, int(np.prod(shape[:-1])))
+        return rng.standard_normal(shape) * (1.5 / np.sqrt(fan))
+    if name.startswith('b'):
+        return rng.standard_normal(shape) * 0.1
+    if name == 'γ':
+        return 1 + 0.1 * rng.standard_normal(shape)
+    if name == 'β':
+        return 0.1 * rng.standard_normal(shape)
+    if name == 'm_avg':
+        return 0.1 * rng.standard_normal(shape)
+    if name == 'v_avg':
+        return 1 + 0.3 * rng.random_sample(shape)
+    raise KeyError(name)
+
+
+def case_inputs(case, seed):
+    rng = np.random.RandomState(1000 + seed)
+    n = case['n']
+    x0 = rng.random_sample((n, 32, 32, 3))
+    y = np.eye(10)[rng.randint(0, 10, n)]
+    kc = np.asarray(K_CPTS)[rng.randint(0, len(K_CPTS), n)] if case.get('dyn') else None
+    return x0, y, kc
+
+
+def ordered_params(net, params_list_rec):
+    """[(name, variable)] in tree order: every layer's own parameters, then its router's."""
+    out = []
+    for ℓ in net.layers:
+        for scope in (ℓ, ℓ.router):
+            if scope is None:
+                continue
+
+            def walk(l):
+                for k, v in vars(l.params).items():
+                    out.append((k, v))
+                for c in getattr(l, 'comps', []):
+                    walk(c)
+            walk(scope)
+    return out
+
+
+def digest(v):
+    v = np.asarray(v, np.float64).reshape(-1)
+    pos = [0, len(v) // 3, len(v) - 1]
+    return [v.sum(), np.abs(v).sum(), v[pos[0]], v[pos[1]], v[pos[2]]]
+
+
+def main():
+    sys.path.insert(0, HERE)
+    import tf_standin
+    sys.modules['tensorflow'] = tf_standin
+    sys.path.insert(0, REF)
+    import lib.net_types as NT                       # the REFERENCE's modules
+    import arch_and_hypers as A
+    assert NT.__file__.startswith(REF) and A.__file__.startswith(REF)
+    out = {}
+    for seed, (key, case) in enumerate(sorted(CASES.items())):
+        tf_standin.reset()
+        make = getattr(A, case['ctor'])(*case.get('args', ()), **case['hypers'])
+        net = make((32, 32, 3), (10,))
+        rng = np.random.RandomState(seed)
+        params = ordered_params(net, NT.params_list_rec)
+        for name, var in params:
+            var.load(param_value(name, var.data.shape, rng))
+        x0, y, kc = case_inputs(case, seed)
+        layers = list(net.layers)
+        leaves = [ℓ for ℓ in layers if len(ℓ.sinks) == 0]
+        switches = [ℓ for ℓ in layers if len(ℓ.sinks) > 1]
+        feed = {net.x0: x0, net.y: y}
+        if case['tau'] is not None:
+            feed[net.τ] = case['tau']
+        if kc is not None:
+            feed[net.k_cpt] = kc
+        has_ptr = hasattr(layers[0], 'p_tr')
+        fetch = {'p_ev': [ℓ.p_ev for ℓ in layers], 'c_err': [ℓ.c_err for ℓ in leaves], 'd_cor': [ℓ.δ_cor for ℓ in leaves]}
+        if has_ptr:
+            fetch['p_tr'] = [ℓ.p_tr for ℓ in layers]
+            fetch['r'] = [ℓ.router.x for ℓ in switches]
+        for mode in ('ev', 'tr'):
+            f = dict(feed)
+            f[net.mode] = mode
+            if mode == 'tr':
+                # (forward values of the training graph, BEFORE the update: a separate run of the same feed
+                # would move the moving averages, so snapshot and restore the non-trainable state)
+                snap = [(v, v.data.detach().clone()) for _, v in params]
+            for k, nodes in fetch.items():
+                vals = tf_standin.run(nodes, f)
+                out['%s/%s/%s' % (key, mode, k)] = np.stack([np.broadcast_to(np.asarray(v, np.float64), np.asarray(vals[0]).shape)
+                                                            if k != 'r' else np.asarray(v, np.float64) for v in vals])
+            if mode == 'tr':
+                for v, d in snap:
+                    v.load(d.numpy())
+        # one training step (momentum 0.9 from zero accumulators), then the state of every variable
+        f = dict(feed)
+        f[net.mode] = 'tr'
+        f[net.λ_lrn] = LR
+        net.train.run(f)
+        out['%s/after' % key] = np.array([digest(v.data.detach().numpy()) for _, v in params])
+        out['%s/names' % key] = np.array([n for n, _ in params])
+        print(key, 'ok:', len(params), 'variables,', len(layers), 'nodes')
+    np.savez_compressed(os.path.join(HERE, 'ref_graph_golden.npz'), **out)
+
+
+if __name__ == '__main__':
+    main()
