@@ -28,7 +28,27 @@ CASES = {
     'cr': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9), tau=0.05, n=4),
     'cr_opt_cls': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9, optimistic=True, use_cls_err=True), tau=0.1, n=3),
     'sr3': dict(ctor='sr_chain', args=(3,), hypers={}, tau=None, n=3),
+    # a 3-way switch over two sub-chains, built from the spec's own rcm / reg / pyr (the reference's dr_tree
+    # cannot run at this revision: `y_shape` scoping bug, arch_and_hypers.py:99-106)
+    'ac_tree3': dict(ctor='small_tree', net='ActorNet', hypers=dict(k_cpt=1.6e-8), tau=0.8, n=4),
+    'cr_tree3': dict(ctor='small_tree', net='CriticNet', hypers=dict(k_cpt=8e-9, optimistic=True), tau=0.05, n=4),
 }
+
+
+def small_tree(A, NT, case):
+    def make_net(x0_shape, y_shape):
+        nc = y_shape[0]
+        root = A.pyr(A.rcm(0, A.reg(nc),
+                           A.rcm(1, A.reg(nc), A.rcm(2, A.reg(nc))),
+                           A.rcm(1, A.reg(nc), A.rcm(2, A.reg(nc), A.rcm(3, A.reg(nc))))))
+        return getattr(NT, case['net'])(x0_shape=x0_shape, y_shape=y_shape, root=root, **case['hypers'])
+    return make_net
+
+
+def make_case(A, NT, case):
+    if case['ctor'] == 'small_tree':
+        return small_tree(A, NT, case)
+    return getattr(A, case['ctor'])(*case.get('args', ()), **case['hypers'])
 K_CPTS = [0.0, 1e-9, 2e-9, 4e-9, 8e-9, 1.6e-8, 3.2e-8, 6.4e-8]
 LR = 0.05
 
@@ -78,6 +98,11 @@ def ordered_params(net, params_list_rec):
     return out
 
 
+def pad_r(v, width=3):
+    v = np.asarray(v, np.float64)
+    return np.concatenate([v, np.zeros((v.shape[0], width - v.shape[1]))], 1)
+
+
 def digest(v):
     v = np.asarray(v, np.float64).reshape(-1)
     pos = [0, len(v) // 3, len(v) - 1]
@@ -95,8 +120,7 @@ def main():
     out = {}
     for seed, (key, case) in enumerate(sorted(CASES.items())):
         tf_standin.reset()
-        make = getattr(A, case['ctor'])(*case.get('args', ()), **case['hypers'])
-        net = make((32, 32, 3), (10,))
+        net = make_case(A, NT, case)((32, 32, 3), (10,))
         rng = np.random.RandomState(seed)
         params = ordered_params(net, NT.params_list_rec)
         for name, var in params:
@@ -124,6 +148,8 @@ def main():
                 snap = [(v, v.data.detach().clone()) for _, v in params]
             for k, nodes in fetch.items():
                 vals = tf_standin.run(nodes, f)
+                if k == 'r':                       # switches have 2 or 3 sinks: zero-padded to the widest
+                    vals = [pad_r(v) for v in vals]
                 out['%s/%s/%s' % (key, mode, k)] = np.stack([np.broadcast_to(np.asarray(v, np.float64), np.asarray(vals[0]).shape)
                                                             if k != 'r' else np.asarray(v, np.float64) for v in vals])
             if mode == 'tr':

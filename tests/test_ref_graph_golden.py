@@ -44,10 +44,11 @@ def ordered(net):
 @pytest.mark.parametrize('key', sorted(M.CASES))
 def test_oracle_matches_the_reference_graph_code(key):
     import arch_and_hypers as A
+    import lib.net_types as NT
     from oracle.ref_net import RefNet
     case = M.CASES[key]
     seed = sorted(M.CASES).index(key)
-    net = getattr(A, case['ctor'])(*case.get('args', ()), **case['hypers'])((32, 32, 3), (10,))
+    net = M.make_case(A, NT, case)((32, 32, 3), (10,))
     params = ordered(net)
     assert [n for n, _ in params] == list(GOLD['%s/names' % key])        # same parameters, same order
     rng = np.random.RandomState(seed)
@@ -78,7 +79,7 @@ def test_oracle_matches_the_reference_graph_code(key):
         assert np.array_equal(np.stack([vec(R(ℓ)['δ_cor']) for ℓ in leaves]), GOLD['%s/%s/d_cor' % (key, mode)])
         if '%s/%s/p_tr' % (key, mode) in GOLD:
             close(np.stack([vec(R(ℓ)['p_tr']) for ℓ in layers]), GOLD['%s/%s/p_tr' % (key, mode)], mode + ' p_tr')
-            close(np.stack([R(ℓ.router)['x'].detach().numpy() for ℓ in switches]), GOLD['%s/%s/r' % (key, mode)], mode + ' router.x')
+            close(np.stack([M.pad_r(R(ℓ.router)['x'].detach().numpy()) for ℓ in switches]), GOLD['%s/%s/r' % (key, mode)], mode + ' router.x')
     # one training step: every variable (parameters after TALR-scaled momentum update, moving averages)
     ref.train_step(x0, y, M.LR, **kw)
     after = np.array([M.digest(ref.V(p).detach().numpy()) for _, p in params])
@@ -95,9 +96,10 @@ def test_product_matches_the_reference_graph_code(key):
     its scale (updates are ~1e-2 of the values; the unused BatchNorms keep their moving averages)."""
     import torch
     import arch_and_hypers as A
+    import lib.net_types as NT
     case = M.CASES[key]
     seed = sorted(M.CASES).index(key)
-    net = getattr(A, case['ctor'])(*case.get('args', ()), **case['hypers'])((32, 32, 3), (10,))
+    net = M.make_case(A, NT, case)((32, 32, 3), (10,))
     net.engine()
     params = ordered(net)
     rng = np.random.RandomState(seed)
@@ -121,7 +123,7 @@ def test_product_matches_the_reference_graph_code(key):
         assert np.abs(ce - g('c_err')).max() <= 2e-4 * (1 + np.abs(g('c_err')).max())
         if '%s/%s/p_tr' % (key, mode) in GOLD:
             assert np.abs(np.stack([ℓ.p_tr.cpu().numpy() for ℓ in layers]) - g('p_tr')).max() <= 2e-4
-            r = np.stack([ℓ.router.x.cpu().numpy() for ℓ in switches])
+            r = np.stack([M.pad_r(ℓ.router.x.cpu().numpy()) for ℓ in switches])
             assert np.abs(r - g('r')).max() <= 2e-4 * (1 + np.abs(g('r')).max())
     net.eval(feed)
     check('ev')
