@@ -21,17 +21,21 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = '/root/reference/scripts'
 
+# (temperatures: moderate on purpose.  A peaked softmax puts p_tr of the deep nodes at the epsilon floor,
+# the TALR scale 1/sqrt(mean p_tr^2) then reaches 1e3..1e6 and multiplies the fp32 rounding noise of
+# analytically-zero gradients -- conv biases ahead of BatchNorm -- into visible parameter changes: a property
+# of the update rule in fp32, not something a float64 fixture can hold the kernels to.)
 CASES = {
     'ac': dict(ctor='ac_chain', hypers=dict(k_cpt=1.6e-8), tau=0.7, n=4),
     'ac_notalr_nokdec': dict(ctor='ac_chain', hypers=dict(k_cpt=4e-9, talr=False, k_dec=0.0), tau=1.0, n=3),
     'ac_dyn': dict(ctor='ac_chain', hypers=dict(dyn_k_cpt=True), tau=0.8, n=4, dyn=True),
-    'cr': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9), tau=0.05, n=4),
-    'cr_opt_cls': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9, optimistic=True, use_cls_err=True), tau=0.1, n=3),
+    'cr': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9), tau=0.5, n=4),
+    'cr_opt_cls': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9, optimistic=True, use_cls_err=True), tau=0.3, n=3),
     'sr3': dict(ctor='sr_chain', args=(3,), hypers={}, tau=None, n=3),
     # a 3-way switch over two sub-chains, built from the spec's own rcm / reg / pyr (the reference's dr_tree
     # cannot run at this revision: `y_shape` scoping bug, arch_and_hypers.py:99-106)
     'ac_tree3': dict(ctor='small_tree', net='ActorNet', hypers=dict(k_cpt=1.6e-8), tau=0.8, n=4),
-    'cr_tree3': dict(ctor='small_tree', net='CriticNet', hypers=dict(k_cpt=8e-9, optimistic=True), tau=0.05, n=4),
+    'cr_tree3': dict(ctor='small_tree', net='CriticNet', hypers=dict(k_cpt=8e-9, optimistic=True), tau=0.4, n=4),
 }
 
 
