@@ -130,7 +130,7 @@ def main():
     import arch_and_hypers as A
     from lib import _dp
     rank, world = _dp.init()
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = _dp.local_device()
     dev = 'cuda:%d' % local
     torch.cuda.set_device(local)
 
@@ -179,14 +179,32 @@ def main():
         for name, (lo, hi) in eng.dp_buckets.items():
             view = eng.G[lo:hi]
             for _ in range(3):
-                dist.all_reduce(view)
+                _dp.allreduce_sum_any(view)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st_c)
             for _ in range(20):
-                dist.all_reduce(view)
+                _dp.allreduce_sum_any(view)
             e1.record(st_c)
             e1.synchronize()
             ar[name] = {'bytes': (hi - lo) * 4, 'us': e0.elapsed_time(e1) / 20 * 1e3}
+
+    # Steady state outside the headline region, on EVERY rank (training steps are collective under data
+    # parallelism): 400 further replays, HIP events around chunks of ten -> median / mean / p95 step time.
+    st_ = torch.cuda.current_stream()
+    CH, NCH_ = 10, 40                                         # (an event per replay would break the back-to-back queue)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(NCH_ + 1)]
+    for _ in range(3):
+        net.train.run(feed)
+    evs[0].record(st_)
+    for k in range(NCH_):
+        for _ in range(CH):
+            net.train.run(feed)
+        evs[k + 1].record(st_)
+    barrier()
+    per = np.array([evs[k].elapsed_time(evs[k + 1]) / CH for k in range(NCH_)])
+    steady = {'steps': CH * NCH_, 'ms_median': float(np.median(per)), 'ms_mean': float(per.mean()),
+              'ms_p95': float(np.percentile(per, 95)), 'images_per_s_median': n * world / (float(np.median(per)) * 1e-3),
+              'what': 'replays after the headline region (rank 0\'s clock), HIP events around chunks of %d steps' % CH}
 
     out = None
     if rank == 0:
@@ -262,23 +280,6 @@ def main():
                     traffic = pm['traffic_bytes_per_launch']
         except Exception:
             pass
-        # steady state outside the headline region: 200 graph replays, one HIP-event pair per step on the
-        # launch stream -> median and mean step time (the driver's 20-step run is not the only evidence)
-        st_ = torch.cuda.current_stream()
-        CH, NCH_ = 10, 40                                         # 40 chunks of 10 replays: an event per replay would break the back-to-back queue
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(NCH_ + 1)]
-        for _ in range(3):
-            net.train.run(feed)
-        evs[0].record(st_)
-        for k in range(NCH_):
-            for _ in range(CH):
-                net.train.run(feed)
-            evs[k + 1].record(st_)
-        torch.cuda.synchronize()
-        per = np.array([evs[k].elapsed_time(evs[k + 1]) / CH for k in range(NCH_)])
-        steady = {'steps': CH * NCH_, 'ms_median': float(np.median(per)), 'ms_mean': float(per.mean()),
-                  'ms_p95': float(np.percentile(per, 95)), 'images_per_s_median': n / (float(np.median(per)) * 1e-3),
-                  'what': 'replays after the headline region on this rank, HIP events around chunks of %d steps' % CH}
         # launch floor: the same number of launches as a training step, each the smallest kernel of the
         # library (a 1-item slab reduction), captured and replayed as one hipGraph
         n_launch = len(ops) + 2                                   # + step_begin + optimizer

@@ -29,11 +29,17 @@ def init(backend=None, force=False):
         os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        backend = os.environ.get('MPNN_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        torch.cuda.set_device(local_device())
     dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size()
+
+
+def local_device():
+    """GPU of this rank: LOCAL_RANK, or 0 for every rank with MPNN_DP_ONE_GPU=1 (functional tests of the
+    multi-rank paths on a one-GPU box, together with MPNN_DP_BACKEND=gloo: RCCL refuses two ranks per GPU)."""
+    return 0 if os.environ.get('MPNN_DP_ONE_GPU') else int(os.environ.get('LOCAL_RANK', '0'))
 
 
 def allreduce_sum(flat):
@@ -49,7 +55,20 @@ def allreduce_async(flat):
     for it (a stream dependency, the host does not block).  xGMI is point to point (7 links of
     ~153 GB/s per GPU) and a bucket is 0.3-1.3 MB, so each all-reduce is latency- not bandwidth-bound:
     three buckets, two of them hidden behind the remaining backward pass."""
+    if flat.is_cuda and dist.get_backend() == 'gloo':          # (test configuration: gloo without device support)
+        h = flat.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        flat.copy_(h)
+        return None
     return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def allreduce_sum_any(flat):
+    """Blocking form of allreduce_async (bench: the collective timed by itself)."""
+    h = allreduce_async(flat)
+    if h is not None:
+        h.wait()
+    return flat
 
 
 def sync_state(net):
@@ -60,7 +79,7 @@ def sync_state(net):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return net
     eng = net.engine()
-    dist.all_reduce(eng.S, op=dist.ReduceOp.SUM)
+    allreduce_sum_any(eng.S)
     eng.S.div_(dist.get_world_size())
     return net
 
@@ -74,6 +93,9 @@ def attach(net, force=False):
     eng.allreduce = allreduce_async
     eng._graphs.clear()                        # graphs captured so far folded the optimizer into the step
     for buf in (eng.P, eng.S, eng.A):          # identical replicas to start from
-        dist.broadcast(buf, src=0)
+        if buf.is_cuda and dist.get_backend() == 'gloo':
+            h = buf.cpu(); dist.broadcast(h, src=0); buf.copy_(h)
+        else:
+            dist.broadcast(buf, src=0)
     eng.invalidate_packs()
     return net

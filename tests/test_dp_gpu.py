@@ -159,3 +159,22 @@ def test_two_gpus_over_rccl_torchrun(tmp_path):
     import json
     line = json.loads([l for l in out.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['rccl_ranks'] == 2 and line['value'] > 0
+
+
+def test_bench_two_ranks_functional_on_one_gpu(tmp_path):
+    """bench.py launched exactly as the driver launches it (torch.distributed.run, --gpus 2), both ranks
+    on GPU 0 over gloo (RCCL refuses two ranks per GPU): bucket sections, collectives issued in the same
+    order on every rank, the rank-0-only measurements after the timed region, the final barrier -- a
+    deadlock or a rank-dependent collective shows up here, not on the 8-GPU node."""
+    import json
+    import subprocess
+    env = dict(os.environ, MPNN_DP_BACKEND='gloo', MPNN_DP_ONE_GPU='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3',
+           '--no-cpu-baseline', '--eval-batch', '256']
+    out = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 256 and line['config']['rccl_ranks'] == 2
+    assert set(line['config']['allreduce']) == {'exit', 'mid', 'end'}
+    assert line['value'] > 0 and line['steady_state']['steps'] == 400
