@@ -36,6 +36,9 @@ ROUTER_COMPS = ['Select', 'LinTrans', 'BatchNorm', 'Rect', 'LinTrans', 'BatchNor
 BLOCK_COMPS = ['MultiscaleConvMax', 'MultiscaleBatchNorm', 'MultiscaleRect']
 HEAD_COMPS = ['Select', 'LinTrans', 'Softmax', 'CrossEntropyError']
 OPT_CHUNK = 2048
+# hipGraph capture mode: thread-local, so that other threads' runtime calls (the process group's
+# watchdog polling its events under data parallelism) are not errors while this thread captures
+CAPTURE_MODE = 'thread_local'
 
 
 def _nf(name):
@@ -1254,7 +1257,7 @@ class Engine:
             torch.cuda.synchronize()
             if not dp:                                     # one process: ONE graph per step
                 ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
+                with torch.cuda.graph(ga, capture_error_mode=CAPTURE_MODE):
                     self._phase_a(prog, train)
                     if train:
                         self._opt(n)
@@ -1265,13 +1268,13 @@ class Engine:
                 secs = []
                 for k, (ops, bucket) in enumerate(self._sections(prog, train)):
                     gk = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gk):
+                    with torch.cuda.graph(gk, capture_error_mode=CAPTURE_MODE):
                         if k == 0:
                             self._begin(train)
                         self._launch(ops, k)
                     secs.append((gk, bucket))
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb):
+                with torch.cuda.graph(gb, capture_error_mode=CAPTURE_MODE):
                     self._opt(n)
                 g = self._graphs[key] = (secs, gb)
         secs, gb = g
