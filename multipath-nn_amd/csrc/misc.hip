@@ -256,6 +256,14 @@ __global__ __launch_bounds__(256) void talr_momentum_k(float *__restrict__ param
     const int tbase = s[6], Cin = s[7], Cout = s[8], fwd = s[9], bwd = s[10];
     const bool emit = packs && Cin > 0;
     const int per_f = ((Cin + 15) >> 4) * 16 * Cout, per_b = ((Cout + 15) >> 4) * 16 * Cin, cc = Cin * Cout;
+    // Fast path: the segment is a whole number of 4-row groups of [tap * Cin + ci][Cout] inside one tap or a
+    // whole number of taps (every shipped shape with Cin % 4 == 0).  The updated weights meet in LDS and
+    // leave as CONTIGUOUS runs of both packs (element by element the pack stores are 4-byte scatters at a
+    // 16-byte stride: the kernel took twice as long as the plain update).
+    __shared__ float wl[2048];
+    const int R = emit ? cnt / Cout : 0, row0 = emit ? (off - tbase) / Cout : 0;
+    const bool fast = emit && cnt <= 2048 && (Cin & 3) == 0 && (row0 & 3) == 0 && (R & 3) == 0 && R * Cout == cnt &&
+                      ((R <= Cin && (row0 % Cin) + R <= Cin) || (R % Cin == 0 && row0 % Cin == 0));
     const float l2 = __int_as_float(s[4]);
     const float lr = hyp[MPNN_HYP_LR], mu = hyp[MPNN_HYP_MU];
     const float pbar = node_stat[node * 2] * inv_n;                   // mean p_tr over the batch
@@ -273,10 +281,30 @@ __global__ __launch_bounds__(256) void talr_momentum_k(float *__restrict__ param
         accum[off + i] = a;
         const float wn = w - lr * a;
         params[off + i] = wn;
-        if (emit) {
+        if (fast) wl[i] = wn;
+        else if (emit) {
             const int e = off + i - tbase, tap = e / cc, rem = e - tap * cc, ci = rem / Cout, co = rem - ci * Cout;
             if (fwd >= 0) packs[fwd + tap * per_f + ((ci >> 2) * Cout + co) * 4 + (ci & 3)] = wn;
             if (bwd >= 0) packs[bwd + (8 - tap) * per_b + ((co >> 2) * Cin + ci) * 4 + (co & 3)] = wn;
+        }
+    }
+    if (fast) {                                        // (uniform)
+        __syncthreads();
+        if (fwd >= 0) {
+            const int gsz = 4 * Cout;                  // a group of 4 input channels x Cout: one contiguous pack block
+            for (int p = threadIdx.x; p < cnt; p += 256) {
+                const int grp = p / gsz, within = p - grp * gsz, co = within >> 2, j = within & 3;
+                const int row = row0 + grp * 4, tap = row / Cin, ci0 = row - tap * Cin;
+                packs[fwd + tap * per_f + (ci0 >> 2) * gsz + within] = wl[(grp * 4 + j) * Cout + co];
+            }
+        }
+        if (bwd >= 0) {
+            const int Rt = R < Cin ? R : Cin, tsz = Rt * Cout, bsz = Rt * 4;     // rows of one tap in this segment
+            for (int p = threadIdx.x; p < cnt; p += 256) {
+                const int tl = p / tsz, rem = p - tl * tsz, gq = rem / bsz, rem2 = rem - gq * bsz, cil = rem2 >> 2, j = rem2 & 3;
+                const int row = row0 + tl * Rt + cil, tap = row / Cin, ci = row - tap * Cin;
+                packs[bwd + (8 - tap) * per_b + (gq * Cin + ci) * 4 + j] = wl[(tl * Rt + cil) * Cout + 4 * gq + j];
+            }
         }
     }
 }
