@@ -181,14 +181,45 @@ __device__ __forceinline__ double reduce_g4(double v) {
     return v;
 }
 
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+// Wave-wide sums, result in every lane.  Inside a 16-lane row the butterfly runs on DPP operands (quad
+// swaps, then the half-row and row mirrors: ALU latency), the four row sums are then read as scalars.
+// (The __shfl_xor butterfly these replace goes through ds_bpermute: six dependent LDS round trips per sum,
+// ~600 cycles -- most of the tail of the one-or-two-workgroup kernels that use them.)
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+#define MPNN_DPP_QUAD_XOR1 0xB1      // quad_perm [1,0,3,2]
+#define MPNN_DPP_QUAD_XOR2 0x4E      // quad_perm [2,3,0,1]
+#define MPNN_DPP_HALF_MIRROR 0x141   // lane i <-> 7-i inside each half row
+#define MPNN_DPP_ROW_MIRROR 0x140    // lane i <-> 15-i inside each row
 
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __int_as_float(dpp_i<MPNN_DPP_QUAD_XOR1>(__float_as_int(v)));
+    v += __int_as_float(dpp_i<MPNN_DPP_QUAD_XOR2>(__float_as_int(v)));
+    v += __int_as_float(dpp_i<MPNN_DPP_HALF_MIRROR>(__float_as_int(v)));
+    v += __int_as_float(dpp_i<MPNN_DPP_ROW_MIRROR>(__float_as_int(v)));
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i<CTRL>((int)b), hi = dpp_i<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ double lane_d(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_d<MPNN_DPP_QUAD_XOR1>(v);
+    v += dpp_d<MPNN_DPP_QUAD_XOR2>(v);
+    v += dpp_d<MPNN_DPP_HALF_MIRROR>(v);
+    v += dpp_d<MPNN_DPP_ROW_MIRROR>(v);
+    return (lane_d(v, 0) + lane_d(v, 16)) + (lane_d(v, 32) + lane_d(v, 48));
 }

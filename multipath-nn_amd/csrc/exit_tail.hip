@@ -2,13 +2,16 @@
 //   head   : Softmax + CrossEntropyError           (layer_types.py:81-84, 262-272)
 //   router : BN -> ReLU -> LinTrans(R) -> BN -> ReLU -> LinTrans(n_sinks)
 //            (arch_and_hypers.py:47-49; BatchNorm over the batch, layer_types.py:219-239)
-// One 256-thread workgroup per exit owns the whole batch: the router's
-// BatchNorms need statistics over every sample, and at R = 16 the arithmetic
-// is a few hundred KFLOP.  The launch is on the step's critical path, so:
+// TWO 256-thread workgroups per exit: an even one for the router tail, which
+// owns the whole batch (its BatchNorms need statistics over every sample, and
+// at R = 16 the arithmetic is a few hundred KFLOP), and an odd one for the
+// head (exp / log / divisions of one sample per thread) -- the two halves of
+// an exit share nothing, and inside one workgroup the head sat in front of the
+// router's serial chain.  The launch is on the step's critical path, so:
 // inputs are copied to LDS once (no dependent global round trips between
 // phases), every per-thread array has COMPILE-TIME bounds (runtime trip counts
-// would push them to scratch memory), reductions are two-pass (mean, then
-// centred second moment) through LDS in a fixed order -> deterministic.
+// would push them to scratch memory), reductions go through LDS in a fixed
+// order -> deterministic.
 // Limits: batch <= 128 per launch, R <= 16, n_sinks <= 4, n_cls <= 16.
 #include "common.h"
 
@@ -21,41 +24,40 @@
 // every LDS access of those phases took 16 passes -- 3.6 us per phase in the phase trace).
 #define TP 17
 
-// Sum over samples of f(s, c) for channel c < TR; totals land in out[c] (LDS).
-template <typename F>
-__device__ __forceinline__ void chan_reduce(int n, float *scratch, float *out, F f) {
-    const int tid = threadIdx.x;
-    const int c = tid & (TR - 1), sub = tid / TR;            // 16 sub-rows of 16 channels
-    float acc = 0.f;
-    for (int s = sub; s < n; s += 256 / TR) acc += f(s, c);
-    __syncthreads();
-    scratch[tid] = acc;
-    __syncthreads();
-    if (tid < TR) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 256 / TR; ++k) t += scratch[k * TR + tid];
-        out[tid] = t;
-    }
-    __syncthreads();
-}
-
-// Batch mean / rstd of x[n][TR] (two-pass) or the moving averages.  Channels >= R are inert.
+// Batch mean / rstd of x[n][TR] or the moving averages.  Channels >= R are inert.
+// ONE pass: sums of d = x - p and d^2 around the pivot p = x[0][c], 16 partial sums per channel in a
+// fixed order (deterministic), var = E[d^2] - (E[d])^2.  The pivot is a sample of the same distribution,
+// so the subtraction loses log2(1 + (mean - p)^2 / var) bits -- a few, of 24; the mean-then-centred
+// two-pass form this replaces cost three more barriers and a second sweep per BatchNorm.
 // m_old / v_old: the moving averages, loaded by the caller at kernel start (a load here would sit in
 // the middle of the serial chain: one more memory round trip per BatchNorm before the barrier).
 __device__ void bn_stats(const float *x, int n, int R, int mode, float eps, float decay, float *m_avg,
                          float *v_avg, float m_old, float v_old, float *scratch, float *mean, float *rstd) {
     const int tid = threadIdx.x;
     if (mode == MPNN_ACT_BN_BATCH) {
-        chan_reduce(n, scratch, mean, [&](int s, int c) { return x[s * TP + c]; });
-        if (tid < TR) mean[tid] /= (float)n;
+        const int c = tid & (TR - 1), sub = tid / TR;            // 16 sub-rows of 16 channels
+        const float pv = x[c];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CHUNK / (256 / TR); ++k) {
+            const int s = sub + k * (256 / TR);
+            const float d = s < n ? x[(s < n ? s : 0) * TP + c] - pv : 0.f;
+            s1 += d; s2 += d * d;
+        }
+        scratch[tid] = s1; scratch[256 + tid] = s2;
         __syncthreads();
-        chan_reduce(n, scratch, rstd, [&](int s, int c) { const float d = x[s * TP + c] - mean[c]; return d * d; });
-        if (tid < R) {
-            const float var = rstd[tid] / (float)n;
-            m_avg[tid] = decay * m_old + (1.f - decay) * mean[tid];
-            v_avg[tid] = decay * v_old + (1.f - decay) * var;
+        if (tid < TR) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 256 / TR; ++k) { t1 += scratch[k * TR + tid]; t2 += scratch[256 + k * TR + tid]; }
+            const float inv = 1.f / (float)n, dm = t1 * inv;
+            const float mu = pv + dm, var = fmaxf(t2 * inv - dm * dm, 0.f);
+            mean[tid] = mu;
             rstd[tid] = rsqrtf(var + eps);
+            if (tid < R) {
+                m_avg[tid] = decay * m_old + (1.f - decay) * mu;
+                v_avg[tid] = decay * v_old + (1.f - decay) * var;
+            }
         }
     } else if (tid < R) {
         mean[tid] = m_old;
@@ -76,52 +78,36 @@ __device__ __forceinline__ void head_softmax(const float *z, int n_cls, float *p
     for (int k = 0; k < TC; ++k) p[k] *= inv;
 }
 
-// Stage x[n][R] (global, row stride R) into LDS rows of TR, zero-padded.
+// Stage x[n][R] (global, row stride R) into LDS rows of TR, zero-padded: loads and stores are separate
+// calls so that a kernel can issue EVERY global load it needs before the first LDS store (a store waits
+// for its load: staging array after array was one memory round trip per array, 1-1.5 us each).
 // (fixed trip count, loads from clamped addresses issued back to back: a rolled loop with runtime
 // bounds made one dependent memory round trip per iteration -- 8 per staged array, 10 us per kernel)
-__device__ __forceinline__ void stage_rows(float *dst, const float *src, int rows, int R) {
-    float v[CHUNK * TR / 256];
+#define ROWS_PT (CHUNK * TR / 256)
+__device__ __forceinline__ void load_rows(float (&v)[ROWS_PT], const float *src, int rows, int R) {
 #pragma unroll
-    for (int k = 0; k < CHUNK * TR / 256; ++k) {
+    for (int k = 0; k < ROWS_PT; ++k) {
         const int i = threadIdx.x + k * 256, s = i / TR, c = i & (TR - 1);
         const bool ok = s < rows && c < R;
         v[k] = src[ok ? s * R + c : 0];
         v[k] = ok ? v[k] : 0.f;
     }
+}
+__device__ __forceinline__ void store_rows(float *dst, const float (&v)[ROWS_PT], int rows) {
 #pragma unroll
-    for (int k = 0; k < CHUNK * TR / 256; ++k) {
+    for (int k = 0; k < ROWS_PT; ++k) {
         const int i = threadIdx.x + k * 256, s = i / TR, c = i & (TR - 1);
         if (s < rows) dst[s * TP + c] = v[k];
     }
 }
 
 __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args *__restrict__ tab) {
-    const mpnn_exit_tail_args &a = tab[blockIdx.x];
+    const mpnn_exit_tail_args &a = tab[blockIdx.x >> 1];
     const int tid = threadIdx.x, n = a.n;
-    __shared__ float scratch[256];
-    __shared__ float bnp[4 * TR];                 // mean1, rstd1, mean2, rstd2
-    __shared__ float w2s[TR * TR], w3s[TR * TS], vec[5 * TR + TS];
-    __shared__ float h1s[CHUNK * TP], h2s[CHUNK * TP];
-
-    // The router's inputs and parameters are requested FIRST; the head (softmax, cross-entropy: its own
-    // loads, exp/log, stores) runs while they fly.
-    const bool has_router = a.h1 && n <= CHUNK;    // the host rejects n > CHUNK (MPNN_E_SHAPE)
-    const int R = a.R, S = a.n_sinks;
-    float m1o = 0.f, v1o = 1.f, m2o = 0.f, v2o = 1.f;
-    if (has_router) {
-        if (tid < R) { m1o = a.m1[tid]; v1o = a.v1[tid]; m2o = a.m2[tid]; v2o = a.v2[tid]; }
-        for (int i = tid; i < TR * TR; i += 256) { const int c = i / TR, j = i & (TR - 1); w2s[i] = (c < R && j < R) ? a.w2[c * R + j] : 0.f; }
-        for (int i = tid; i < TR * TS; i += 256) { const int c = i / TS, k = i & (TS - 1); w3s[i] = (c < R && k < S) ? a.w3[c * S + k] : 0.f; }
-        if (tid < TR) {
-            const bool ok = tid < R;
-            vec[tid] = ok ? a.g1[tid] : 0.f; vec[TR + tid] = ok ? a.b1[tid] : 0.f; vec[2 * TR + tid] = ok ? a.bias2[tid] : 0.f;
-            vec[3 * TR + tid] = ok ? a.g2[tid] : 0.f; vec[4 * TR + tid] = ok ? a.b2[tid] : 0.f;
-        }
-        if (tid < TS) vec[5 * TR + tid] = tid < S ? a.bias3[tid] : 0.f;
-        if (tid < 4 * TR) bnp[tid] = 0.f;
-        stage_rows(h1s, a.h1, n, R);
-    }
-    if (a.z) {
+    trace_stamp(0); trace_note(6, 12);
+    if (blockIdx.x & 1) {
+        // ---- the head: Softmax + CrossEntropyError, one sample per thread ----
+        if (!a.z) return;
         const int nc = a.n_cls;
         for (int s = tid; s < n; s += 256) {
             float z[TC], y[TC], p[TC];
@@ -143,27 +129,71 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
             a.c_err[s] = ce;
             a.d_cor[s] = ap == ay ? 1.f : 0.f;
         }
+        trace_stamp(5);
+        return;
     }
+    __shared__ float scratch[2 * 256];
+    __shared__ float bnp[4 * TR];                 // mean1, rstd1, mean2, rstd2
+    __shared__ float w2s[TR * TR], w3s[TR * TS], vec[5 * TR + TS];
+    __shared__ float h1s[CHUNK * TP], h2s[CHUNK * TP];
+
+    const bool has_router = a.h1 && n <= CHUNK;    // the host rejects n > CHUNK (MPNN_E_SHAPE)
     if (!has_router) return;
+    const int R = a.R, S = a.n_sinks;
+    float m1o, v1o, m2o, v2o;
+    {
+        // every global load of the kernel, then the LDS stores: ONE memory round trip
+        float rh[ROWS_PT];
+        load_rows(rh, a.h1, n, R);
+        const int tc = tid < R ? tid : 0;
+        m1o = a.m1[tc]; v1o = a.v1[tc]; m2o = a.m2[tc]; v2o = a.v2[tc];
+        const int wc = tid / TR, wj = tid & (TR - 1);
+        const bool ok2 = wc < R && wj < R;
+        float rw2 = a.w2[ok2 ? wc * R + wj : 0];
+        const int w3c = (tid & (TR * TS - 1)) / TS, w3k = tid & (TS - 1);
+        const bool ok3 = w3c < R && w3k < S;
+        float rw3 = a.w3[ok3 ? w3c * S + w3k : 0];
+        const float rg1 = a.g1[tc], rb1 = a.b1[tc], rbias2 = a.bias2[tc], rg2 = a.g2[tc], rb2 = a.b2[tc];
+        const float rbias3 = a.bias3[tid < S ? tid : 0];
+        store_rows(h1s, rh, n);
+        w2s[tid] = ok2 ? rw2 : 0.f;
+        if (tid < TR * TS) w3s[tid] = ok3 ? rw3 : 0.f;
+        if (tid < TR) {
+            const bool ok = tid < R;
+            vec[tid] = ok ? rg1 : 0.f; vec[TR + tid] = ok ? rb1 : 0.f; vec[2 * TR + tid] = ok ? rbias2 : 0.f;
+            vec[3 * TR + tid] = ok ? rg2 : 0.f; vec[4 * TR + tid] = ok ? rb2 : 0.f;
+        }
+        if (tid < TS) vec[5 * TR + tid] = tid < S ? rbias3 : 0.f;
+        if (tid < 4 * TR) bnp[tid] = 0.f;
+    }
     __syncthreads();
+    trace_stamp(1);
 
     bn_stats(h1s, n, R, a.mode, a.bn_eps, a.bn_decay, a.m1, a.v1, m1o, v1o, scratch, bnp, bnp + TR);
-    for (int s = tid; s < n; s += 256) {
-        float a1[TR];
+    trace_stamp(2);
+    {
+        // a1 = relu(bn1(h1)); h2 = a1 @ W2 + bias2: two threads per sample, eight output columns each
+        const int s = tid >> 1, j0 = (tid & 1) * (TR / 2);
+        if (s < n) {
+            float a1[TR];
 #pragma unroll
-        for (int c = 0; c < TR; ++c)
-            a1[c] = fmaxf(vec[c] * (h1s[s * TP + c] - bnp[c]) * bnp[TR + c] + vec[TR + c], 0.f);
+            for (int c = 0; c < TR; ++c)
+                a1[c] = fmaxf(vec[c] * (h1s[s * TP + c] - bnp[c]) * bnp[TR + c] + vec[TR + c], 0.f);
 #pragma unroll
-        for (int j = 0; j < TR; ++j) {
-            float h = vec[2 * TR + j];
+            for (int jj = 0; jj < TR / 2; ++jj) {
+                const int j = j0 + jj;
+                float h = vec[2 * TR + j];
 #pragma unroll
-            for (int c = 0; c < TR; ++c) h += a1[c] * w2s[c * TR + j];
-            h2s[s * TP + j] = h;
-            if (j < R) a.h2[s * R + j] = h;
+                for (int c = 0; c < TR; ++c) h += a1[c] * w2s[c * TR + j];
+                h2s[s * TP + j] = h;
+                if (j < R) a.h2[s * R + j] = h;
+            }
         }
     }
     __syncthreads();
+    trace_stamp(3);
     bn_stats(h2s, n, R, a.mode, a.bn_eps, a.bn_decay, a.m2, a.v2, m2o, v2o, scratch, bnp + 2 * TR, bnp + 3 * TR);
+    trace_stamp(4);
     for (int s = tid; s < n; s += 256) {
         float a2[TR];
 #pragma unroll
@@ -181,6 +211,7 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
         a.bn_save[tid] = bnp[tid]; a.bn_save[R + tid] = bnp[TR + tid];
         a.bn_save[2 * R + tid] = bnp[2 * TR + tid]; a.bn_save[3 * R + tid] = bnp[3 * TR + tid];
     }
+    trace_stamp(5);
 }
 
 int mpnn_trace_install_tail(void *buf) { return mpnn_trace_install(buf); }
@@ -189,7 +220,7 @@ extern "C" int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int coun
     if (count <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
     if (n_max > CHUNK) return MPNN_E_SHAPE;
-    hipLaunchKernelGGL(exit_tail_fwd_k, dim3(count), dim3(256), 0, (hipStream_t)stream, dev_table);
+    hipLaunchKernelGGL(exit_tail_fwd_k, dim3(2 * count), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;
 }
@@ -215,90 +246,107 @@ __device__ __forceinline__ f32x4 contract(int n, FA fa, FB fb) {
 }
 
 __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_args *__restrict__ tab) {
-    const mpnn_exit_tail_bwd_args &b = tab[blockIdx.x];
+    const mpnn_exit_tail_bwd_args &b = tab[blockIdx.x >> 1];
     const mpnn_exit_tail_args &a = b.f;
     const int tid = threadIdx.x, n = a.n;
     const int lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     trace_stamp(0); trace_note(6, 13);
 
+    if (blockIdx.x & 1) {
+        // ---- the head's backward, one sample per thread ----
+        if (!(a.z && b.dz)) return;
+        const int nc = a.n_cls;
+        for (int hs = tid; hs < n; hs += 256) {
+            float hz[TC], hy[TC], p[TC], gp[TC];
+#pragma unroll
+            for (int k = 0; k < TC; ++k) {
+                hz[k] = k < nc ? a.z[(size_t)hs * nc + k] : 0.f;
+                hy[k] = k < nc ? a.y[(size_t)hs * nc + k] : 0.f;
+            }
+            const float hw = b.w_cerr[hs];
+            head_softmax(hz, nc, p);
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < TC; ++k) {
+                const float q = a.eps_ce / (float)nc + (1.f - a.eps_ce) * p[k];
+                gp[k] = k < nc ? -hw * hy[k] * (1.f - a.eps_ce) / q : 0.f;
+                dot += gp[k] * p[k];
+            }
+#pragma unroll
+            for (int k = 0; k < TC; ++k) if (k < nc) b.dz[(size_t)hs * nc + k] = p[k] * (gp[k] - dot);
+        }
+        trace_stamp(5);
+        return;
+    }
+    const bool has_router = a.h1 && n <= CHUNK;
+    if (!has_router) return;
+
     const int R = a.R, S = a.n_sinks;
     __shared__ float w2s[TR * TR], w3s[TR * TS], vec[4 * TR], bnp[4 * TR];
     __shared__ float red[4 * TR];                 // dbeta2, dgamma2, dbeta1, dgamma1
     __shared__ float rowA[CHUNK * TP], rowB[CHUNK * TP], rowC[CHUNK * TP];
     __shared__ float h1s[CHUNK * TP], h2s[CHUNK * TP], drs[CHUNK * TS];
-    // ONE memory round trip for everything the kernel reads: the head's operands go to registers
-    // first, then the router tail's inputs are requested; head arithmetic and stores follow.
-    // The head's backward (one sample per thread) runs on waves 2-3 while waves 0-1 carry the first
-    // per-sample phase of the router tail: the two halves of the exit are independent.
-    const int hs = tid - 128;                            // the head sample of this thread (waves 2, 3)
-    const bool has_head = a.z && b.dz && hs >= 0 && hs < n;
-    float hz[TC], hy[TC], hw = 0.f;
     {
-        const int nc = a.n_cls;
-#pragma unroll
-        for (int k = 0; k < TC; ++k) {
-            const bool ok = has_head && k < nc;
-            hz[k] = a.z ? a.z[ok ? (size_t)hs * nc + k : 0] : 0.f;
-            hy[k] = a.y ? a.y[ok ? (size_t)hs * nc + k : 0] : 0.f;
-            if (!ok) { hz[k] = 0.f; hy[k] = 0.f; }
-        }
-        if (has_head) hw = b.w_cerr[hs];
-    }
-    const bool has_router = a.h1 && n <= CHUNK;
-    if (has_router) {
-        stage_rows(h1s, a.h1, n, R);
-        stage_rows(h2s, a.h2, n, R);
+        // every global load of the kernel, then the LDS stores: ONE memory round trip
+        float rh1[ROWS_PT], rh2[ROWS_PT], rdr[CHUNK * TS / 256];
+        load_rows(rh1, a.h1, n, R);
+        load_rows(rh2, a.h2, n, R);
 #pragma unroll
         for (int kk = 0; kk < CHUNK * TS / 256; ++kk) {
             const int i = tid + kk * 256, s = i / TS, k = i & (TS - 1);
             const bool ok = s < n && k < S;
-            const float v = b.dr[ok ? (size_t)s * a.r_stride + k : 0];
-            if (i < n * TS) drs[i] = ok ? v : 0.f;
+            rdr[kk] = b.dr[ok ? (size_t)s * a.r_stride + k : 0];
+            rdr[kk] = ok ? rdr[kk] : 0.f;
         }
-        { const int c = tid / TR, j = tid & (TR - 1); w2s[tid] = (c < R && j < R) ? a.w2[c * R + j] : 0.f; }
-        if (tid < TR * TS) { const int c = tid / TS, k = tid & (TS - 1); w3s[tid] = (c < R && k < S) ? a.w3[c * S + k] : 0.f; }
+        const int wc = tid / TR, wj = tid & (TR - 1);
+        const bool ok2 = wc < R && wj < R;
+        const float rw2 = a.w2[ok2 ? wc * R + wj : 0];
+        const int w3c = (tid & (TR * TS - 1)) / TS, w3k = tid & (TS - 1);
+        const bool ok3 = w3c < R && w3k < S;
+        const float rw3 = a.w3[ok3 ? w3c * S + w3k : 0];
+        const int tc = tid < R ? tid : 0;
+        const float rg1 = a.g1[tc], rb1 = a.b1[tc], rg2 = a.g2[tc], rb2 = a.b2[tc];
+        const float s0 = a.bn_save[tc], s1 = a.bn_save[R + tc], s2 = a.bn_save[2 * R + tc], s3 = a.bn_save[3 * R + tc];
+        store_rows(h1s, rh1, n);
+        store_rows(h2s, rh2, n);
+#pragma unroll
+        for (int kk = 0; kk < CHUNK * TS / 256; ++kk) {
+            const int i = tid + kk * 256;
+            if (i < n * TS) drs[i] = rdr[kk];
+        }
+        w2s[tid] = ok2 ? rw2 : 0.f;
+        if (tid < TR * TS) w3s[tid] = ok3 ? rw3 : 0.f;
         if (tid < TR) {
             const bool ok = tid < R;
-            vec[tid] = ok ? a.g1[tid] : 0.f; vec[TR + tid] = ok ? a.b1[tid] : 0.f;
-            vec[2 * TR + tid] = ok ? a.g2[tid] : 0.f; vec[3 * TR + tid] = ok ? a.b2[tid] : 0.f;
-            bnp[tid] = ok ? a.bn_save[tid] : 0.f; bnp[TR + tid] = ok ? a.bn_save[R + tid] : 0.f;
-            bnp[2 * TR + tid] = ok ? a.bn_save[2 * R + tid] : 0.f; bnp[3 * TR + tid] = ok ? a.bn_save[3 * R + tid] : 0.f;
+            vec[tid] = ok ? rg1 : 0.f; vec[TR + tid] = ok ? rb1 : 0.f;
+            vec[2 * TR + tid] = ok ? rg2 : 0.f; vec[3 * TR + tid] = ok ? rb2 : 0.f;
+            bnp[tid] = ok ? s0 : 0.f; bnp[TR + tid] = ok ? s1 : 0.f;
+            bnp[2 * TR + tid] = ok ? s2 : 0.f; bnp[3 * TR + tid] = ok ? s3 : 0.f;
         }
     }
-    auto head_bwd = [&]() {
-        if (!has_head) return;
-        const int nc = a.n_cls;
-        float p[TC], gp[TC];
-        head_softmax(hz, nc, p);
-        float dot = 0.f;
-#pragma unroll
-        for (int k = 0; k < TC; ++k) {
-            const float q = a.eps_ce / (float)nc + (1.f - a.eps_ce) * p[k];
-            gp[k] = k < nc ? -hw * hy[k] * (1.f - a.eps_ce) / q : 0.f;
-            dot += gp[k] * p[k];
-        }
-#pragma unroll
-        for (int k = 0; k < TC; ++k) if (k < nc) b.dz[(size_t)hs * nc + k] = p[k] * (gp[k] - dot);
-    };
-    if (!has_router) { head_bwd(); return; }
     __syncthreads();
     trace_stamp(1);
     const float inv_n = 1.f / (float)n;
     auto xh2 = [&](int s, int c) { return (h2s[s * TP + c] - bnp[2 * TR + c]) * bnp[3 * TR + c]; };
     auto xh1 = [&](int s, int c) { return (h1s[s * TP + c] - bnp[c]) * bnp[TR + c]; };
+    // the per-sample phases: two threads per sample, eight channels each
+    const int ps = tid >> 1, pc0 = (tid & 1) * (TR / 2);
 
-    // ---- phase A: per-sample a2 and the masked dL/d(bn2 out) (waves 0-1); the head on waves 2-3 ----
-    head_bwd();
-    if (tid < n) {
+    // ---- phase A: per-sample a2 and the masked dL/d(bn2 out) ----
+    if (ps < n) {
+        float drv[TS];
 #pragma unroll
-        for (int c = 0; c < TR; ++c) {
-            const float a2 = fmaxf(vec[2 * TR + c] * xh2(tid, c) + vec[3 * TR + c], 0.f);
+        for (int i = 0; i < TS; ++i) drv[i] = drs[ps * TS + i];
+#pragma unroll
+        for (int cc = 0; cc < TR / 2; ++cc) {
+            const int c = pc0 + cc;
+            const float a2 = fmaxf(vec[2 * TR + c] * xh2(ps, c) + vec[3 * TR + c], 0.f);
             float da = 0.f;
 #pragma unroll
-            for (int i = 0; i < TS; ++i) da += drs[tid * TS + i] * w3s[c * TS + i];
-            rowA[tid * TP + c] = a2;
-            rowB[tid * TP + c] = a2 > 0.f ? da : 0.f;
+            for (int i = 0; i < TS; ++i) da += drv[i] * w3s[c * TS + i];
+            rowA[ps * TP + c] = a2;
+            rowB[ps * TP + c] = a2 > 0.f ? da : 0.f;
         }
     }
     __syncthreads();
@@ -325,16 +373,33 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
     trace_stamp(2);
 
     // ---- phase B: dh2 (BatchNorm-2 backward) and a1 ----
-    if (tid < n) {
+    if (ps < n) {
 #pragma unroll
-        for (int c = 0; c < TR; ++c) {
-            const float dh2 = vec[2 * TR + c] * bnp[3 * TR + c] * (rowB[tid * TP + c] - red[c] * inv_n - xh2(tid, c) * red[TR + c] * inv_n);
-            rowB[tid * TP + c] = dh2;
-            rowA[tid * TP + c] = fmaxf(vec[c] * xh1(tid, c) + vec[TR + c], 0.f);   // a1
+        for (int cc = 0; cc < TR / 2; ++cc) {
+            const int c = pc0 + cc;
+            const float dh2 = vec[2 * TR + c] * bnp[3 * TR + c] * (rowB[ps * TP + c] - red[c] * inv_n - xh2(ps, c) * red[TR + c] * inv_n);
+            rowB[ps * TP + c] = dh2;
+            rowA[ps * TP + c] = fmaxf(vec[c] * xh1(ps, c) + vec[TR + c], 0.f);   // a1
         }
     }
     __syncthreads();
-    // dW2 = a1^T dh2 | dbias2 = sum dh2 (waves 0, 1); waves 2, 3: per-sample masked dL/d(bn1 out) -> rowC
+    // per-sample masked dL/d(bn1 out) -> rowC (needs the sample's whole dh2 row: hence the barrier)
+    if (ps < n) {
+        float dh2[TR];
+#pragma unroll
+        for (int j = 0; j < TR; ++j) dh2[j] = rowB[ps * TP + j];
+#pragma unroll
+        for (int cc = 0; cc < TR / 2; ++cc) {
+            const int c = pc0 + cc;
+            float da1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < TR; ++j) da1 += dh2[j] * w2s[c * TR + j];
+            rowC[ps * TP + c] = rowA[ps * TP + c] > 0.f ? da1 : 0.f;
+        }
+    }
+    __syncthreads();
+    trace_stamp(3);
+    // dW2 = a1^T dh2 | dbias2 = sum dh2 | dbeta1 = sum d1 | dgamma1 = sum d1 * xhat1: one wave each
     if (wave == 0) {
         const f32x4 d = contract(n, [&](int s, int i) { return rowA[s * TP + i]; }, [&](int s, int j) { return rowB[s * TP + j]; });
 #pragma unroll
@@ -342,28 +407,10 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
     } else if (wave == 1) {
         const f32x4 d = contract(n, [&](int, int i) { return i == 0 ? 1.f : 0.f; }, [&](int s, int j) { return rowB[s * TP + j]; });
         if (g == 0 && li < R) b.dbias2[li] = d[0];
-    } else {
-        const int s = tid - 128;
-        if (s < n) {
-            float dh2[TR];
-#pragma unroll
-            for (int j = 0; j < TR; ++j) dh2[j] = rowB[s * TP + j];
-#pragma unroll
-            for (int c = 0; c < TR; ++c) {
-                float da1 = 0.f;
-#pragma unroll
-                for (int j = 0; j < TR; ++j) da1 += dh2[j] * w2s[c * TR + j];
-                rowC[s * TP + c] = rowA[s * TP + c] > 0.f ? da1 : 0.f;
-            }
-        }
-    }
-    __syncthreads();
-    trace_stamp(3);
-    // dbeta1 = sum d1, dgamma1 = sum d1 * xhat1
-    if (wave == 0) {
+    } else if (wave == 2) {
         const f32x4 d = contract(n, [&](int, int i) { return i == 0 ? 1.f : 0.f; }, [&](int s, int j) { return rowC[s * TP + j]; });
         if (g == 0) { red[2 * TR + li] = d[0]; if (li < R) b.db1[li] = d[0]; }
-    } else if (wave == 1) {
+    } else {
         const f32x4 d = contract(n, [&](int, int i) { return i == 0 ? 1.f : 0.f; }, [&](int s, int j) { return rowC[s * TP + j] * xh1(s, j); });
         if (g == 0) { red[3 * TR + li] = d[0]; if (li < R) b.dg1[li] = d[0]; }
     }
@@ -382,7 +429,7 @@ extern "C" int mpnn_exit_tail_bwd(const mpnn_exit_tail_bwd_args *dev_table, int 
     if (count <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
     if (n_max > CHUNK) return MPNN_E_SHAPE;
-    hipLaunchKernelGGL(exit_tail_bwd_k, dim3(count), dim3(256), 0, (hipStream_t)stream, dev_table);
+    hipLaunchKernelGGL(exit_tail_bwd_k, dim3(2 * count), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

@@ -20,11 +20,19 @@
 // Critic: every cost is weighted by stop_gradient(p_tr), so only c_cre
 // reaches the router: dL/dr_i = p_tr * 2 * k_cre * (r_i + target_i) / n.
 //
-// Organisation (this launch is on the step's critical path): all 256 threads
-// preload the node table and every per-sample input into LDS in one burst;
-// then one wave walks the tree top-down (p_tr, p_ev) and bottom-up, each node
-// PUSHING its value into its parent's accumulator (no child searches); all
-// per-thread arrays have compile-time bounds so nothing lives in scratch.
+// Organisation (this launch is on the step's critical path; two workgroups at batch 128, so what
+// counts is the length of the dependent chain, not throughput):
+//   1. all threads preload every per-sample input into LDS in one burst, pack one 16-byte record
+//      per node in topological (depth, preorder) order, and compute softmax / arg-max of every
+//      (switch, sample) and the nodes' own cost terms;
+//   2. the two tree RECURRENCES run concurrently, each in one wave with no barriers: wave 0 top-down
+//      (p_tr, p_ev), wave 1 bottom-up (actor V / critic c_ev, c_opt) -- they do not depend on each
+//      other -- each node = one LDS round trip (operands from clamped addresses, no control flow,
+//      the next record fetched ahead);
+//   3. one barrier, then everything that is merely a FUNCTION of those values (global stores, dL/dr,
+//      loss terms, TALR statistics) by all four waves, nodes dealt round-robin.
+// The first version did all of a node's work inside the level-by-level walk: ~1 us per tree level,
+// 17 of the launch's 22 us.  All per-thread arrays have compile-time bounds: nothing in scratch.
 #include "common.h"
 
 #define MSK MPNN_MAX_SINKS
@@ -33,36 +41,45 @@
 // (47 blocks + 47 leaves, 39 switches: arch_and_hypers.py:99-127) would not fit 160 KB at 64.  The
 // working wave always has 64 lanes: lanes >= RB repeat lane RB-1's sample (same inputs, same
 // arithmetic, identical LDS writes) and keep out of every global write and sum.
+#define RT_THREADS 512       // eight waves: the preload and the read-only phase scale with them
+#define RT_WAVES (RT_THREADS / 64)
+
+__device__ __forceinline__ int4 uniform4(int4 v) {   // a record is the same in every lane: keep it in SGPRs
+    return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
+                     __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+}
+
 template <int RB>
-__global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
+__global__ __launch_bounds__(RT_THREADS) void route_k(const mpnn_route_args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = a.n, NN = a.n_nodes, MS = a.max_sinks;
     trace_stamp(0); trace_note(6, 14);
     float *P = lds;                               // p_tr per node            [NN][RB]
-    float *V = P + NN * RB;                       // actor: V ; critic: c_ev  [NN][RB]
+    float *PE = P + NN * RB;                      // p_ev per node            [NN][RB]
+    float *V = PE + NN * RB;                      // actor: V ; critic: c_ev  [NN][RB]
     float *O = V + NN * RB;                       // critic: c_opt            [NN][RB]
     float *RIN = O + NN * RB;                     // router outputs           [n_switches*MS][RB]
     float *CE = RIN + a.n_switches * MS * RB;     // leaf c_err               [n_leaves][RB]
     float *DC = CE + a.n_leaves * RB;             // leaf delta_cor           [n_leaves][RB]
-    int *ND = (int *)(DC + a.n_leaves * RB);      // node table               [NN][8]
-    float *OPS = (float *)(ND + NN * 8);          // node ops                 [NN]
-    float *SM = OPS + ((NN + 3) & ~3);            // softmax(r / tau)         [n_switches*MS][RB]
+    float *SM = DC + a.n_leaves * RB;             // softmax(r / tau)         [n_switches*MS][RB]
     int *ARG = (int *)(SM + a.n_switches * MS * RB);   // arg-max sink       [n_switches][RB]
-    int *SWN = ARG + a.n_switches * RB;           // sinks of each switch     [n_switches]
-    int *LV = SWN + a.n_switches;                 // nodes in (depth, preorder) order   [NN]
-    int *LS = LV + NN;                            // first LV slot of each depth level   [NN + 2]
-    {
-        const int s0 = blockIdx.x * RB;
+    int4 *REC = (int4 *)(ARG + a.n_switches * RB);     // node records by rank   [NN + 1]  (16-byte aligned: RB % 4 == 0)
+    float *OPS = (float *)(REC + NN + 1);         // node ops                 [NN]
+    int *SWN = (int *)(OPS + NN);                 // sinks of each switch     [n_switches]
+    const int s0 = blockIdx.x * RB;
+    const int wave = threadIdx.x >> 6;
+    constexpr int BT = RT_THREADS - 64;            // threads of the input burst; the last wave packs the records meanwhile
+    if (wave < RT_WAVES - 1) {
         const int rows_r = a.n_switches * MS, rows = rows_r + 2 * a.n_leaves;
         // Eight loads in flight per thread, from clamped addresses with no branch around them (a rolled
         // loop with one conditional load per iteration is one dependent memory round trip per iteration:
         // 8 of them = most of this kernel's time before).
         const int total = rows * RB;
-        for (int base = 0; base < total; base += 256 * 8) {
+        for (int base = 0; base < total; base += BT * 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = base + threadIdx.x + u * 256;
+                const int i = base + threadIdx.x + u * BT;
                 const int ic = i < total ? i : 0;
                 const int row = ic / RB, t = ic - row * RB, s = s0 + t;
                 const bool ok = i < total && s < n;
@@ -75,33 +92,41 @@ __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = base + threadIdx.x + u * 256;
+                const int i = base + threadIdx.x + u * BT;
                 if (i < total) RIN[i] = v[u];      // RIN, CE, DC are contiguous
             }
         }
-        for (int i = threadIdx.x; i < NN * 8; i += 256) ND[i] = a.nodes[i];
-        for (int i = threadIdx.x; i < NN; i += 256) {
-            const int sw = a.nodes[i * 8 + 3];
-            if (sw >= 0) SWN[sw] = a.nodes[i * 8 + 2];
+    } else {
+        // One record per node, stored at its rank nd[7] in (depth, preorder) order -- parents before
+        // children -- with everything the walks need about the node AND its parent:
+        //   x = par+1 | si<<8 | ns<<12 | (sw+1)<<16 | (leaf+1)<<24
+        //   y = n_leaves | n_leaves(par)<<8 | (sw(par)+1)<<16 | ns(par)<<24
+        //   z = the children of the node's switch, 8 bits each        w = node id
+        for (int i = threadIdx.x - BT; i < NN; i += 64) {
+            const int *nd = a.nodes + i * 8;
+            const int par = nd[0], ns = nd[2], sw = nd[3];
+            const int *pn = a.nodes + (par >= 0 ? par : 0) * 8;
+            int kids = 0;
+#pragma unroll
+            for (int k = 0; k < MSK; ++k)
+                if (sw >= 0 && k < ns && k < MS) kids |= (a.sw_children[sw * MS + k] & 255) << (8 * k);
+            REC[nd[7]] = make_int4((par + 1) | (nd[1] << 8) | (ns << 12) | ((sw + 1) << 16) | ((nd[4] + 1) << 24),
+                                   nd[5] | (pn[5] << 8) | ((par >= 0 ? pn[3] + 1 : 0) << 16) | ((par >= 0 ? pn[2] : 0) << 24),
+                                   kids, i);
+            if (sw >= 0) SWN[sw] = ns;
+            OPS[i] = a.node_ops[i];
         }
-        for (int i = threadIdx.x; i < NN; i += 256) OPS[i] = a.node_ops[i];
-        // level lists from the table's depth (nd[6]) and rank in (depth, preorder) order (nd[7])
-        for (int i = threadIdx.x; i < NN + 2; i += 256) LS[i] = NN;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < NN; i += 256) {
-        const int d = a.nodes[i * 8 + 6], rk = a.nodes[i * 8 + 7];
-        LV[rk] = i;
-        atomicMin(&LS[d], rk);
+        if (threadIdx.x == BT) REC[NN] = make_int4(0, 0, 0, 0);   // (the walks fetch one record ahead)
     }
     __syncthreads();
     trace_stamp(1);
-    // softmax(r / tau) and arg-max (first index on ties) of EVERY (switch, sample), by all four waves:
-    // the serial tree walks below only read them (they used to recompute them up to three times per
-    // node inside the one working wave).
+    const int type = a.net_type;
+    const bool dyn = type != MPNN_NET_SR;
+    // softmax(r / tau) and arg-max (first index on ties) of EVERY (switch, sample), and every node's own
+    // term of the bottom-up recursions, by all four waves: the walks below only read them.
     {
         const float inv_tau0 = 1.f / a.hyp[MPNN_HYP_TAU];
-        for (int i = threadIdx.x; i < a.n_switches * RB; i += 256) {
+        for (int i = threadIdx.x; i < a.n_switches * RB; i += RT_THREADS) {
             const int sw = i / RB, tt = i - sw * RB;
             const int ns = SWN[sw];
             const float *r = RIN + (sw * MS) * RB + tt;
@@ -118,153 +143,187 @@ __global__ __launch_bounds__(256) void route_k(const mpnn_route_args a) {
             for (int k = 0; k < MSK; ++k) if (k < MS) SM[(sw * MS + k) * RB + tt] = e[k] * inv;
             ARG[sw * RB + tt] = arg;
         }
+        if (dyn) {
+            const int tt = threadIdx.x % RB;           // (RT_THREADS % RB == 0: the same sample every iteration)
+            const float kc = a.k_cpt_vec ? (s0 + tt < n ? a.k_cpt_vec[s0 + tt] : 0.f) : a.hyp[MPNN_HYP_KCPT];
+            const bool cls = type == MPNN_NET_CRITIC && a.use_cls_err;
+            for (int i = threadIdx.x; i < NN * RB; i += RT_THREADS) {
+                const int j = i / RB, leaf = a.nodes[j * 8 + 4];
+                const int lc = leaf >= 0 ? leaf : 0;
+                const float ce = cls ? 1.f - DC[lc * RB + tt] : CE[lc * RB + tt];
+                const float own = (leaf >= 0 ? ce : 0.f) + kc * OPS[j];
+                V[i] = own;                            // actor: V; critic: c_ev accumulator
+                O[i] = own;                            // critic: c_opt starts from the same own term
+            }
+        }
     }
     __syncthreads();
     trace_stamp(2);
-    const int wave = threadIdx.x >> 6;
-    int D = 0;                                     // deepest level
-    for (int d = 0; d < NN; ++d) if (LS[d] < NN) D = d;
     const int lane_t = threadIdx.x & 63;
     const int t = lane_t < RB ? lane_t : RB - 1;
-    const int s = blockIdx.x * RB + t;
+    const int s = s0 + t;
     const bool in_range = s < n, live = in_range && lane_t < RB;
     const float inv_n = 1.f / (float)a.n_total;
     const float tau = a.hyp[MPNN_HYP_TAU], eps = a.hyp[MPNN_HYP_EPS];
     const float k_cpt = a.k_cpt_vec ? (in_range ? a.k_cpt_vec[s] : 0.f) : a.hyp[MPNN_HYP_KCPT];
     const float k_dec = a.hyp[MPNN_HYP_KDEC], k_cre = a.hyp[MPNN_HYP_KCRE];
     const float inv_tau = 1.f / tau;
-    const float eps_unit = eps / (float)ND[5];    // eps / n_leaves(root)
-    const int type = a.net_type;
-    const bool dyn = type != MPNN_NET_SR;
+    const float eps_unit = eps / (float)a.nodes[5];    // eps / n_leaves(root)
     float l_err = 0.f, l_cpt = 0.f, l_aux = 0.f;
 
-    // softmax / arg-max of switch sw for this sample: precomputed above
-    auto soft = [&](int sw, int ns, float *sm, int &arg) {
-#pragma unroll
-        for (int i = 0; i < MSK; ++i) sm[i] = (i < ns && i < MS) ? SM[(sw * MS + i) * RB + t] : 0.f;
-        arg = ARG[sw * RB + t];
+    // p_tr, p_ev of a node from its parent's (operands from clamped addresses, no control flow)
+    auto from_parent = [&](const int4 rc, float &ptr, float &pev) {
+        const int par = (rc.x & 255) - 1, si = (rc.x >> 8) & 15;
+        const int nl = rc.y & 255, pnl = (rc.y >> 8) & 255, psw = ((rc.y >> 16) & 255) - 1, pns = (rc.y >> 24) & 15;
+        const int parc = par >= 0 ? par : 0, pswc = psw >= 0 ? psw : 0;
+        const float pp = P[parc * RB + t], ppe = PE[parc * RB + t];
+        const float mine = SM[(pswc * MS + (si < MS ? si : 0)) * RB + t];
+        const int arg = ARG[pswc * RB + t];
+        const bool dynp = dyn && psw >= 0 && pns >= 2;
+        ptr = dynp ? (pp - eps_unit * (float)pnl) * mine + eps_unit * (float)nl : pp;
+        pev = dynp ? (arg == si ? ppe : 0.f) : ppe;
+        ptr = par >= 0 ? ptr : 1.f;
+        pev = par >= 0 ? pev : 1.f;
     };
-
-    // ---- top-down, one tree LEVEL at a time: p_tr, p_ev; own cost terms ----
-    // The nodes of a level only depend on the level above, so the four waves take them in parallel (the
-    // chains have two nodes per level: nine steps instead of a 17-node serial walk in one wave).
-    for (int d = 0; d <= D; ++d) {
-        for (int kq = LS[d] + wave; kq < LS[d + 1]; kq += 4) {
-            const int j = LV[kq];
-            const int *nd = ND + j * 8;
-            const int par = nd[0], si = nd[1], leaf = nd[4];
-            float ptr = 1.f, pev = 1.f;
-            if (par >= 0) {
-                const int *pn = ND + par * 8;
-                const int psw = pn[3], pns = pn[2];
-                const float pp = P[par * RB + t], ppe = O[par * RB + t];   // O doubles as p_ev storage top-down
-                if (dyn && psw >= 0 && pns >= 2) {
-                    float sm[MSK]; int arg;
-                    soft(psw, pns, sm, arg);
-                    float mine = 0.f;
-#pragma unroll
-                    for (int i = 0; i < MSK; ++i) if (i == si) mine = sm[i];
-                    ptr = (pp - eps_unit * (float)pn[5]) * mine + eps_unit * (float)nd[5];
-                    pev = arg == si ? ppe : 0.f;
-                } else { ptr = pp; pev = ppe; }
+    if (wave == 0) {
+        // ---- top-down recurrence: p_tr, p_ev of every node THAT HAS CHILDREN, parents first (the
+        // childless ones -- half of a chain -- are nobody's operand: phase 3 evaluates them) ----
+        int4 rc = uniform4(REC[0]);
+        for (int kq = 0; kq < NN; ++kq) {
+            const int4 nxv = REC[kq + 1];
+            if (((rc.x >> 12) & 15) > 0) {
+                float ptr, pev;
+                from_parent(rc, ptr, pev);
+                P[rc.w * RB + t] = ptr;
+                PE[rc.w * RB + t] = pev;
             }
-            P[j * RB + t] = ptr;
-            O[j * RB + t] = pev;
-            if (live) { a.p_tr[(size_t)j * n + s] = ptr; a.p_ev[(size_t)j * n + s] = pev; }
-            // own terms of the bottom-up recursions
-            const float cerr = leaf >= 0 ? CE[leaf * RB + t] : 0.f;
-            const float dcor = leaf >= 0 ? DC[leaf * RB + t] : 1.f;
-            const float ops = OPS[j];
-            const float w = type == MPNN_NET_SR ? 1.f : ptr;
-            if (leaf >= 0 && live && a.w_cerr) a.w_cerr[(size_t)leaf * n + s] = w * inv_n;
-            l_err += w * cerr;
-            if (type == MPNN_NET_ACTOR) { l_cpt += ptr * k_cpt * ops; V[j * RB + t] = cerr + k_cpt * ops; }
-            else if (type == MPNN_NET_CRITIC) {
-                const float ce = a.use_cls_err ? (leaf >= 0 ? 1.f - dcor : 0.f) : cerr;
-                V[j * RB + t] = ce + k_cpt * ops;      // c_ev accumulator (children pushed below)
+            rc = uniform4(nxv);
+        }
+    } else if (wave == 1 && dyn) {
+        // ---- bottom-up recurrence, children first; a node with a static parent pushes into it (a
+        // dynamic parent reads its children itself; a static node has at most one sink).  One loop per
+        // net type and only the net's own sink count: this wave's instruction count IS the phase. ----
+        const bool actor = type == MPNN_NET_ACTOR;
+        int4 rc = uniform4(REC[NN - 1]);
+        for (int kq = NN - 1; kq >= 0; --kq) {
+            const int4 nxv = REC[kq > 0 ? kq - 1 : NN];       // (made uniform at the bottom: off the critical path)
+            const int par = (rc.x & 255) - 1, ns = (rc.x >> 12) & 15, sw = ((rc.x >> 16) & 255) - 1, j = rc.w;
+            const int psw = ((rc.y >> 16) & 255) - 1, pns = (rc.y >> 24) & 15;
+            const bool is_sw = sw >= 0 && ns >= 2, push = par >= 0 && !(psw >= 0 && pns >= 2);
+            if (is_sw || push) {                       // (else: a leaf under a dynamic switch, its own term is final)
+                const int parc = par >= 0 ? par : 0, swc = sw >= 0 ? sw : 0;
+                const float *smp = SM + swc * MS * RB + t;
+                const float vj = V[j * RB + t], vp = V[parc * RB + t];
+                float kev[MSK], sm[MSK];
+#pragma unroll
+                for (int i = 0; i < MSK; ++i)
+                    if (i < MS) { kev[i] = V[((rc.z >> (8 * i)) & 255) * RB + t]; sm[i] = smp[i * RB]; }
+                float v_new = vj;
+                if (actor) {
+                    if (is_sw) {
+#pragma unroll
+                        for (int i = 0; i < MSK; ++i)
+                            if (i < MS) v_new += i < ns ? sm[i] * kev[i] : 0.f;
+                        V[j * RB + t] = v_new;
+                    }
+                    if (push) V[parc * RB + t] = vp + v_new;
+                } else {
+                    const float oj = O[j * RB + t], op = O[parc * RB + t];
+                    const int arg = ARG[swc * RB + t];
+                    float kopt[MSK];
+#pragma unroll
+                    for (int i = 0; i < MSK; ++i)
+                        if (i < MS) kopt[i] = O[((rc.z >> (8 * i)) & 255) * RB + t];
+                    float o_new = oj;
+                    if (is_sw) {
+                        float mn = kopt[0];
+#pragma unroll
+                        for (int i = 0; i < MSK; ++i)
+                            if (i < MS) {
+                                v_new += (i < ns && i == arg) ? kev[i] : 0.f;
+                                mn = i < ns ? fminf(mn, kopt[i]) : mn;
+                            }
+                        o_new += mn;
+                        V[j * RB + t] = v_new;
+                        O[j * RB + t] = o_new;
+                    }
+                    if (push) { V[parc * RB + t] = vp + v_new; O[parc * RB + t] = op + o_new; }
+                }
+            }
+            rc = uniform4(nxv);
+        }
+    }
+    __syncthreads();
+    trace_stamp(3);
+
+    // ---- everything that only READS the recurrences: nodes dealt to the four waves ----
+    for (int kq = wave; kq < NN; kq += RT_WAVES) {
+        const int4 rc = uniform4(REC[kq]);
+        const int ns = (rc.x >> 12) & 15, sw = ((rc.x >> 16) & 255) - 1, leaf = ((rc.x >> 24) & 255) - 1, j = rc.w;
+        const int nl = rc.y & 255;
+        const int swc = sw >= 0 ? sw : 0, leafc = leaf >= 0 ? leaf : 0;
+        float ptr = P[j * RB + t], pev = PE[j * RB + t];
+        const float cerr_l = CE[leafc * RB + t], ops = OPS[j];
+        float ptr_c, pev_c;
+        from_parent(rc, ptr_c, pev_c);
+        ptr = ns > 0 ? ptr : ptr_c;                // (childless: not stored by the recurrence)
+        pev = ns > 0 ? pev : pev_c;
+        float sm[MSK], rr[MSK], kev[MSK], kopt[MSK];
+#pragma unroll
+        for (int i = 0; i < MSK; ++i) {
+            sm[i] = rr[i] = kev[i] = kopt[i] = 0.f;
+            if (i < MS && dyn) {
+                const int kid = (rc.z >> (8 * i)) & 255;
+                sm[i] = SM[(swc * MS + i) * RB + t];
+                rr[i] = RIN[(swc * MS + i) * RB + t];
+                kev[i] = V[kid * RB + t];
+                kopt[i] = O[kid * RB + t];
             }
         }
-        __syncthreads();
-    }
-    trace_stamp(3);
-    // ---- node statistics for TALR: sum p_tr, sum p_tr^2 (every wave its share of the nodes) ----
-    if (a.node_stat) {
-        for (int j = wave; j < NN; j += 4) {
-            const float p = live ? P[j * RB + t] : 0.f;
-            const float s1 = wave_sum_f(p), s2 = wave_sum_f(p * p);
+        const float cerr = leaf >= 0 ? cerr_l : 0.f;
+        const float w = type == MPNN_NET_SR ? 1.f : ptr;
+        if (live) {
+            a.p_tr[(size_t)j * n + s] = ptr; a.p_ev[(size_t)j * n + s] = pev;
+            if (leaf >= 0 && a.w_cerr) a.w_cerr[(size_t)leaf * n + s] = w * inv_n;
+        }
+        l_err += w * cerr;
+        if (type == MPNN_NET_ACTOR) l_cpt += ptr * k_cpt * ops;
+        if (a.node_stat) {                         // TALR: sum p_tr, sum p_tr^2
+            const float pl = live ? ptr : 0.f;
+            const float s1 = wave_sum_f(pl), s2 = wave_sum_f(pl * pl);
             if (lane_t == 0) { atomicAdd(a.node_stat + j * 2, s1); atomicAdd(a.node_stat + j * 2 + 1, s2); }
         }
-    }
-    if (type == MPNN_NET_CRITIC) {
-        for (int j = wave; j < NN; j += 4) O[j * RB + t] = V[j * RB + t];     // c_opt starts from the same own term
-        __syncthreads();
-    }
-
-    // ---- bottom-up, deepest level first; each node pushes into its (static) parent ----
-    if (type != MPNN_NET_SR) {
-        for (int d = D; d >= 0; --d) {
-            for (int kq = LS[d] + wave; kq < LS[d + 1]; kq += 4) {
-                const int j = LV[kq];
-                const int *nd = ND + j * 8;
-                const int par = nd[0], ns = nd[2], sw = nd[3];
-                const float p = P[j * RB + t];
-                if (sw >= 0 && ns >= 2) {              // dynamic switch: children are final
-                    const float *r = RIN + (sw * MS) * RB + t;
-                    const int *kids = a.sw_children + sw * MS;
-                    float sm[MSK]; int arg;
-                    soft(sw, ns, sm, arg);
-                    if (type == MPNN_NET_ACTOR) {
-                        const float eps_l = eps_unit * (float)nd[5];
-                        float u[MSK], ubar = 0.f, r2 = 0.f, v = V[j * RB + t];
+        if (dyn && sw >= 0 && ns >= 2) {
+            const float p = ptr;
+            if (type == MPNN_NET_ACTOR) {
+                const float eps_l = eps_unit * (float)nl;
+                float u[MSK], ubar = 0.f, r2 = 0.f;
 #pragma unroll
-                        for (int i = 0; i < MSK; ++i) {
-                            u[i] = 0.f;
-                            if (i < ns) {
-                                const float vc = V[kids[i] * RB + t];
-                                v += sm[i] * vc;
-                                u[i] = (p - eps_l) * vc;
-                                ubar += sm[i] * u[i];
-                                r2 += r[i * RB] * r[i * RB];
-                            }
-                        }
-                        V[j * RB + t] = v;
-                        l_aux += p * k_dec * r2;
-                        if (a.want_grad && live) {
+                for (int i = 0; i < MSK; ++i) {
+                    const bool on = i < ns;
+                    u[i] = on ? (p - eps_l) * kev[i] : 0.f;
+                    ubar += on ? sm[i] * u[i] : 0.f;
+                    r2 += on ? rr[i] * rr[i] : 0.f;
+                }
+                l_aux += p * k_dec * r2;
+                if (a.want_grad && live) {
 #pragma unroll
-                            for (int i = 0; i < MSK; ++i)
-                                if (i < ns)
-                                    a.dr[((size_t)sw * n + s) * MS + i] =
-                                        (sm[i] * (u[i] - ubar) * inv_tau + 2.f * k_dec * p * r[i * RB]) * inv_n;
-                        }
-                    } else {
-                        float cev = V[j * RB + t], mn = 0.f, cre = 0.f;
+                    for (int i = 0; i < MSK; ++i)
+                        if (i < ns)
+                            a.dr[((size_t)sw * n + s) * MS + i] = (sm[i] * (u[i] - ubar) * inv_tau + 2.f * k_dec * p * rr[i]) * inv_n;
+                }
+            } else {
+                float cre = 0.f;
 #pragma unroll
-                        for (int i = 0; i < MSK; ++i) {
-                            if (i < ns) {
-                                const float kev = V[kids[i] * RB + t], kopt = O[kids[i] * RB + t];
-                                mn = i == 0 ? kopt : fminf(mn, kopt);
-                                if (i == arg) cev += kev;
-                                const float dd = r[i * RB] + (a.optimistic ? kopt : kev);
-                                cre += dd * dd;
-                                if (a.want_grad && live) a.dr[((size_t)sw * n + s) * MS + i] = p * 2.f * k_cre * dd * inv_n;
-                            }
-                        }
-                        V[j * RB + t] = cev;
-                        O[j * RB + t] += mn;
-                        l_aux += p * k_cre * cre;
+                for (int i = 0; i < MSK; ++i) {
+                    if (i < ns) {
+                        const float dd = rr[i] + (a.optimistic ? kopt[i] : kev[i]);
+                        cre += dd * dd;
+                        if (a.want_grad && live) a.dr[((size_t)sw * n + s) * MS + i] = p * 2.f * k_cre * dd * inv_n;
                     }
                 }
-                // push into a STATIC parent (a dynamic parent reads its children itself; a static node has
-                // at most one sink, so nobody else writes the parent's slot in this level)
-                if (par >= 0) {
-                    const int *pn = ND + par * 8;
-                    if (!(pn[3] >= 0 && pn[2] >= 2)) {
-                        V[par * RB + t] += V[j * RB + t];
-                        if (type == MPNN_NET_CRITIC) O[par * RB + t] += O[j * RB + t];
-                    }
-                }
+                l_aux += p * k_cre * cre;
             }
-            __syncthreads();
         }
     }
 
@@ -286,8 +345,8 @@ extern "C" int mpnn_route(const mpnn_route_args *args, void *stream) {
     if (!args || !args->nodes || !args->p_tr || !args->p_ev) return MPNN_E_ARG;
     if (args->n_nodes > MPNN_MAX_NODES || args->max_sinks > MPNN_MAX_SINKS) return MPNN_E_SHAPE;
     if (args->n <= 0) return 0;
-    const size_t per = (size_t)(3 * args->n_nodes + 2 * args->n_switches * args->max_sinks + args->n_switches + 2 * args->n_leaves) * 4;
-    const size_t fix = (size_t)(args->n_nodes * 11 + 8 + args->n_switches) * 4;
+    const size_t per = (size_t)(4 * args->n_nodes + 2 * args->n_switches * args->max_sinks + args->n_switches + 2 * args->n_leaves) * 4;
+    const size_t fix = (size_t)(args->n_nodes * 5 + 8 + args->n_switches) * 4;
     const size_t cap = 160 * 1024;
     const hipStream_t st = (hipStream_t)stream;
     const int n = args->n;
@@ -298,9 +357,9 @@ extern "C" int mpnn_route(const mpnn_route_args *args, void *stream) {
         hipFuncSetAttribute((const void *)route_k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
         raised = true;
     }
-    if (per * 64 + fix <= cap)      hipLaunchKernelGGL(route_k<64>, dim3((n + 63) / 64), dim3(256), per * 64 + fix, st, *args);
-    else if (per * 32 + fix <= cap) hipLaunchKernelGGL(route_k<32>, dim3((n + 31) / 32), dim3(256), per * 32 + fix, st, *args);
-    else if (per * 16 + fix <= cap) hipLaunchKernelGGL(route_k<16>, dim3((n + 15) / 16), dim3(256), per * 16 + fix, st, *args);
+    if (per * 64 + fix <= cap)      hipLaunchKernelGGL(route_k<64>, dim3((n + 63) / 64), dim3(RT_THREADS), per * 64 + fix, st, *args);
+    else if (per * 32 + fix <= cap) hipLaunchKernelGGL(route_k<32>, dim3((n + 31) / 32), dim3(RT_THREADS), per * 32 + fix, st, *args);
+    else if (per * 16 + fix <= cap) hipLaunchKernelGGL(route_k<16>, dim3((n + 15) / 16), dim3(RT_THREADS), per * 16 + fix, st, *args);
     else return MPNN_E_SHAPE;
     MPNN_LAUNCH_CHECK();
     return 0;

@@ -183,7 +183,11 @@ def test_cr_chain():
 
 def test_cr_chain_optimistic_clserr():
     import arch_and_hypers as A
-    run_case(A.cr_chain(k_cpt=8e-9, optimistic=True, use_cls_err=True), 12, lambda net, t: {net.τ: 0.05}, steps=2)
+    # (tau = 0.05 pins p_tr of the deep nodes at the epsilon floor: their TALR scale 1/sqrt(mean p_tr^2) is
+    # in the hundreds and multiplies gradient errors that sit inside the gradient check's own 1e-6 absolute
+    # floor; the worst update error of this case moves between 0.98e-4 and 1.2e-4 with the summation order
+    # of the routing kernel, so it gets 2e-4)
+    run_case(A.cr_chain(k_cpt=8e-9, optimistic=True, use_cls_err=True), 12, lambda net, t: {net.τ: 0.05}, steps=2, tol=2e-4)
 
 
 def test_ac_chain_notalr_nokdec():
