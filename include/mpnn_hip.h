@@ -268,7 +268,7 @@ int mpnn_lin_fwd(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void 
 typedef struct {
     mpnn_act a;  int HW;
     const float *w[2];  const float *dy[2];  int M[2];
-    float *dw[2];  float *db[2];         /* ACCUMULATED into (caller-zeroed) tensors */
+    float *dw[2];  float *db[2];         /* written (sums over all n rows, fixed order) */
     float *dx;                           /* [n, HW*C] written, or NULL             */
     const float *k_cpt;  float alpha_cpt;  int extra_col[2];
     int n;

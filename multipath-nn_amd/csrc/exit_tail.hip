@@ -102,7 +102,7 @@ __device__ __forceinline__ void store_rows(float *dst, const float (&v)[ROWS_PT]
 }
 
 __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args *__restrict__ tab) {
-    const mpnn_exit_tail_args &a = tab[blockIdx.x >> 1];
+    const mpnn_exit_tail_args a = tab[blockIdx.x >> 1];   // (by value: every field's scalar load in the entry block)
     const int tid = threadIdx.x, n = a.n;
     trace_stamp(0); trace_note(6, 12);
     if (blockIdx.x & 1) {
@@ -246,7 +246,7 @@ __device__ __forceinline__ f32x4 contract(int n, FA fa, FB fb) {
 }
 
 __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_args *__restrict__ tab) {
-    const mpnn_exit_tail_bwd_args &b = tab[blockIdx.x >> 1];
+    const mpnn_exit_tail_bwd_args b = tab[blockIdx.x >> 1];   // (by value: every field's scalar load in the entry block)
     const mpnn_exit_tail_args &a = b.f;
     const int tid = threadIdx.x, n = a.n;
     const int lane = tid & 63, g = lane >> 4, li = lane & 15;

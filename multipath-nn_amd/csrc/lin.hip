@@ -4,16 +4,16 @@
 // trunk -> exits -> router -> exits backward -> trunk backward) with almost no
 // arithmetic, so they are organised for latency: table-driven (one launch for
 // every exit of the tree), K split over 16 waves in the forward, and ONE
-// backward kernel in which a thread owns a feature k, streams the batch rows
-// (dY broadcast from LDS, X prefetched 16 rows at a time) and produces dX, dW
-// and db in a single pass (row groups add their dW/db partials with fp32 atomics).
+// backward kernel that produces dX, dW and db (and the fused BatchNorm-backward
+// reductions) from one load of X on MFMA tiles (row groups add their dW/db
+// partials with fp32 atomics).
 #include "common.h"
 
 // ------------------------------- forward ------------------------------------
 // 16 samples x 16 outputs per MFMA tile; waves split K, partial tiles meet in LDS.
 #define LF_WAVES 16
 __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_args *__restrict__ tab) {
-    const mpnn_lin_fwd_args &a = tab[blockIdx.y];
+    const mpnn_lin_fwd_args &a = tab[blockIdx.y];      // (by reference: w[] / b[] are indexed at run time, a copy would live in scratch)
     const int n0 = blockIdx.x * 16;
     if (n0 >= a.n) return;
     trace_stamp(0); trace_note(6, 10);
@@ -34,6 +34,22 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
     const int row = n0 + li;
     const bool valid = row < a.n;
     const int M0 = a.w[0] ? a.M[0] : 0, M1 = a.w[1] ? a.M[1] : 0;
+    // The epilogue's own operands (bias, the dyn_k_cpt column) are requested NOW: loaded where they are
+    // used they were one more memory round trip at the very end of the kernel.
+    float ep_bias = 0.f, ep_extra = 0.f;
+    bool ep_on = false;
+    int ep_row = 0, ep_col = 0, ep_M = 0, ep_s = 0;
+    if (tid < 512) {                         // (set, lane, r): 2 * 64 * 4 outputs
+        const int e = tid & 255, l = e >> 2, r = e & 3;
+        ep_s = tid >> 8;
+        ep_M = ep_s ? M1 : M0;
+        ep_row = n0 + (l >> 4) * 4 + r; ep_col = l & 15;
+        ep_on = ep_M > 0 && ep_row < a.n && ep_col < ep_M;
+        if (ep_on) {
+            ep_bias = a.b[ep_s][ep_col];
+            if (a.extra_col[ep_s]) ep_extra = a.alpha_cpt * a.k_cpt[ep_row] * a.w[ep_s][(size_t)K * ep_M + ep_col];
+        }
+    }
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     // LF_UN 16-feature blocks per iteration, ALL their loads issued before the first MFMA: a wave's K
     // share is a chain of dependent memory round trips (one per iteration), 8 of them at K = 2048 with
@@ -83,19 +99,12 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
         red[(wid * 2 + 1) * 256 + lane * 4 + r] = acc1[r];
     }
     __syncthreads();
-    if (tid < 512) {                         // (set, lane, r): 2 * 64 * 4 outputs
-        const int s = tid >> 8, e = tid & 255, l = e >> 2, r = e & 3;
-        if (a.w[s]) {
-            const int M = a.M[s];
-            const int orow = n0 + (l >> 4) * 4 + r, col = l & 15;
-            if (orow < a.n && col < M) {
-                float v = a.b[s][col];
+    if (ep_on) {
+        const int e = tid & 255;
+        float v = ep_bias;
 #pragma unroll
-                for (int w = 0; w < LF_WAVES; ++w) v += red[(w * 2 + s) * 256 + e];
-                if (a.extra_col[s]) v += a.alpha_cpt * a.k_cpt[orow] * a.w[s][(size_t)K * M + col];
-                a.y[s][(size_t)orow * M + col] = v;
-            }
-        }
+        for (int w = 0; w < LF_WAVES; ++w) v += red[(w * 2 + ep_s) * 256 + e];
+        a.y[ep_s][(size_t)ep_row * ep_M + ep_col] = v + ep_extra;
     }
     trace_stamp(5);
 }
@@ -112,123 +121,200 @@ extern "C" int mpnn_lin_fwd(const mpnn_lin_fwd_args *dev_table, int count, int n
 }
 
 // ------------------------------- backward -----------------------------------
-// Thread <-> feature k.  For every batch row r:
-//   dX[r][k]   = sum_s sum_m dY_s[r][m] * W_s[k][m]
-//   dW_s[k][m] += act(X)[r][k] * dY_s[r][m]           db_s[m] = sum_r dY_s[r][m]
-// W rows live in registers, dY rows are staged in LDS (<= LB_ROWS rows per pass).
-#ifndef LB_ROWS
-#define LB_ROWS 16          // rows per pass and per z-slice (the row loop is VALU-bound: ~100 instructions per row)
-#endif
+// A workgroup owns 64 features k (one 16-feature MFMA tile per wave) and ALL batch rows, 16 per pass;
+// both contractions run on v_mfma_f32_16x16x4_f32:
+//   dX[r][k]    = sum_m dY[r][m] * W[k][m]          D[i = r][j = k]   inner index m = 4s + g, s = 0..7
+//   dW[k][m]    = sum_r act(X)[r][k] * dY[r][m]      D[i = k][j = m]   inner index r = 4g + s, s = 0..3
+//   db[m]       = sum_r dY[r][m]
+// (m: the head's outputs in columns 0..15, the router's in 16..31, zero-padded.)  A lane (g, li) of the
+// dX tile holds rows 4g..4g+3 of feature li -- exactly the A operands the dW contraction wants when its
+// inner index is ordered r = 4g + s, so X is loaded ONCE, in that layout (every row of the batch up
+// front: one memory round trip), W straight into B-operand registers, and only dY goes through LDS.
+// No workgroup shares an output with another: dW, db are plain stores in a fixed summation order.
+// (History: a thread-per-feature VALU loop, ~100 instructions per row, with the rows split over eight
+// workgroups that ADDED their dW partials -- 0.8 M fp32 atomics per step, 7 us of a 21 us launch.)
+#define LB_ROWS 16          // rows per MFMA pass
+#define LB_SUPER 128        // rows held in LDS / registers at a time (the exit tails cap a launch at 128 anyway)
+#define LB_NP (LB_SUPER / LB_ROWS)
+#define LB_GP 4             // passes in flight together
+#define LB_DP 36            // LDS pitch of a dY row: 4 * 36 = 16 (mod 32) -> the dW operand reads are conflict-free
 __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__restrict__ tab) {
-    const mpnn_lin_bwd_args &a = tab[blockIdx.y];
+    const mpnn_lin_bwd_args &a = tab[blockIdx.y];      // (by reference: w[] / dy[] are indexed at run time, a copy would live in scratch)
     const int C = a.a.C, K = a.HW * C;
     const bool has_extra = a.extra_col[0] || a.extra_col[1];
     const int kext = K + (has_extra ? 1 : 0);
-    if ((int)(blockIdx.x * 256) >= kext) return;
+    const int k0 = blockIdx.x * 64;
+    if (k0 >= kext) return;
     trace_stamp(0); trace_note(6, 11);
-    __shared__ float dys[LB_ROWS * 32];
-    const int tid = threadIdx.x;
-    const int k = blockIdx.x * 256 + tid;
+    __shared__ float dys[LB_SUPER * LB_DP];
+    __shared__ __attribute__((aligned(16))) float coef[64 * 4];       // per local feature: mean, gamma*rstd, beta, rstd
+    __shared__ float tr[2 * 4 * 64 + 256];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M0 = a.w[0] ? a.M[0] : 0, M1 = a.w[1] ? a.M[1] : 0;
     const bool bn = a.a.mode != MPNN_ACT_IDENTITY;
-    float cm = 0.f, ca = 1.f, cb = 0.f, crs = 0.f;
-    if (bn && k < K) { const BnC c = bn_coef(a.a, k % C); cm = c.m; ca = c.gamma * c.rstd; cb = c.beta; crs = c.rstd; }
     const bool fuse_bn = a.dz_out != nullptr && bn;          // uniform: fused mpnn_bn_bwd_reduce
-    float r1 = 0.f, r2 = 0.f;                                // sum dz, sum dz * xhat of this thread's feature
-    float w[32], acc[32];
+    const int fl = wid * 16 + li, f = k0 + fl;               // this lane's feature
+    // ---- one memory round trip for everything read before the arithmetic ----
+    constexpr int DY_PT = LB_SUPER * 32 / 256;
+    float xv[LB_NP][4], dyr[DY_PT];
+    auto load_super = [&](int R0) {
+        const int nr = min(LB_SUPER, a.n - R0);
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        w[m] = (k < kext && m < M0 && (k < K || a.extra_col[0])) ? a.w[0][(size_t)k * M0 + m] : 0.f;
-        w[16 + m] = (k < kext && m < M1 && (k < K || a.extra_col[1])) ? a.w[1][(size_t)k * M1 + m] : 0.f;
-        acc[m] = 0.f; acc[16 + m] = 0.f;
-    }
-    trace_stamp(1);
-    float dbs = 0.f;
-    // blockIdx.z owns rows [z*LB_ROWS, ...) with stride gridDim.z*LB_ROWS: four times the workgroups,
-    // a quarter of the serial row loop; dW/db are then ADDED into the (zeroed) gradient tensors.
-    for (int r0 = blockIdx.z * LB_ROWS; r0 < a.n; r0 += gridDim.z * LB_ROWS) {
-        const int nr = min(LB_ROWS, a.n - r0);
-        __syncthreads();
-        for (int i = tid; i < LB_ROWS * 32; i += 256) {
-            const int rr = i >> 5, col = i & 31, s = col >> 4, m = col & 15;
+        for (int q = 0; q < DY_PT; ++q) {
+            const int i = tid + q * 256, rr = i >> 5, col = i & 31, s = col >> 4, m = col & 15;
             const int M = s ? M1 : M0;
-            dys[i] = (rr < nr && m < M) ? a.dy[s][(size_t)(r0 + rr) * M + m] : 0.f;
+            const bool ok = rr < nr && m < M;
+            dyr[q] = a.dy[s] ? a.dy[s][ok ? (size_t)(R0 + rr) * M + m : 0] : 0.f;
+            dyr[q] = ok ? dyr[q] : 0.f;
         }
+#pragma unroll
+        for (int p = 0; p < LB_NP; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = LB_ROWS * p + 4 * g + q;
+                const bool okx = rr < nr && f < K, oke = rr < nr && f == K && has_extra;
+                float v = a.a.x[okx ? (size_t)(R0 + rr) * K + f : 0];
+                if (has_extra) { const float e = a.k_cpt[oke ? R0 + rr : 0]; v = oke ? a.alpha_cpt * e : v; }
+                xv[p][q] = (okx || oke) ? v : 0.f;
+            }
+    };
+    load_super(0);
+    if (tid < 64) {
+        f32x4 cf = {0.f, 1.f, 0.f, 0.f};
+        if (bn && k0 + tid < K) { const BnC c = bn_coef(a.a, (k0 + tid) % C); cf[0] = c.m; cf[1] = c.gamma * c.rstd; cf[2] = c.beta; cf[3] = c.rstd; }
+        ((f32x4 *)coef)[tid] = cf;
+    }
+    // W in B-operand layout: wv[s] = W_set[f][4 (s & 3) + g], set = s >> 2
+    float wv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int set = s >> 2, m = 4 * (s & 3) + g, M = set ? M1 : M0;
+        const bool ok = m < M && (f < K || (f == K && a.extra_col[set]));
+        const float v = a.w[set] ? a.w[set][ok ? (size_t)f * M + m : 0] : 0.f;
+        wv[s] = ok ? v : 0.f;
+    }
+    f32x4 accW[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float r1 = 0.f, r2 = 0.f;                               // sum dz, sum dz * xhat over this lane's rows
+    float dbs = 0.f;
+    trace_stamp(1);
+    for (int R0 = 0; R0 < a.n; R0 += LB_SUPER) {
+        const int nr = min(LB_SUPER, a.n - R0);
+        if (R0) load_super(R0);
         __syncthreads();
-        if (blockIdx.x == 0 && tid < 32)
-            for (int rr = 0; rr < nr; ++rr) dbs += dys[rr * 32 + tid];
-        if (k >= kext) continue;
-        for (int rb = 0; rb < nr; rb += 16) {
-            float xv[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {             // 16 independent loads in flight
-                const int rr = rb + u;
-                xv[u] = 0.f;
-                if (rr < nr) xv[u] = k < K ? a.a.x[(size_t)(r0 + rr) * K + k] : a.alpha_cpt * a.k_cpt[r0 + rr];
+        for (int q = 0; q < DY_PT; ++q) { const int i = tid + q * 256; dys[(i >> 5) * LB_DP + (i & 31)] = dyr[q]; }
+        __syncthreads();
+        if (blockIdx.x == 0) {                               // db: eight row groups of 32 columns, fixed order
+            const int col = tid & 31, rg = tid >> 5;
+            float t = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < LB_SUPER / 8; ++rr) t += dys[(rg * (LB_SUPER / 8) + rr) * LB_DP + col];   // (rows >= nr are zero)
+            dbs += t;
+        }
+        const f32x4 c = ((const f32x4 *)coef)[fl];
+        // LB_GP passes at a time: their LDS reads, MFMA chains (independent across passes) and stores overlap
+        // (one pass at a time was a serial chain of LDS wait -> 8 dependent MFMAs -> drain -> stores: 1 us each)
+#pragma unroll
+        for (int pg = 0; pg < LB_NP; pg += LB_GP) {
+            if (LB_ROWS * pg >= nr) break;                     // (uniform; rows >= nr are zero in LDS, masked below)
+            float ady[LB_GP][8], bdy[LB_GP][2][4];
+#pragma unroll
+            for (int pp = 0; pp < LB_GP; ++pp) {
+                const int p = pg + pp;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) ady[pp][s] = dys[(LB_ROWS * p + li) * LB_DP + 4 * s + g];              // dY[r = li][m = 4s + g]
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bdy[pp][mt][s] = dys[(LB_ROWS * p + 4 * g + s) * LB_DP + 16 * mt + li];   // dY[r = 4g + s][m]
+            }
+            float xa[LB_GP][4], xh[LB_GP][4];
+            f32x4 dx[LB_GP];
+#pragma unroll
+            for (int pp = 0; pp < LB_GP; ++pp) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xc = xv[pg + pp][q] - c[0];
+                    xa[pp][q] = (bn && f < K) ? fmaxf(xc * c[1] + c[2], 0.f) : xv[pg + pp][q];
+                    xh[pp][q] = xc * c[3];
+                }
+                dx[pp] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int rr = rb + u;
-                if (rr >= nr) continue;            // (no `break`: the loop must stay fully unrolled)
-                float x = xv[u];
-                const float xc = x - cm;
-                if (bn && k < K) x = fmaxf(xc * ca + cb, 0.f);
-                const f32x4 *d4 = (const f32x4 *)(dys + rr * 32);
-                float dx = 0.f;
+            for (int s = 0; s < 8; ++s)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const f32x4 d = d4[q];
+                for (int pp = 0; pp < LB_GP; ++pp) dx[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ady[pp][s], wv[s], dx[pp], 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { acc[q * 4 + j] += x * d[j]; dx += d[j] * w[q * 4 + j]; }
+            for (int pp = 0; pp < LB_GP; ++pp)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    accW[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[pp][s], bdy[pp][0][s], accW[0], 0, 0, 0);
+                    accW[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[pp][s], bdy[pp][1][s], accW[1], 0, 0, 0);
                 }
-                if (a.dx && k < K) a.dx[(size_t)(r0 + rr) * K + k] = dx;
-                if (fuse_bn && k < K) {
-                    const float dz = x > 0.f ? dx : 0.f;
-                    a.dz_out[(size_t)(r0 + rr) * K + k] = dz;
-                    r1 += dz; r2 += dz * (xc * crs);
+            mfma_drain();
+#pragma unroll
+            for (int pp = 0; pp < LB_GP; ++pp)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rr = LB_ROWS * (pg + pp) + 4 * g + q;
+                    if (rr < nr && f < K) {
+                        if (a.dx) a.dx[(size_t)(R0 + rr) * K + f] = dx[pp][q];
+                        if (fuse_bn) {
+                            const float dz = xa[pp][q] > 0.f ? dx[pp][q] : 0.f;
+                            a.dz_out[(size_t)(R0 + rr) * K + f] = dz;
+                            r1 += dz; r2 += dz * xh[pp][q];
+                        }
+                    }
                 }
-            }
         }
     }
-    // dW block of this workgroup = rows [k0, k0+256) of a [K(+1)][M] tensor: contiguous in memory.
-    // Transpose the per-thread rows through LDS so every atomic wave-instruction adds 256 contiguous
-    // bytes (one lane per row would put 64 lanes in 64 different 64-B segments: ~17x slower).
     trace_stamp(4);
-    __shared__ float tr[256 * 17];
+    // dW tile of a set: lane holds rows 4g..4g+3 of the wave's 16 features, column li
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        if (!a.w[s] || !a.dw[s]) continue;          // uniform
-        const int M = a.M[s];
-        const int krows = a.extra_col[s] ? K + 1 : K;
-        __syncthreads();
+    for (int set = 0; set < 2; ++set) {
+        if (!a.w[set] || !a.dw[set]) continue;          // uniform
+        const int M = a.M[set];
+        const int krows = a.extra_col[set] ? K + 1 : K;
+        if (li < M) {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) tr[tid * 17 + m] = acc[s * 16 + m];
-        __syncthreads();
-        const int k0 = blockIdx.x * 256;
-        const int rows = min(256, krows - k0);
-        float *dst = a.dw[s] + (size_t)k0 * M;
-        for (int i = tid; i < rows * M; i += 256) {
-            const int kk = i / M, m = i - kk * M;
-            atomicAdd(dst + i, tr[kk * 17 + m]);
+            for (int q = 0; q < 4; ++q) {
+                const int fr = k0 + wid * 16 + 4 * g + q;
+                if (fr < krows) a.dw[set][(size_t)fr * M + li] = accW[set][q];
+            }
         }
     }
-    if (blockIdx.x == 0 && tid < 32) {
-        const int s = tid >> 4, m = tid & 15;
-        if (a.w[s] && a.db[s] && m < a.M[s]) atomicAdd(a.db[s] + m, dbs);
+    if (blockIdx.x == 0) {
+        float *dbp = tr + 512;
+        dbp[tid] = dbs;
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 8; ++rg) t += dbp[rg * 32 + tid];
+            const int s = tid >> 4, m = tid & 15;
+            if (a.w[s] && a.db[s] && m < a.M[s]) a.db[s][m] = t;
+        }
     }
-    // fused BatchNorm-backward reductions: feature k = pixel * C + c; the workgroup's 256 features are
-    // 256 / C pixels of all C channels (C | 256) or a 256-channel slice of one pixel
+    // fused BatchNorm-backward reductions: feature k = pixel * C + c; the workgroup's 64 features are
+    // 64 / C pixels of all C channels (C | 64) or a 64-channel slice of one pixel
     if (fuse_bn) {
+        tr[g * 64 + fl] = r1; tr[256 + g * 64 + fl] = r2;
         __syncthreads();
-        tr[tid] = r1; tr[256 + tid] = r2;
+        float f1 = 0.f, f2 = 0.f;
+        if (tid < 64) {
+            f1 = (tr[tid] + tr[64 + tid]) + (tr[128 + tid] + tr[192 + tid]);
+            f2 = (tr[256 + tid] + tr[320 + tid]) + (tr[384 + tid] + tr[448 + tid]);
+        }
         __syncthreads();
-        const int k0 = blockIdx.x * 256;
-        const int span = C < 256 ? C : 256;                  // distinct channels in this workgroup
+        if (tid < 64) { tr[tid] = f1; tr[64 + tid] = f2; }
+        __syncthreads();
+        const int span = C < 64 ? C : 64;                    // distinct channels in this workgroup
         if (tid < span && k0 + tid < K) {
             double a1 = 0.0, a2 = 0.0;
-            for (int t = tid; t < 256 && k0 + t < K; t += span) { a1 += (double)tr[t]; a2 += (double)tr[256 + t]; }
+            for (int t = tid; t < 64 && k0 + t < K; t += span) { a1 += (double)tr[t]; a2 += (double)tr[64 + t]; }
             const int c = (k0 + tid) % C;
-            double *slot = a.red_out + (size_t)((blockIdx.x + blockIdx.z * gridDim.x) % a.red_nslot) * 2 * C;
+            double *slot = a.red_out + (size_t)(blockIdx.x % a.red_nslot) * 2 * C;
             atomicAdd(slot + c, a1);
             atomicAdd(slot + C + c, a2);
         }
@@ -239,10 +325,7 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
 extern "C" int mpnn_lin_bwd(const mpnn_lin_bwd_args *dev_table, int count, int n_max, int k_max, void *stream) {
     if (count <= 0 || n_max <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    int zsplit = (n_max + LB_ROWS - 1) / LB_ROWS;              // one pass of LB_ROWS rows per workgroup
-    if (zsplit > 16) zsplit = 16;
-    hipLaunchKernelGGL(lin_bwd_k, dim3((k_max + 1 + 255) / 256, count, zsplit), dim3(256), 0, (hipStream_t)stream,
-                       dev_table);
+    hipLaunchKernelGGL(lin_bwd_k, dim3((k_max + 1 + 63) / 64, count), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

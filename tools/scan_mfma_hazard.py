@@ -6,8 +6,8 @@ hazard by counting ANY instruction between the two as a wait state.  On MI355X a
 instructions (the branch conditions of a persistent loop) does not take that long, and the
 accumulator register written last by the last MFMA was read stale.  The kernels therefore end every
 MFMA block with mfma_drain() (an explicit s_nop 15); this script checks, in text order, that between
-each v_mfma and the next v_accvgpr_read/v_accvgpr_mov there is an s_nop or >= 11 vector
-instructions.
+each v_accvgpr_read/v_accvgpr_mov and the LAST MFMA THAT WROTE THE REGISTER IT READS there is an s_nop
+or >= 11 vector-instruction slots (an MFMA in between counts as 8).
 
     python tools/scan_mfma_hazard.py            # compiles csrc/*.hip to ISA with hipcc -S
 """
@@ -18,29 +18,40 @@ CSRC = os.path.join(ROOT, 'multipath-nn_amd', 'csrc')
 
 
 def scan(asm_path):
-    kern, last, sites = None, None, []
-    n_valu = n_salu = 0
-    nop = False
+    """[(kernel, line, vector instructions since the write, SALU since the write)] for every accumulator
+    read whose LAST WRITING MFMA is closer than 11 vector-instruction slots with no s_nop in between
+    (another MFMA in between counts as 8 slots: it occupies the pipe for at least 8 passes)."""
+    import re
+    kern, sites = None, []
+    writes = {}                      # accumulator register -> (valu, salu, nops) counters at its last MFMA write
+    valu = salu = nops = 0
+    dst = re.compile(r'^v_mfma\S*\s+a\[(\d+):(\d+)\]')
     for ln, raw in enumerate(open(asm_path), 1):
         t = raw.strip()
         if t.startswith('_Z') and ':' in t and ' ' not in t.split(':')[0]:
-            kern, last = t.split(':')[0], None
+            kern, writes = t.split(':')[0], {}
         if not t or t[0] in ';.' or t.endswith(':'):
             continue
         op = t.split()[0]
         if op.startswith('v_mfma'):
-            last, n_valu, n_salu, nop = ln, 0, 0, False
-        elif last is not None:
-            if op.startswith('v_accvgpr_read') or op.startswith('v_accvgpr_mov'):
-                if not nop and n_valu < 11:
-                    sites.append((kern, ln, n_valu, n_salu))
-                last = None
-            elif op == 's_nop':
-                nop = True
-            elif op.startswith('s_'):
-                n_salu += 1
-            else:
-                n_valu += 1
+            valu += 8
+            m = dst.match(t)
+            if m:
+                for r in range(int(m.group(1)), int(m.group(2)) + 1):
+                    writes[r] = (valu, salu, nops)
+        elif op.startswith('v_accvgpr_read') or op.startswith('v_accvgpr_mov'):
+            m = re.search(r'\ba(\d+)\b', t.split(',', 1)[1] if ',' in t else '')
+            if m and int(m.group(1)) in writes:
+                v0, s0, n0 = writes[int(m.group(1))]
+                if nops == n0 and valu - v0 < 11:
+                    sites.append((kern, ln, valu - v0, salu - s0))
+            valu += 1
+        elif op == 's_nop':
+            nops += 1
+        elif op.startswith('s_'):
+            salu += 1
+        else:
+            valu += 1
     return sites
 
 
