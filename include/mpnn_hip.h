@@ -213,9 +213,10 @@ int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *horz, const mpnn_dgrad_ver
 /* Number of 64-pixel tiles (upper bound of n_split) for a map, or MPNN_E_SHAPE. */
 int mpnn_wgrad_tiles(int n, int H, int W);
 /* dst[i] = sum_{s<n_split} src[s*stride + i].  table: 6 ints per work item:
- * src_off (floats in `slabs`), dst_off (floats in `grads`), count (<= 256),
- * n_split, stride, reserved.  One workgroup per item; a count above 256 is MPNN_E_ARG-free
+ * src_off (floats in `slabs`), dst_off (floats in `grads`), count (<= MPNN_SLAB_ITEM),
+ * n_split, stride, reserved.  One workgroup per item; a larger count is MPNN_E_ARG-free
  * undefined behaviour, so split larger tensors into several items. */
+#define MPNN_SLAB_ITEM 1024
 int mpnn_slab_reduce(const float *slabs, float *grads, const int *table, int n_items,
                      void *stream);
 

@@ -430,51 +430,62 @@ extern "C" int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *h, const mpnn_d
 
 // ---------------------------------------------------------------------------
 // mpnn_slab_reduce: dst[i] = sum_{s < n_split} src[s * stride + i], in a fixed order.
-// table: 6 ints per work item: src_off, dst_off, count (<= 256), n_split, stride, -.
-// One workgroup per item: lane l of every wave owns elements [4l, 4l+4); the four waves each sum a
-// contiguous quarter of the slabs (8 loads in flight), and the quarters are combined through LDS in
-// wave order -- the serial chain is n_split / 32 round trips instead of n_split / 8.
+// table: 6 ints per work item: src_off, dst_off, count (<= MPNN_SLAB_ITEM = 1024), n_split, stride, -.
+// One workgroup per item.  Its 256 threads are (element quad q, slab group grp): the item's count / 4
+// quads times as many groups G (a power of two, <= 16) as fit; group grp sums slabs grp, grp + G, ...
+// with sixteen 16-byte loads in flight, and the groups' partial sums meet in LDS in group order.  The
+// caller sizes the items so that n_split / G <= 16 -- ONE memory round trip per workgroup whatever the
+// split (1024 elements at a split of 16 or less, 64 elements at 256): few, full workgroups for the big
+// tensors of the deep blocks, slab-parallel ones for the small tensors with hundreds of slabs.
+// (History: fixed 256-element items, slabs dealt to the four waves: 6 500 workgroups of two loads per
+// thread for the chains -- latency, not bandwidth: 2 TB/s.)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void slab_item(const float *__restrict__ slabs, float *__restrict__ grads, const int *__restrict__ t) {
     const int src = t[0], dst = t[1], cnt = t[2], ns = t[3], stride = t[4];
-    __shared__ f32x4 part[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = lane * 4;
-    const int per = (ns + 3) >> 2, s0 = w * per, s1 = min(ns, s0 + per);
+    __shared__ f32x4 part[256];
+    const int quads = (cnt + 3) >> 2;
+    int G = 1;
+    while (G < 16 && 2 * G * quads <= 256) G *= 2;              // uniform
+    const int tid = threadIdx.x, grp = tid / quads, q = tid - grp * quads;
+    const int i = q * 4;
+    const bool on_t = grp < G;
     const bool vec = ((src | stride | dst) & 3) == 0;          // uniform
     f32x4 tot = {0.f, 0.f, 0.f, 0.f};
-    if (i < cnt) {
+    if (on_t) {
         if (vec && i + 4 <= cnt) {
             const float *base = slabs + src + i;
             f32x4 a[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            int sl = s0;
-            for (; sl + 16 <= s1; sl += 16) {
+            for (int sl = grp; sl < ns; sl += 16 * G) {        // (one trip when the caller sized the item)
 #pragma unroll
-                for (int u = 0; u < 16; ++u) a[u] += *(const f32x4 *)(base + (size_t)(sl + u) * stride);
+                for (int u = 0; u < 16; ++u) {
+                    const int s_ = sl + u * G;
+                    const bool on = s_ < ns;
+                    const f32x4 v = *(const f32x4 *)(base + (size_t)(on ? s_ : grp) * stride);
+                    a[u] += on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
-            for (; sl + 4 <= s1; sl += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] += *(const f32x4 *)(base + (size_t)(sl + u) * stride);
-            }
-            for (; sl < s1; ++sl) a[0] += *(const f32x4 *)(base + (size_t)sl * stride);
             tot = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
                   (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
         } else {
             for (int j = 0; j < 4 && i + j < cnt; ++j) {
                 float acc = 0.f;
-                for (int sl = s0; sl < s1; ++sl) acc += slabs[src + (size_t)sl * stride + i + j];
+                for (int sl = grp; sl < ns; sl += G) acc += slabs[src + (size_t)sl * stride + i + j];
                 tot[j] = acc;
             }
         }
     }
-    part[w][lane] = tot;
-    __syncthreads();
-    if (w == 0 && i < cnt) {
-        const f32x4 r = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-        if (vec && i + 4 <= cnt) *(f32x4 *)(grads + dst + i) = r;
-        else for (int j = 0; j < 4 && i + j < cnt; ++j) grads[dst + i + j] = r[j];
+    if (G > 1) {                                                // uniform
+        part[tid] = tot;
+        __syncthreads();
+        if (grp == 0) {
+            for (int k = 1; k < G; ++k) tot += part[k * quads + q];
+        }
+    }
+    if (on_t && grp == 0) {
+        if (vec && i + 4 <= cnt) *(f32x4 *)(grads + dst + i) = tot;
+        else for (int j = 0; j < 4 && i + j < cnt; ++j) grads[dst + i + j] = tot[j];
     }
 }
 

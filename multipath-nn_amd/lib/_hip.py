@@ -15,6 +15,17 @@ HYP_LR, HYP_MU, HYP_TAU, HYP_EPS, HYP_KCPT, HYP_KDEC, HYP_KCRE, HYP_ARTR, HYP_N 
 MAX_NODES, MAX_SINKS = 128, 4
 BN_SLOTS = 16                  # MPNN_BN_SLOTS
 SEG_INTS = 12                  # MPNN_SEG_INTS
+SLAB_ITEM = 1024               # MPNN_SLAB_ITEM: elements per mpnn_slab_reduce work item
+
+
+def slab_item_size(n_split):
+    """Elements per mpnn_slab_reduce item for a tensor summed over n_split slabs: the largest for which
+    the kernel's slab groups (256 threads / (item / 4) quads, at most 16) leave every thread <= 16 slabs,
+    i.e. one batch of loads: 1024 up to a split of 16, 64 at 256 and beyond."""
+    size = SLAB_ITEM
+    while size > 64 and (256 // (size // 4)) * 16 < n_split:
+        size //= 2
+    return size
 
 P = C.c_void_p
 

@@ -792,8 +792,9 @@ class Engine:
                     for prm, sz in zip((pa, pv, pb), sizes):
                         if prm is None:
                             continue
-                        for k in range(0, sz, 256):
-                            slab_plan['table'] += [off + k, prm.offset + k, min(256, sz - k), split, stride, 0]
+                        item = _hip.slab_item_size(split)
+                        for k in range(0, sz, item):
+                            slab_plan['table'] += [off + k, prm.offset + k, min(item, sz - k), split, stride, 0]
                         slab_plan['ptrs'].append((a, {id(pa): 'dwa', id(pb): 'db'}.get(id(prm), 'dwv'), off))
                         off += sz
                     a.split_stride = stride

@@ -302,8 +302,9 @@ class ConvEngine:
             if supp == 3 and split > 1:
                 tab = []
                 for prm, o in ((pw, 0), (pb, pw.size)):
-                    for j in range(0, prm.size, 256):
-                        tab += [o + j, prm.offset + j, min(256, prm.size - j), split, stride, 0]
+                    item = _hip.slab_item_size(split)
+                    for j in range(0, prm.size, item):
+                        tab += [o + j, prm.offset + j, min(item, prm.size - j), split, stride, 0]
                 t = torch.tensor(tab, dtype=torch.int32, device=self.dev)
                 keep.append(t)
                 self._chk(lib.mpnn_slab_reduce(self.slab.data_ptr(), self.G.data_ptr(), t.data_ptr(), len(tab) // 6, st), 'slab_reduce')

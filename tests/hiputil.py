@@ -186,8 +186,9 @@ def wgrad(x, g, v=None, bn=None, mode=_hip.ACT_IDENTITY, shift=0, bn_cnt=1, n_sp
     if n_split > 1:
         tab = []
         for o, sz in zip(offs, sizes):
-            for k in range(0, sz, 256):
-                tab += [o + k, o + k, min(256, sz - k), n_split, stride, 0]
+            item = _hip.slab_item_size(n_split)
+            for k in range(0, sz, item):
+                tab += [o + k, o + k, min(item, sz - k), n_split, stride, 0]
         t = dev(np.array(tab, np.int32), torch.int32)
         _hip.check(lib.mpnn_slab_reduce(slab.data_ptr(), grads.data_ptr(), t.data_ptr(), len(tab) // 6, stream()),
                    'slab_reduce')
