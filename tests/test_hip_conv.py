@@ -252,6 +252,43 @@ def test_step_begin_packs_and_clears():
                                arena[1:].data_ptr(), 64, U.stream()) == _hip.E_ARG
 
 
+@pytest.mark.parametrize('split', [1, 3, 16, 17, 40, 256, 515])
+def test_slab_reduce_items_and_groups(split):
+    """mpnn_slab_reduce against a float64 sum for every item size / slab-group count the planner can
+    produce (`_hip.slab_item_size`), ragged last items, a tensor whose offset is not 16-byte aligned
+    (scalar path) and a deliberately oversized item (more than 16 slabs per thread: the kernel's loop)."""
+    import torch
+    import hiputil as U
+    from lib import _hip
+    lib = _hip.load()
+    rng = np.random.default_rng(split)
+    sizes = [1024 * 3 + 20, 433, 7, 64]
+    stride = (sum(sizes) + 5 + 3) // 4 * 4
+    slab = torch.tensor(rng.standard_normal(split * stride).astype(np.float32), device=U.DEV)
+    grads = torch.full((stride,), 7.0, device=U.DEV)
+    tab, off, want = [], 0, []
+    for ti, sz in enumerate(sizes):
+        if ti == 2:
+            off += 1                                   # misaligned tensor: the scalar path
+        item = _hip.slab_item_size(split) if ti != 3 else 64
+        for k in range(0, sz, item):
+            tab += [off + k, off + k, min(item, sz - k), split, stride, 0]
+        want.append((off, sz))
+        off += sz
+    tab += [0, want[0][0], 1024, split, stride, 0]     # item 0 again as a full-size item whatever the split
+    t = torch.tensor(tab, dtype=torch.int32, device=U.DEV)
+    _hip.check(lib.mpnn_slab_reduce(slab.data_ptr(), grads.data_ptr(), t.data_ptr(), len(tab) // 6, U.stream()), 'slab_reduce')
+    torch.cuda.synchronize()
+    ref = slab.cpu().numpy().astype(np.float64).reshape(split, stride).sum(0)
+    got = grads.cpu().numpy()
+    for o, sz in want:
+        assert np.abs(got[o:o + sz] - ref[o:o + sz]).max() <= 2e-6 * np.sqrt(split) * (1 + np.abs(ref[o:o + sz]).max()), (split, o, sz)
+    untouched = np.ones(stride, bool)
+    for o, sz in want:
+        untouched[o:o + sz] = False
+    assert (got[untouched] == 7.0).all()
+
+
 def test_bwd_scale_slots_query():
     from lib import _hip
     import torch

@@ -160,3 +160,19 @@ def test_isa_has_no_uncovered_mfma_result_reads():
                                   cwd=S.CSRC, stderr=subprocess.DEVNULL)
             bad += [(name,) + site for site in S.scan(out)]
     assert not bad, bad[:5]
+
+
+def test_slab_item_size_keeps_one_load_batch_per_thread():
+    """The planner's item size for mpnn_slab_reduce: a power of two in [64, MPNN_SLAB_ITEM] such that the
+    kernel's slab groups (256 threads / (item / 4) element quads, at most 16) leave a thread <= 16 slabs
+    wherever that is possible at all (up to 256 slabs)."""
+    from lib import _hip
+    for split in list(range(1, 70)) + [127, 128, 129, 255, 256]:
+        item = _hip.slab_item_size(split)
+        assert 64 <= item <= _hip.SLAB_ITEM and item & (item - 1) == 0
+        groups = min(16, 256 // (item // 4))
+        assert -(-split // groups) <= 16, (split, item, groups)
+        if item < _hip.SLAB_ITEM:                      # never smaller than necessary
+            g2 = min(16, 256 // (2 * item // 4))
+            assert -(-split // g2) > 16, (split, item)
+    assert _hip.slab_item_size(4096) == 64
