@@ -530,7 +530,28 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     // before the tables was measured slower: memory returns in order, so the table loads queue behind
     // the tile loads and nothing is saved, while the registers stay live across the table code.)
     UI cu = {}, n1 = {}, n2 = {};
-    if (EPI == EPI_FWD && p.a.mode != MPNN_ACT_IDENTITY) {
+    // Forward, batch statistics: the slot array (nslot x 2C doubles, contiguous) is REQUESTED here, spread
+    // over all threads (<= TABQ loads each), and only summed after the first two units' loads have been
+    // issued -- the coefficient round trip and the tile round trip overlap instead of following each other.
+    // Same summation order as bn_coef (slots ascending), so the coefficients are bit-identical.
+#ifndef MPNN_LATE_TAB
+#define MPNN_LATE_TAB 1
+#endif
+    constexpr int TABQ = 8;
+    [[maybe_unused]] double tabq[TABQ];
+    [[maybe_unused]] float tab_g = 1.f, tab_b = 0.f;
+    bool tab_late = false;
+    if constexpr (EPI == EPI_FWD) {
+        const int tot = p.a.nslot * 2 * p.a.C;
+        tab_late = MPNN_LATE_TAB && p.a.mode == MPNN_ACT_BN_BATCH && tot <= TABQ * 256 && p.a.C <= 256;     // (uniform)
+        if (tab_late) {
+#pragma unroll
+            for (int j = 0; j < TABQ; ++j) { const int k = tid + 256 * j; tabq[j] = p.a.sum[k < tot ? k : 0]; }
+            const int c = tid < p.a.C ? tid : 0;
+            tab_g = p.a.gamma[c]; tab_b = p.a.beta[c];
+        }
+    }
+    if (EPI == EPI_FWD && p.a.mode != MPNN_ACT_IDENTITY && !tab_late) {
         for (int c = tid; c < p.a.C; c += 256) {
             const BnC k = bn_coef(p.a, c);
             cA[c * 3] = k.m; cA[c * 3 + 1] = k.gamma * k.rstd; cA[c * 3 + 2] = k.beta;
@@ -561,7 +582,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             }
         }
     }
-    __syncthreads();
+    if (!tab_late) __syncthreads();
     trace_stamp(1);
     gen_tile(gen, bx);
     cu = gen;
@@ -570,6 +591,25 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         gen_next(gen);
         n1 = gen;
         unit_load(n1, xrB, brB);
+    }
+    if constexpr (EPI == EPI_FWD) {
+        if (tab_late) {
+            // (the slot values are older than the tile loads: the wait below is vmcnt(tile loads), not 0)
+            double *scr = (double *)smem;            // the tile / weight buffers are not in use yet
+            const int C = p.a.C, tot = p.a.nslot * 2 * C;
+#pragma unroll
+            for (int j = 0; j < TABQ; ++j) { const int k = tid + 256 * j; if (k < tot) scr[k] = tabq[j]; }
+            __syncthreads();
+            if (tid < C) {
+                double s1 = 0.0, s2 = 0.0;
+                for (int sl = 0; sl < p.a.nslot; ++sl) { s1 += scr[(2 * sl) * C + tid]; s2 += scr[(2 * sl + 1) * C + tid]; }
+                const double inv = 1.0 / (double)p.a.cnt, mean = s1 * inv;
+                double var = s2 * inv - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                cA[tid * 3] = (float)mean; cA[tid * 3 + 1] = tab_g * rsqrtf((float)var + p.a.eps); cA[tid * 3 + 2] = tab_b;
+            }
+            __syncthreads();
+        }
     }
     if (n_units > 0) unit_store(cu, xrA, brA, 0, true);
     __syncthreads();
