@@ -13,7 +13,9 @@
 // 16 samples x 16 outputs per MFMA tile; waves split K, partial tiles meet in LDS.
 #define LF_WAVES 16
 __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_args *__restrict__ tab) {
-    const mpnn_lin_fwd_args &a = tab[blockIdx.y];      // (by reference: w[] / b[] are indexed at run time, a copy would live in scratch)
+    // (by value: every field's scalar load sits in the entry block, one round trip.  The two-element arrays are
+    // only ever indexed by CONSTANTS below -- a run-time index would put the copy in scratch memory: +4 us)
+    const mpnn_lin_fwd_args a = tab[blockIdx.y];
     const int n0 = blockIdx.x * 16;
     if (n0 >= a.n) return;
     trace_stamp(0); trace_note(6, 10);
@@ -46,8 +48,8 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
         ep_row = n0 + (l >> 4) * 4 + r; ep_col = l & 15;
         ep_on = ep_M > 0 && ep_row < a.n && ep_col < ep_M;
         if (ep_on) {
-            ep_bias = a.b[ep_s][ep_col];
-            if (a.extra_col[ep_s]) ep_extra = a.alpha_cpt * a.k_cpt[ep_row] * a.w[ep_s][(size_t)K * ep_M + ep_col];
+            ep_bias = (ep_s ? a.b[1] : a.b[0])[ep_col];
+            if (ep_s ? a.extra_col[1] : a.extra_col[0]) ep_extra = a.alpha_cpt * a.k_cpt[ep_row] * (ep_s ? a.w[1] : a.w[0])[(size_t)K * ep_M + ep_col];
         }
     }
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
         float v = ep_bias;
 #pragma unroll
         for (int w = 0; w < LF_WAVES; ++w) v += red[(w * 2 + ep_s) * 256 + e];
-        a.y[ep_s][(size_t)ep_row * ep_M + ep_col] = v + ep_extra;
+        (ep_s ? a.y[1] : a.y[0])[(size_t)ep_row * ep_M + ep_col] = v + ep_extra;
     }
     trace_stamp(5);
 }
@@ -139,7 +141,7 @@ extern "C" int mpnn_lin_fwd(const mpnn_lin_fwd_args *dev_table, int count, int n
 #define LB_GP 4             // passes in flight together
 #define LB_DP 36            // LDS pitch of a dY row: 4 * 36 = 16 (mod 32) -> the dW operand reads are conflict-free
 __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__restrict__ tab) {
-    const mpnn_lin_bwd_args &a = tab[blockIdx.y];      // (by reference: w[] / dy[] are indexed at run time, a copy would live in scratch)
+    const mpnn_lin_bwd_args &a = tab[blockIdx.y];      // (by reference: a copy needs more SGPRs than there are -- 254 spills, +1.2 us)
     const int C = a.a.C, K = a.HW * C;
     const bool has_extra = a.extra_col[0] || a.extra_col[1];
     const int kext = K + (has_extra ? 1 : 0);
@@ -165,7 +167,8 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
             const int i = tid + q * 256, rr = i >> 5, col = i & 31, s = col >> 4, m = col & 15;
             const int M = s ? M1 : M0;
             const bool ok = rr < nr && m < M;
-            dyr[q] = a.dy[s] ? a.dy[s][ok ? (size_t)(R0 + rr) * M + m : 0] : 0.f;
+            const float *dyp = s ? a.dy[1] : a.dy[0];
+            dyr[q] = dyp ? dyp[ok ? (size_t)(R0 + rr) * M + m : 0] : 0.f;
             dyr[q] = ok ? dyr[q] : 0.f;
         }
 #pragma unroll
@@ -190,8 +193,9 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int set = s >> 2, m = 4 * (s & 3) + g, M = set ? M1 : M0;
-        const bool ok = m < M && (f < K || (f == K && a.extra_col[set]));
-        const float v = a.w[set] ? a.w[set][ok ? (size_t)f * M + m : 0] : 0.f;
+        const float *wp = set ? a.w[1] : a.w[0];
+        const bool ok = m < M && (f < K || (f == K && (set ? a.extra_col[1] : a.extra_col[0])));
+        const float v = wp ? wp[ok ? (size_t)f * M + m : 0] : 0.f;
         wv[s] = ok ? v : 0.f;
     }
     f32x4 accW[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -273,14 +277,16 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
     // dW tile of a set: lane holds rows 4g..4g+3 of the wave's 16 features, column li
 #pragma unroll
     for (int set = 0; set < 2; ++set) {
-        if (!a.w[set] || !a.dw[set]) continue;          // uniform
-        const int M = a.M[set];
-        const int krows = a.extra_col[set] ? K + 1 : K;
+        const float *wp = set ? a.w[1] : a.w[0];
+        float *dwp = set ? a.dw[1] : a.dw[0];
+        if (!wp || !dwp) continue;                      // uniform
+        const int M = set ? a.M[1] : a.M[0];
+        const int krows = (set ? a.extra_col[1] : a.extra_col[0]) ? K + 1 : K;
         if (li < M) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int fr = k0 + wid * 16 + 4 * g + q;
-                if (fr < krows) a.dw[set][(size_t)fr * M + li] = accW[set][q];
+                if (fr < krows) dwp[(size_t)fr * M + li] = accW[set][q];
             }
         }
     }
@@ -293,7 +299,9 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
 #pragma unroll
             for (int rg = 0; rg < 8; ++rg) t += dbp[rg * 32 + tid];
             const int s = tid >> 4, m = tid & 15;
-            if (a.w[s] && a.db[s] && m < a.M[s]) a.db[s][m] = t;
+            const float *wps = s ? a.w[1] : a.w[0];
+            float *dbp2 = s ? a.db[1] : a.db[0];
+            if (wps && dbp2 && m < (s ? a.M[1] : a.M[0])) dbp2[m] = t;
         }
     }
     // fused BatchNorm-backward reductions: feature k = pixel * C + c; the workgroup's 64 features are
