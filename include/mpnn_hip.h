@@ -263,8 +263,19 @@ typedef struct {
     const float *w[2];  const float *b[2];  float *y[2];  int M[2];   /* M <= 16   */
     const float *k_cpt;  float alpha_cpt;  int extra_col[2];
     int n;
+    /* Scratch of mpnn_lin_fwd_ks (both NULL: the record is never sliced; ignored by mpnn_lin_fwd):
+     *   kpart: ceil(n/16) * MPNN_LIN_KSLICES * 512 floats, any contents
+     *   kcnt : ceil(n/16) ints, ZERO before the first launch (left zero by every launch) */
+    float *kpart;  int *kcnt;
 } mpnn_lin_fwd_args;
+#define MPNN_LIN_KSLICES 8
 int mpnn_lin_fwd(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void *stream);
+/* The same map for SMALL batches (the training step: 8 row groups), K-sliced: a record with scratch and
+ * K >= 512 is split over S = min(MPNN_LIN_KSLICES, K / 256) 256-thread workgroups per 16 rows; each leaves
+ * its partial tile in kpart, and the LAST to arrive (ticket counter kcnt, which it resets) adds the S
+ * partials in slice order -- the result does not depend on which workgroup that is (bit-identical from
+ * launch to launch); it differs from mpnn_lin_fwd's in the last bits (another summation tree). */
+int mpnn_lin_fwd_ks(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void *stream);
 
 typedef struct {
     mpnn_act a;  int HW;

@@ -11,22 +11,35 @@
 
 // ------------------------------- forward ------------------------------------
 // 16 samples x 16 outputs per MFMA tile; waves split K, partial tiles meet in LDS.
-#define LF_WAVES 16
-__global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_args *__restrict__ tab) {
+// LFW waves per workgroup.  16 (mpnn_lin_fwd): one workgroup per 16 rows owns all of K.
+// 4 (mpnn_lin_fwd_ks, small batches): a record with K >= 512 is split over S = min(8, K / 256)
+// workgroups per 16 rows -- the K = 1024 workgroups of the unsliced form pull 170 KB (weights re-read
+// by every row group + activations) through ONE compute unit, 8 us of a 14 us launch.  A slice leaves
+// its partial tile in scratch with write-through (system-scope) stores and takes a ticket; the last to
+// arrive adds the S partials in slice order, so the result does not depend on who that is.  No
+// agent-scope fence anywhere: on this part a release fence writes back the XCD's whole L2 (measured:
+// the launch took 83 us with __threadfence()).  Four waves, not sixteen: the dispatcher starts
+// 240 sixteen-wave workgroups over 7 us.
+template <int LFW, bool SLICED>
+__global__ __launch_bounds__(LFW * 64) void lin_fwd_k(const mpnn_lin_fwd_args *__restrict__ tab) {
     // (by value: every field's scalar load sits in the entry block, one round trip.  The two-element arrays are
     // only ever indexed by CONSTANTS below -- a run-time index would put the copy in scratch memory: +4 us)
-    const mpnn_lin_fwd_args a = tab[blockIdx.y];
+    const mpnn_lin_fwd_args a = tab[SLICED ? blockIdx.y / MPNN_LIN_KSLICES : blockIdx.y];
     const int n0 = blockIdx.x * 16;
     if (n0 >= a.n) return;
+    const int slice = SLICED ? blockIdx.y % MPNN_LIN_KSLICES : 0;
+    const int S = (SLICED && a.kpart && a.kcnt) ? min(MPNN_LIN_KSLICES, max(1, (a.HW * a.a.C) >> 8)) : 1;
+    if (slice >= S) return;
     trace_stamp(0); trace_note(6, 10);
+    constexpr int NT_ = LFW * 64, NO = 512 / (NT_ < 512 ? NT_ : 512);        // outputs per thread: (set, lane, r) = 512
     __shared__ float cA[128 * 3];
-    __shared__ float red[LF_WAVES * 2 * 256];
+    __shared__ float red[LFW * 2 * 256];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = a.a.C, K = a.HW * C;
     const bool bn = a.a.mode != MPNN_ACT_IDENTITY;
     if (bn) {
-        for (int c = tid; c < C; c += LF_WAVES * 64) {
+        for (int c = tid; c < C; c += NT_) {
             const BnC k = bn_coef(a.a, c);
             cA[c * 3] = k.m; cA[c * 3 + 1] = k.gamma * k.rstd; cA[c * 3 + 2] = k.beta;
         }
@@ -38,18 +51,22 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
     const int M0 = a.w[0] ? a.M[0] : 0, M1 = a.w[1] ? a.M[1] : 0;
     // The epilogue's own operands (bias, the dyn_k_cpt column) are requested NOW: loaded where they are
     // used they were one more memory round trip at the very end of the kernel.
-    float ep_bias = 0.f, ep_extra = 0.f;
-    bool ep_on = false;
-    int ep_row = 0, ep_col = 0, ep_M = 0, ep_s = 0;
-    if (tid < 512) {                         // (set, lane, r): 2 * 64 * 4 outputs
-        const int e = tid & 255, l = e >> 2, r = e & 3;
-        ep_s = tid >> 8;
-        ep_M = ep_s ? M1 : M0;
-        ep_row = n0 + (l >> 4) * 4 + r; ep_col = l & 15;
-        ep_on = ep_M > 0 && ep_row < a.n && ep_col < ep_M;
-        if (ep_on) {
-            ep_bias = (ep_s ? a.b[1] : a.b[0])[ep_col];
-            if (ep_s ? a.extra_col[1] : a.extra_col[0]) ep_extra = a.alpha_cpt * a.k_cpt[ep_row] * (ep_s ? a.w[1] : a.w[0])[(size_t)K * ep_M + ep_col];
+    float ep_bias[NO], ep_extra[NO];
+    bool ep_on[NO];
+    int ep_row[NO], ep_col[NO], ep_M[NO], ep_s[NO];
+#pragma unroll
+    for (int q = 0; q < NO; ++q) {
+        const int o = tid + q * NT_;             // (set, lane, r): 2 * 64 * 4 outputs
+        const int e = o & 255, l = e >> 2, r = e & 3;
+        ep_bias[q] = 0.f; ep_extra[q] = 0.f;
+        ep_s[q] = (o >> 8) & 1;
+        ep_M[q] = ep_s[q] ? M1 : M0;
+        ep_row[q] = n0 + (l >> 4) * 4 + r; ep_col[q] = l & 15;
+        ep_on[q] = o < 512 && ep_M[q] > 0 && ep_row[q] < a.n && ep_col[q] < ep_M[q];
+        if (ep_on[q] && S == 1) {               // (sliced: only the last arriver needs them, it loads them then)
+            ep_bias[q] = (ep_s[q] ? a.b[1] : a.b[0])[ep_col[q]];
+            if (ep_s[q] ? a.extra_col[1] : a.extra_col[0])
+                ep_extra[q] = a.alpha_cpt * a.k_cpt[ep_row[q]] * (ep_s[q] ? a.w[1] : a.w[0])[(size_t)K * ep_M[q] + ep_col[q]];
         }
     }
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
@@ -57,9 +74,10 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
     // share is a chain of dependent memory round trips (one per iteration), 8 of them at K = 2048 with
     // one block per iteration -- two with four.
     constexpr int LF_UN = 4;
-    const int nkb = K >> 4;
+    const int nkb_all = K >> 4;
+    const int kb_lo = slice * nkb_all / S, nkb = (slice + 1) * nkb_all / S;      // this workgroup's blocks [kb_lo, nkb)
     const float *xrow = a.a.x + (size_t)(valid ? row : 0) * K;
-    for (int kb = wid * LF_UN; kb < nkb; kb += LF_WAVES * LF_UN) {
+    for (int kb = kb_lo + wid * LF_UN; kb < nkb; kb += LFW * LF_UN) {
         f32x4 x[LF_UN];
         float b0[LF_UN][4], b1[LF_UN][4];
 #pragma unroll
@@ -101,12 +119,51 @@ __global__ __launch_bounds__(LF_WAVES * 64) void lin_fwd_k(const mpnn_lin_fwd_ar
         red[(wid * 2 + 1) * 256 + lane * 4 + r] = acc1[r];
     }
     __syncthreads();
-    if (ep_on) {
-        const int e = tid & 255;
-        float v = ep_bias;
+    float vsum[NO];
 #pragma unroll
-        for (int w = 0; w < LF_WAVES; ++w) v += red[(w * 2 + ep_s) * 256 + e];
-        (ep_s ? a.y[1] : a.y[0])[(size_t)ep_row * ep_M + ep_col] = v + ep_extra;
+    for (int q = 0; q < NO; ++q) {
+        const int o = tid + q * NT_, e = o & 255;
+        float v = 0.f;
+        if (o < 512) {
+#pragma unroll
+            for (int w = 0; w < LFW; ++w) v += red[(w * 2 + ep_s[q]) * 256 + e];
+        }
+        vsum[q] = v;
+    }
+    if (S == 1) {
+#pragma unroll
+        for (int q = 0; q < NO; ++q)
+            if (ep_on[q]) (ep_s[q] ? a.y[1] : a.y[0])[(size_t)ep_row[q] * ep_M[q] + ep_col[q]] = (ep_bias[q] + vsum[q]) + ep_extra[q];
+    } else if constexpr (SLICED) {
+        __shared__ int ticket;
+        float *part = a.kpart + (size_t)blockIdx.x * MPNN_LIN_KSLICES * 512;
+#pragma unroll
+        for (int q = 0; q < NO; ++q) {
+            const int o = tid + q * NT_;
+            if (o < 512) __hip_atomic_store(part + slice * 512 + o, vsum[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (= wait for the stores; see the header comment)
+        __syncthreads();
+        if (tid == 0) ticket = __hip_atomic_fetch_add(a.kcnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        if (ticket == S - 1) {
+#pragma unroll
+            for (int q = 0; q < NO; ++q) {
+                if (!ep_on[q]) continue;
+                const int o = tid + q * NT_;
+                float pv[MPNN_LIN_KSLICES];
+#pragma unroll
+                for (int sl = 0; sl < MPNN_LIN_KSLICES; ++sl)
+                    pv[sl] = __hip_atomic_load(part + (sl < S ? sl : 0) * 512 + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                float v = (ep_s[q] ? a.b[1] : a.b[0])[ep_col[q]];
+#pragma unroll
+                for (int sl = 0; sl < MPNN_LIN_KSLICES; ++sl) v += sl < S ? pv[sl] : 0.f;
+                if (ep_s[q] ? a.extra_col[1] : a.extra_col[0])
+                    v += a.alpha_cpt * a.k_cpt[ep_row[q]] * (ep_s[q] ? a.w[1] : a.w[0])[(size_t)K * ep_M[q] + ep_col[q]];
+                (ep_s[q] ? a.y[1] : a.y[0])[(size_t)ep_row[q] * ep_M[q] + ep_col[q]] = v;
+            }
+            if (tid == 0) __hip_atomic_store(a.kcnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     trace_stamp(5);
 }
@@ -116,8 +173,16 @@ int mpnn_trace_install_lin(void *buf) { return mpnn_trace_install(buf); }
 extern "C" int mpnn_lin_fwd(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void *stream) {
     if (count <= 0 || n_max <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    hipLaunchKernelGGL(lin_fwd_k, dim3((n_max + 15) / 16, count), dim3(LF_WAVES * 64), 0, (hipStream_t)stream,
-                       dev_table);
+    hipLaunchKernelGGL((lin_fwd_k<16, false>), dim3((n_max + 15) / 16, count), dim3(16 * 64), 0, (hipStream_t)stream, dev_table);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mpnn_lin_fwd_ks(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void *stream) {
+    if (count <= 0 || n_max <= 0) return 0;
+    if (!dev_table) return MPNN_E_ARG;
+    hipLaunchKernelGGL((lin_fwd_k<4, true>), dim3((n_max + 15) / 16, count * MPNN_LIN_KSLICES), dim3(4 * 64), 0,
+                       (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

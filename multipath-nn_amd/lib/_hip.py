@@ -16,6 +16,7 @@ MAX_NODES, MAX_SINKS = 128, 4
 BN_SLOTS = 16                  # MPNN_BN_SLOTS
 SEG_INTS = 12                  # MPNN_SEG_INTS
 SLAB_ITEM = 1024               # MPNN_SLAB_ITEM: elements per mpnn_slab_reduce work item
+LIN_KSLICES = 8                # MPNN_LIN_KSLICES: most K-slices of one mpnn_lin_fwd record
 
 
 def slab_item_size(n_split):
@@ -67,7 +68,8 @@ class WgradArgs(C.Structure):
 
 class LinFwdArgs(C.Structure):
     _fields_ = [('a', Act), ('HW', C.c_int), ('w', P * 2), ('b', P * 2), ('y', P * 2), ('M', C.c_int * 2),
-                ('k_cpt', P), ('alpha_cpt', C.c_float), ('extra_col', C.c_int * 2), ('n', C.c_int)]
+                ('k_cpt', P), ('alpha_cpt', C.c_float), ('extra_col', C.c_int * 2), ('n', C.c_int),
+                ('kpart', P), ('kcnt', P)]
 
 
 class LinBwdArgs(C.Structure):
@@ -148,6 +150,7 @@ _SIGS = {
     'mpnn_slab_reduce': [P, P, P, C.c_int, P],
     'mpnn_lin_fwd': [P, C.c_int, C.c_int, P],
     'mpnn_lin_bwd': [P, C.c_int, C.c_int, C.c_int, P],
+    'mpnn_lin_fwd_ks': [P, C.c_int, C.c_int, P],
     'mpnn_exit_tail_fwd': [P, C.c_int, C.c_int, P],
     'mpnn_exit_tail_bwd': [P, C.c_int, C.c_int, P],
     'mpnn_route': [C.POINTER(RouteArgs), P],

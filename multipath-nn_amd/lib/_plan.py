@@ -634,6 +634,14 @@ class Engine:
             lf.n = lb.n = tf.n = n
             lf.k_cpt = lb.k_cpt = self.k_cpt.data_ptr()
             lf.alpha_cpt = lb.alpha_cpt = float(_attr(ϕ, 'α_cpt', 0.0))
+            if K >= 512 and n <= 512:
+                # K-slices for mpnn_lin_fwd (one workgroup per 16 rows pulled all of W through one compute
+                # unit); small batches only -- with thousands of rows the launch has workgroups enough
+                rg = (n + 15) // 16
+                kpart = torch.empty(rg * _hip.LIN_KSLICES * 512, device=self.dev)
+                kcnt = torch.zeros(rg, dtype=torch.int32, device=self.dev)
+                keep += [kpart, kcnt]
+                lf.kpart, lf.kcnt = kpart.data_ptr(), kcnt.data_ptr()
             lb.dx = b.dx.data_ptr()
             if mode == 'tr' and not b.children and not self.multi_stream:
                 # the exit's dX is the only gradient of this map: lin_bwd masks it and accumulates the
@@ -687,7 +695,7 @@ class Engine:
         t_tf, t_tb = _hip.to_device_table(tail_f, self.dev), _hip.to_device_table(tail_b, self.dev)
         keep += [t_lf, t_lb, t_tf, t_tb]
         if n_exit:
-            fwd.append(call(lib.mpnn_lin_fwd, 'lin_fwd', t_lf.data_ptr(), n_exit, n))
+            fwd.append(call(lib.mpnn_lin_fwd_ks if n <= 512 else lib.mpnn_lin_fwd, 'lin_fwd', t_lf.data_ptr(), n_exit, n))
             fwd.append(call(lib.mpnn_exit_tail_fwd, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n))
 
         # ---- route ----

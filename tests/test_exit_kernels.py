@@ -83,6 +83,26 @@ def test_lin_fwd_bwd(n, C_, dyn):
     r1 = af @ w1[:K].astype(np.float64) + b1 + (alpha * kc[:, None].astype(np.float64) * w1[K] if dyn else 0)
     close(y0.cpu().numpy(), r0, 2e-5, 'head logits')
     close(y1.cpu().numpy(), r1, 2e-5, 'router h1')
+    # the same map K-SLICED (scratch given): partial tiles met by the last workgroup to arrive.  Three
+    # launches in a row: the ticket counters must be left at zero, and the result may not depend on the
+    # arrival order (bit-identical every time).
+    rg = (n + 15) // 16
+    kpart = torch.full((rg * _hip.LIN_KSLICES * 512,), float('nan'), device=DEV)
+    kcnt = torch.zeros(rg, dtype=torch.int32, device=DEV)
+    lf.kpart, lf.kcnt = kpart.data_ptr(), kcnt.data_ptr()
+    tab2 = _hip.to_device_table([lf], DEV)
+    outs = []
+    for rep in range(3):
+        y0.fill_(7.0); y1.fill_(7.0)
+        _hip.check(lib.mpnn_lin_fwd_ks(tab2.data_ptr(), 1, n, stream()), 'lin_fwd sliced')
+        torch.cuda.synchronize()
+        assert int(kcnt.abs().sum()) == 0
+        outs.append((y0.cpu().numpy().copy(), y1.cpu().numpy().copy()))
+    close(outs[0][0], r0, 2e-5, 'head logits (K-sliced)')
+    close(outs[0][1], r1, 2e-5, 'router h1 (K-sliced)')
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+    lf.kpart, lf.kcnt = None, None
 
     # backward: dX, dW, db (accumulated into zeroed tensors); fused BatchNorm-backward reductions
     dy0, dy1 = rng.standard_normal((n, M0)).astype(np.float32), rng.standard_normal((n, M1)).astype(np.float32)
