@@ -289,9 +289,20 @@ typedef struct {
      * also writes dz = dX where relu(bn(x)) > 0 else 0 to dz_out [n, HW*C] and adds
      * [sum dz, sum dz * xhat] per channel to red_out (fp64 [red_nslot][2C], caller-zeroed). */
     float *dz_out;  double *red_out;  int red_nslot;
+    /* Scratch of mpnn_lin_bwd_rs (ignored by mpnn_lin_bwd):
+     *   kpart: ceil((K+1)/64) * MPNN_LIN_RSPLIT * MPNN_LIN_RS_TILE floats, any contents
+     *   kcnt : ceil((K+1)/64) ints, ZERO before the first launch (left zero by every launch) */
+    float *kpart;  int *kcnt;
 } mpnn_lin_bwd_args;
+#define MPNN_LIN_RSPLIT 8
+#define MPNN_LIN_RS_TILE 2080            /* 64 features x 32 outputs of dW + 32 of db */
 int mpnn_lin_bwd(const mpnn_lin_bwd_args *dev_table, int count, int n_max, int k_max,
                  void *stream);
+/* The same for SMALL batches, ROW-SPLIT: min(MPNN_LIN_RSPLIT, ceil(n_max / 64)) workgroups share the rows
+ * of a 64-feature block; their dW / db partial tiles meet in kpart, added in row-group order by the last
+ * to arrive (ticket counter kcnt) -- bit-identical from launch to launch.  Every record needs scratch. */
+int mpnn_lin_bwd_rs(const mpnn_lin_bwd_args *dev_table, int count, int n_max, int k_max,
+                    void *stream);
 
 /* ---- exit tail: everything after the first affine map ----------------------
  * Head: Softmax + CrossEntropyError (layer_types.py:81-84, 262-272).

@@ -200,18 +200,31 @@ extern "C" int mpnn_lin_fwd_ks(const mpnn_lin_fwd_args *dev_table, int count, in
 // No workgroup shares an output with another: dW, db are plain stores in a fixed summation order.
 // (History: a thread-per-feature VALU loop, ~100 instructions per row, with the rows split over eight
 // workgroups that ADDED their dW partials -- 0.8 M fp32 atomics per step, 7 us of a 21 us launch.)
+//
+// Row split (mpnn_lin_bwd_rs, small batches): gridDim.z workgroups share the rows of a feature block, four
+// passes (64 rows) at a time each; they leave their dW / db partial tiles in scratch with write-through
+// stores and take a ticket, and the last to arrive adds the partials in row-group order (as
+// mpnn_lin_fwd_ks: deterministic, no agent-scope fence).  The unsplit form reads 52 KB per workgroup
+// in 56 loads per thread before its first MFMA: 6 of its 17 us.
 #define LB_ROWS 16          // rows per MFMA pass
-#define LB_SUPER 128        // rows held in LDS / registers at a time (the exit tails cap a launch at 128 anyway)
-#define LB_NP (LB_SUPER / LB_ROWS)
-#define LB_GP 4             // passes in flight together
 #define LB_DP 36            // LDS pitch of a dY row: 4 * 36 = 16 (mod 32) -> the dW operand reads are conflict-free
+// NP = passes (of 16 rows) held in LDS / registers at a time; RS = row split
+template <int NP, bool RS>
 __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__restrict__ tab) {
+    constexpr int LB_SUPER = NP * LB_ROWS, LB_NP = NP, LB_GP = NP < 4 ? NP : 4;     // LB_GP: passes in flight together
     const mpnn_lin_bwd_args &a = tab[blockIdx.y];      // (by reference: a copy needs more SGPRs than there are -- 254 spills, +1.2 us)
     const int C = a.a.C, K = a.HW * C;
     const bool has_extra = a.extra_col[0] || a.extra_col[1];
     const int kext = K + (has_extra ? 1 : 0);
     const int k0 = blockIdx.x * 64;
     if (k0 >= kext) return;
+    // this workgroup's rows [r_lo, r_hi): whole passes, dealt evenly to the Z row groups that have any
+    const int np_all = (a.n + LB_ROWS - 1) / LB_ROWS;
+    const int ppw = RS ? (np_all + (int)gridDim.z - 1) / (int)gridDim.z : np_all;
+    const int Z = RS ? (np_all + ppw - 1) / max(ppw, 1) : 1;
+    const int zi = RS ? (int)blockIdx.z : 0;
+    if (zi >= Z) return;
+    const int r_lo = zi * ppw * LB_ROWS, r_hi = min(a.n, (zi + 1) * ppw * LB_ROWS);
     trace_stamp(0); trace_note(6, 11);
     __shared__ float dys[LB_SUPER * LB_DP];
     __shared__ __attribute__((aligned(16))) float coef[64 * 4];       // per local feature: mean, gamma*rstd, beta, rstd
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
     constexpr int DY_PT = LB_SUPER * 32 / 256;
     float xv[LB_NP][4], dyr[DY_PT];
     auto load_super = [&](int R0) {
-        const int nr = min(LB_SUPER, a.n - R0);
+        const int nr = min(LB_SUPER, r_hi - R0);
 #pragma unroll
         for (int q = 0; q < DY_PT; ++q) {
             const int i = tid + q * 256, rr = i >> 5, col = i & 31, s = col >> 4, m = col & 15;
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
                 xv[p][q] = (okx || oke) ? v : 0.f;
             }
     };
-    load_super(0);
+    load_super(r_lo);
     if (tid < 64) {
         f32x4 cf = {0.f, 1.f, 0.f, 0.f};
         if (bn && k0 + tid < K) { const BnC c = bn_coef(a.a, (k0 + tid) % C); cf[0] = c.m; cf[1] = c.gamma * c.rstd; cf[2] = c.beta; cf[3] = c.rstd; }
@@ -267,9 +280,9 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
     float r1 = 0.f, r2 = 0.f;                               // sum dz, sum dz * xhat over this lane's rows
     float dbs = 0.f;
     trace_stamp(1);
-    for (int R0 = 0; R0 < a.n; R0 += LB_SUPER) {
-        const int nr = min(LB_SUPER, a.n - R0);
-        if (R0) load_super(R0);
+    for (int R0 = r_lo; R0 < r_hi; R0 += LB_SUPER) {
+        const int nr = min(LB_SUPER, r_hi - R0);
+        if (R0 != r_lo) load_super(R0);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < DY_PT; ++q) { const int i = tid + q * 256; dys[(i >> 5) * LB_DP + (i & 31)] = dyr[q]; }
@@ -281,6 +294,7 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
             for (int rr = 0; rr < LB_SUPER / 8; ++rr) t += dys[(rg * (LB_SUPER / 8) + rr) * LB_DP + col];   // (rows >= nr are zero)
             dbs += t;
         }
+        static_assert(LB_SUPER % 8 == 0, "db row groups");
         const f32x4 c = ((const f32x4 *)coef)[fl];
         // LB_GP passes at a time: their LDS reads, MFMA chains (independent across passes) and stores overlap
         // (one pass at a time was a serial chain of LDS wait -> 8 dependent MFMAs -> drain -> stores: 1 us each)
@@ -339,6 +353,64 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
         }
     }
     trace_stamp(4);
+    // db of this workgroup's rows (feature block 0 only): eight row-group partials, fixed order
+    float dbt = 0.f;
+    if (blockIdx.x == 0) {
+        float *dbp = tr + 512;
+        dbp[tid] = dbs;
+        __syncthreads();
+        if (tid < 32) {
+#pragma unroll
+            for (int rg = 0; rg < 8; ++rg) dbt += dbp[rg * 32 + tid];
+        }
+    }
+    if constexpr (RS) {
+        if (Z > 1) {
+            // partial tiles -> scratch (write-through); the last row group to arrive adds them in row-group order
+            __shared__ int ticket;
+            float *part0 = a.kpart + (size_t)blockIdx.x * gridDim.z * MPNN_LIN_RS_TILE;
+            float *mine = part0 + (size_t)zi * MPNN_LIN_RS_TILE;
+#pragma unroll
+            for (int set = 0; set < 2; ++set)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    __hip_atomic_store(mine + (wid * 16 + 4 * g + q) * 32 + set * 16 + li, accW[set][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (blockIdx.x == 0 && tid < 32) __hip_atomic_store(mine + 2048 + tid, dbt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (= wait for the stores; see lin_fwd_k)
+            __syncthreads();
+            if (tid == 0) ticket = __hip_atomic_fetch_add(a.kcnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __syncthreads();
+            if (ticket != Z - 1) { trace_stamp(5); goto bn_sums; }
+            {
+                float pv[2][4][MPNN_LIN_RSPLIT];
+#pragma unroll
+                for (int set = 0; set < 2; ++set)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int z = 0; z < MPNN_LIN_RSPLIT; ++z)
+                            pv[set][q][z] = __hip_atomic_load(part0 + (size_t)(z < Z ? z : 0) * MPNN_LIN_RS_TILE + (wid * 16 + 4 * g + q) * 32 + set * 16 + li,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                float pd[MPNN_LIN_RSPLIT];
+#pragma unroll
+                for (int z = 0; z < MPNN_LIN_RSPLIT; ++z)
+                    pd[z] = (blockIdx.x == 0 && tid < 32) ? __hip_atomic_load(part0 + (size_t)(z < Z ? z : 0) * MPNN_LIN_RS_TILE + 2048 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.f;
+#pragma unroll
+                for (int set = 0; set < 2; ++set)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int z = 0; z < MPNN_LIN_RSPLIT; ++z) v += z < Z ? pv[set][q][z] : 0.f;
+                        accW[set][q] = v;
+                    }
+                dbt = 0.f;
+#pragma unroll
+                for (int z = 0; z < MPNN_LIN_RSPLIT; ++z) dbt += z < Z ? pd[z] : 0.f;
+                if (tid == 0) __hip_atomic_store(a.kcnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
     // dW tile of a set: lane holds rows 4g..4g+3 of the wave's 16 features, column li
 #pragma unroll
     for (int set = 0; set < 2; ++set) {
@@ -355,20 +427,13 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
             }
         }
     }
-    if (blockIdx.x == 0) {
-        float *dbp = tr + 512;
-        dbp[tid] = dbs;
-        __syncthreads();
-        if (tid < 32) {
-            float t = 0.f;
-#pragma unroll
-            for (int rg = 0; rg < 8; ++rg) t += dbp[rg * 32 + tid];
-            const int s = tid >> 4, m = tid & 15;
-            const float *wps = s ? a.w[1] : a.w[0];
-            float *dbp2 = s ? a.db[1] : a.db[0];
-            if (wps && dbp2 && m < (s ? a.M[1] : a.M[0])) dbp2[m] = t;
-        }
+    if (blockIdx.x == 0 && tid < 32) {
+        const int s = tid >> 4, m = tid & 15;
+        const float *wps = s ? a.w[1] : a.w[0];
+        float *dbp2 = s ? a.db[1] : a.db[0];
+        if (wps && dbp2 && m < (s ? a.M[1] : a.M[0])) dbp2[m] = dbt;
     }
+bn_sums:
     // fused BatchNorm-backward reductions: feature k = pixel * C + c; the workgroup's 64 features are
     // 64 / C pixels of all C channels (C | 64) or a 64-channel slice of one pixel
     if (fuse_bn) {
@@ -387,7 +452,7 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
             double a1 = 0.0, a2 = 0.0;
             for (int t = tid; t < 64 && k0 + t < K; t += span) { a1 += (double)tr[t]; a2 += (double)tr[64 + t]; }
             const int c = (k0 + tid) % C;
-            double *slot = a.red_out + (size_t)(blockIdx.x % a.red_nslot) * 2 * C;
+            double *slot = a.red_out + (size_t)((blockIdx.x + zi * gridDim.x) % a.red_nslot) * 2 * C;
             atomicAdd(slot + c, a1);
             atomicAdd(slot + C + c, a2);
         }
@@ -398,7 +463,17 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
 extern "C" int mpnn_lin_bwd(const mpnn_lin_bwd_args *dev_table, int count, int n_max, int k_max, void *stream) {
     if (count <= 0 || n_max <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    hipLaunchKernelGGL(lin_bwd_k, dim3((k_max + 1 + 63) / 64, count), dim3(256), 0, (hipStream_t)stream, dev_table);
+    hipLaunchKernelGGL((lin_bwd_k<8, false>), dim3((k_max + 1 + 63) / 64, count), dim3(256), 0, (hipStream_t)stream, dev_table);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mpnn_lin_bwd_rs(const mpnn_lin_bwd_args *dev_table, int count, int n_max, int k_max, void *stream) {
+    if (count <= 0 || n_max <= 0) return 0;
+    if (!dev_table) return MPNN_E_ARG;
+    int z = (n_max + 63) / 64;                               // four 16-row passes per workgroup
+    if (z > MPNN_LIN_RSPLIT) z = MPNN_LIN_RSPLIT;
+    hipLaunchKernelGGL((lin_bwd_k<4, true>), dim3((k_max + 1 + 63) / 64, count, z), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

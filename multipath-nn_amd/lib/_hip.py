@@ -17,6 +17,8 @@ BN_SLOTS = 16                  # MPNN_BN_SLOTS
 SEG_INTS = 12                  # MPNN_SEG_INTS
 SLAB_ITEM = 1024               # MPNN_SLAB_ITEM: elements per mpnn_slab_reduce work item
 LIN_KSLICES = 8                # MPNN_LIN_KSLICES: most K-slices of one mpnn_lin_fwd record
+LIN_RSPLIT = 8                 # MPNN_LIN_RSPLIT: most row groups of one mpnn_lin_bwd_rs feature block
+LIN_RS_TILE = 2080             # MPNN_LIN_RS_TILE: floats of one row group's partial tile
 
 
 def slab_item_size(n_split):
@@ -76,7 +78,7 @@ class LinBwdArgs(C.Structure):
     _fields_ = [('a', Act), ('HW', C.c_int), ('w', P * 2), ('dy', P * 2), ('M', C.c_int * 2),
                 ('dw', P * 2), ('db', P * 2), ('dx', P), ('k_cpt', P), ('alpha_cpt', C.c_float),
                 ('extra_col', C.c_int * 2), ('n', C.c_int),
-                ('dz_out', P), ('red_out', P), ('red_nslot', C.c_int)]
+                ('dz_out', P), ('red_out', P), ('red_nslot', C.c_int), ('kpart', P), ('kcnt', P)]
 
 
 class ExitTailArgs(C.Structure):
@@ -151,6 +153,7 @@ _SIGS = {
     'mpnn_lin_fwd': [P, C.c_int, C.c_int, P],
     'mpnn_lin_bwd': [P, C.c_int, C.c_int, C.c_int, P],
     'mpnn_lin_fwd_ks': [P, C.c_int, C.c_int, P],
+    'mpnn_lin_bwd_rs': [P, C.c_int, C.c_int, C.c_int, P],
     'mpnn_exit_tail_fwd': [P, C.c_int, C.c_int, P],
     'mpnn_exit_tail_bwd': [P, C.c_int, C.c_int, P],
     'mpnn_route': [C.POINTER(RouteArgs), P],

@@ -642,6 +642,13 @@ class Engine:
                 kcnt = torch.zeros(rg, dtype=torch.int32, device=self.dev)
                 keep += [kpart, kcnt]
                 lf.kpart, lf.kcnt = kpart.data_ptr(), kcnt.data_ptr()
+            if mode == 'tr' and n <= 512:
+                # row split for mpnn_lin_bwd_rs: partial dW / db tiles of the row groups of a feature block
+                nblk = (K + 1 + 63) // 64
+                bpart = torch.empty(nblk * _hip.LIN_RSPLIT * _hip.LIN_RS_TILE, device=self.dev)
+                bcnt = torch.zeros(nblk, dtype=torch.int32, device=self.dev)
+                keep += [bpart, bcnt]
+                lb.kpart, lb.kcnt = bpart.data_ptr(), bcnt.data_ptr()
             lb.dx = b.dx.data_ptr()
             if mode == 'tr' and not b.children and not self.multi_stream:
                 # the exit's dX is the only gradient of this map: lin_bwd masks it and accumulates the
@@ -711,7 +718,7 @@ class Engine:
         slab_plan = dict(size=0, table=[], ptrs=[])
         if n_exit:
             bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
-            bwd.append(call(lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
+            bwd.append(call(lib.mpnn_lin_bwd_rs if n <= 512 else lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
         if dp and 'exit' in self.dp_buckets:
             bwd.append(marker('bucket', 'exit'))       # head + router gradients are final: their all-reduce starts here
         bwd.append(marker('fork'))

@@ -106,7 +106,13 @@ def test_lin_fwd_bwd(n, C_, dyn):
 
     # backward: dX, dW, db (accumulated into zeroed tensors); fused BatchNorm-backward reductions
     dy0, dy1 = rng.standard_normal((n, M0)).astype(np.float32), rng.standard_normal((n, M1)).astype(np.float32)
-    for fused in (False, True):
+    nblk = (K + 1 + 63) // 64
+    bpart = torch.full((nblk * _hip.LIN_RSPLIT * _hip.LIN_RS_TILE,), float('nan'), device=DEV)
+    bcnt = torch.zeros(nblk, dtype=torch.int32, device=DEV)
+    prev = {}
+    # (rs: the ROW-SPLIT form, mpnn_lin_bwd_rs -- partial tiles met by the last row group to arrive; run
+    # twice: the ticket counters must be left at zero and the result may not depend on the arrival order)
+    for fused, rs in ((False, False), (True, False), (False, True), (True, True), (True, True)):
         dy0d, dy1d = dev(dy0), dev(dy1)
         dw0, dw1 = torch.zeros_like(w0d), torch.zeros_like(w1d)
         db0, db1 = torch.zeros(M0, device=DEV), torch.zeros(M1, device=DEV)
@@ -123,9 +129,17 @@ def test_lin_fwd_bwd(n, C_, dyn):
             lb.dx, lb.dz_out, lb.red_out, lb.red_nslot = None, dz.data_ptr(), red.data_ptr(), _hip.BN_SLOTS
         else:
             lb.dx = dx.data_ptr()
+        if rs:
+            lb.kpart, lb.kcnt = bpart.data_ptr(), bcnt.data_ptr()
         tb = _hip.to_device_table([lb], DEV)
-        _hip.check(lib.mpnn_lin_bwd(tb.data_ptr(), 1, n, K, stream()), 'lin_bwd')
+        _hip.check((lib.mpnn_lin_bwd_rs if rs else lib.mpnn_lin_bwd)(tb.data_ptr(), 1, n, K, stream()), 'lin_bwd')
         torch.cuda.synchronize()
+        if rs:
+            assert int(bcnt.abs().sum()) == 0
+            got = [t.cpu().numpy().copy() for t in (dw0, dw1, db0, db1, dz if fused else dx)]
+            if fused in prev:
+                assert all(np.array_equal(u, v) for u, v in zip(got, prev[fused])), 'row-split result depends on arrival order'
+            prev[fused] = got
         dxr = dy0.astype(np.float64) @ w0.T + dy1.astype(np.float64) @ w1[:K].T
         gclose(dw0.cpu().numpy(), af.T @ dy0, 'dW head')
         ext = np.concatenate([af, alpha * kc[:, None].astype(np.float64)], 1) if dyn else af

@@ -60,7 +60,8 @@ def test_ctypes_structs_match_the_c_layout():
         py = {'MPNN_BN_SLOTS': _hip.BN_SLOTS, 'MPNN_MAX_NODES': _hip.MAX_NODES, 'MPNN_MAX_SINKS': _hip.MAX_SINKS,
               'MPNN_HYP_N': _hip.HYP_N, 'MPNN_HYP_TAU': _hip.HYP_TAU, 'MPNN_HYP_EPS': _hip.HYP_EPS,
               'MPNN_NET_CRITIC': _hip.NET_CRITIC, 'MPNN_ACT_BN_MOVING': _hip.ACT_BN_MOVING,
-              'MPNN_SLAB_ITEM': _hip.SLAB_ITEM, 'MPNN_LIN_KSLICES': _hip.LIN_KSLICES, 'MPNN_SEG_INTS': _hip.SEG_INTS}.get(name)
+              'MPNN_SLAB_ITEM': _hip.SLAB_ITEM, 'MPNN_LIN_KSLICES': _hip.LIN_KSLICES, 'MPNN_SEG_INTS': _hip.SEG_INTS,
+              'MPNN_LIN_RSPLIT': _hip.LIN_RSPLIT, 'MPNN_LIN_RS_TILE': _hip.LIN_RS_TILE}.get(name)
         if py is not None:
             assert py == int(val), name
 

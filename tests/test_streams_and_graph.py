@@ -22,11 +22,23 @@ def run(multi, graph, steps=4):
 
 
 def test_multi_stream_and_graph_match_sequential():
-    p0, s0 = run(False, False)
+    """ONE step from the same state: every schedule must agree to rounding (the multi-stream schedule uses
+    the unfused backward launches, i.e. other summation trees: 1e-7).  A wrong dependency shows up here.
+    Over several steps only runs of the SAME launch list are compared (graph replay vs eager): training
+    amplifies a 1e-7 difference through ReLU / max-pool decisions -- 2e-4 after the second step, 6e-4 after
+    the fourth, measured -- so a multi-step comparison ACROSS schedules tests the net's conditioning, not
+    the scheduler."""
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    p0, s0 = run(False, False, steps=1)
     for multi, graph in ((True, False), (False, True), (True, True)):
-        p1, s1 = run(multi, graph)
-        assert np.abs(p1 - p0).max() <= 1e-4 * np.abs(p0).max(), (multi, graph)
-        assert np.abs(s1 - s0).max() <= 1e-4 * np.abs(s0).max(), (multi, graph)
+        p1, s1 = run(multi, graph, steps=1)
+        assert rel(p1, p0) <= 2e-6 and rel(s1, s0) <= 2e-6, (multi, graph, rel(p1, p0), rel(s1, s0))
+    p0, s0 = run(False, False)
+    p1, s1 = run(False, True)
+    assert rel(p1, p0) <= 1e-6 and rel(s1, s0) <= 1e-6, ('graph replay vs eager, 4 steps', rel(p1, p0))
+    p0, s0 = run(True, False)
+    p1, s1 = run(True, True)
+    assert rel(p1, p0) <= 1e-4 and rel(s1, s0) <= 1e-4, ('multi-stream: graph replay vs eager, 4 steps', rel(p1, p0))
 
 
 def _net128(seed=5):
