@@ -274,8 +274,9 @@ int mpnn_lin_fwd(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void 
  * K >= 512 is split over S = min(MPNN_LIN_KSLICES, K / 256) 256-thread workgroups per 16 rows; each leaves
  * its partial tile in kpart, and the LAST to arrive (ticket counter kcnt, which it resets) adds the S
  * partials in slice order -- the result does not depend on which workgroup that is (bit-identical from
- * launch to launch); it differs from mpnn_lin_fwd's in the last bits (another summation tree). */
-int mpnn_lin_fwd_ks(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void *stream);
+ * launch to launch); it differs from mpnn_lin_fwd's in the last bits (another summation tree).
+ * k_max >= HW*C of every record (sizes the grid). */
+int mpnn_lin_fwd_ks(const mpnn_lin_fwd_args *dev_table, int count, int n_max, int k_max, void *stream);
 
 typedef struct {
     mpnn_act a;  int HW;

@@ -21,13 +21,13 @@
 // the launch took 83 us with __threadfence()).  Four waves, not sixteen: the dispatcher starts
 // 240 sixteen-wave workgroups over 7 us.
 template <int LFW, bool SLICED>
-__global__ __launch_bounds__(LFW * 64) void lin_fwd_k(const mpnn_lin_fwd_args *__restrict__ tab) {
+__global__ __launch_bounds__(LFW * 64) void lin_fwd_k(const mpnn_lin_fwd_args *__restrict__ tab, const int n_rec) {
     // (by value: every field's scalar load sits in the entry block, one round trip.  The two-element arrays are
     // only ever indexed by CONSTANTS below -- a run-time index would put the copy in scratch memory: +4 us)
-    const mpnn_lin_fwd_args a = tab[SLICED ? blockIdx.y / MPNN_LIN_KSLICES : blockIdx.y];
+    const mpnn_lin_fwd_args a = tab[SLICED ? blockIdx.y % n_rec : blockIdx.y];     // (sliced: y = slice * n_rec + record)
     const int n0 = blockIdx.x * 16;
     if (n0 >= a.n) return;
-    const int slice = SLICED ? blockIdx.y % MPNN_LIN_KSLICES : 0;
+    const int slice = SLICED ? blockIdx.y / n_rec : 0;
     const int S = (SLICED && a.kpart && a.kcnt) ? min(MPNN_LIN_KSLICES, max(1, (a.HW * a.a.C) >> 8)) : 1;
     if (slice >= S) return;
     trace_stamp(0); trace_note(6, 10);
@@ -173,16 +173,18 @@ int mpnn_trace_install_lin(void *buf) { return mpnn_trace_install(buf); }
 extern "C" int mpnn_lin_fwd(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void *stream) {
     if (count <= 0 || n_max <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    hipLaunchKernelGGL((lin_fwd_k<16, false>), dim3((n_max + 15) / 16, count), dim3(16 * 64), 0, (hipStream_t)stream, dev_table);
+    hipLaunchKernelGGL((lin_fwd_k<16, false>), dim3((n_max + 15) / 16, count), dim3(16 * 64), 0, (hipStream_t)stream, dev_table, count);
     MPNN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int mpnn_lin_fwd_ks(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void *stream) {
+extern "C" int mpnn_lin_fwd_ks(const mpnn_lin_fwd_args *dev_table, int count, int n_max, int k_max, void *stream) {
     if (count <= 0 || n_max <= 0) return 0;
-    if (!dev_table) return MPNN_E_ARG;
-    hipLaunchKernelGGL((lin_fwd_k<4, true>), dim3((n_max + 15) / 16, count * MPNN_LIN_KSLICES), dim3(4 * 64), 0,
-                       (hipStream_t)stream, dev_table);
+    if (!dev_table || k_max <= 0) return MPNN_E_ARG;
+    int s_max = k_max >> 8;                                  // slices of the largest record: the grid's extent
+    s_max = s_max < 1 ? 1 : (s_max > MPNN_LIN_KSLICES ? MPNN_LIN_KSLICES : s_max);
+    hipLaunchKernelGGL((lin_fwd_k<4, true>), dim3((n_max + 15) / 16, count * s_max), dim3(4 * 64), 0,
+                       (hipStream_t)stream, dev_table, count);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

@@ -152,7 +152,7 @@ _SIGS = {
     'mpnn_slab_reduce': [P, P, P, C.c_int, P],
     'mpnn_lin_fwd': [P, C.c_int, C.c_int, P],
     'mpnn_lin_bwd': [P, C.c_int, C.c_int, C.c_int, P],
-    'mpnn_lin_fwd_ks': [P, C.c_int, C.c_int, P],
+    'mpnn_lin_fwd_ks': [P, C.c_int, C.c_int, C.c_int, P],
     'mpnn_lin_bwd_rs': [P, C.c_int, C.c_int, C.c_int, P],
     'mpnn_exit_tail_fwd': [P, C.c_int, C.c_int, P],
     'mpnn_exit_tail_bwd': [P, C.c_int, C.c_int, P],

@@ -702,7 +702,10 @@ class Engine:
         t_tf, t_tb = _hip.to_device_table(tail_f, self.dev), _hip.to_device_table(tail_b, self.dev)
         keep += [t_lf, t_lb, t_tf, t_tb]
         if n_exit:
-            fwd.append(call(lib.mpnn_lin_fwd_ks if n <= 512 else lib.mpnn_lin_fwd, 'lin_fwd', t_lf.data_ptr(), n_exit, n))
+            if n <= 512:
+                fwd.append(call(lib.mpnn_lin_fwd_ks, 'lin_fwd', t_lf.data_ptr(), n_exit, n, kmax))
+            else:
+                fwd.append(call(lib.mpnn_lin_fwd, 'lin_fwd', t_lf.data_ptr(), n_exit, n))
             fwd.append(call(lib.mpnn_exit_tail_fwd, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n))
 
         # ---- route ----

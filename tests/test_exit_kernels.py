@@ -94,7 +94,7 @@ def test_lin_fwd_bwd(n, C_, dyn):
     outs = []
     for rep in range(3):
         y0.fill_(7.0); y1.fill_(7.0)
-        _hip.check(lib.mpnn_lin_fwd_ks(tab2.data_ptr(), 1, n, stream()), 'lin_fwd sliced')
+        _hip.check(lib.mpnn_lin_fwd_ks(tab2.data_ptr(), 1, n, K, stream()), 'lin_fwd sliced')
         torch.cuda.synchronize()
         assert int(kcnt.abs().sum()) == 0
         outs.append((y0.cpu().numpy().copy(), y1.cpu().numpy().copy()))
