@@ -233,15 +233,19 @@ extern "C" int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int coun
 template <typename FA, typename FB>
 __device__ __forceinline__ f32x4 contract(int n, FA fa, FB fb) {
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int it = 0; it < CHUNK / 4; ++it) {
-        const int s = 4 * it + g;
-        const bool ok = s < n;
+    // two accumulators (even / odd sample quads): a lone chain of 32 dependent MFMAs is ~36 cycles per link
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int it = 0; it < CHUNK / 4; it += 2) {
+        const int s = 4 * it + g, s2 = s + 4;
+        const bool ok = s < n, ok2 = s2 < n;
         const float av = ok ? fa(s, li) : 0.f, bv = ok ? fb(s, li) : 0.f;
+        const float av2 = ok2 ? fa(s2, li) : 0.f, bv2 = ok2 ? fb(s2, li) : 0.f;
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av2, bv2, acc2, 0, 0, 0);
     }
     mfma_drain();
+    acc += acc2;
     return acc;                                    // D[row = 4g + r][col = li] = acc[r]
 }
 
