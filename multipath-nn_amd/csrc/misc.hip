@@ -272,20 +272,37 @@ __global__ __launch_bounds__(256) void talr_momentum_k(float *__restrict__ param
         scale = 1.f / sqrtf(node_stat[node * 2 + 1] * inv_n);          // 1/sqrt(mean p_tr^2)
         if (is_router) scale *= hyp[MPNN_HYP_ARTR];
     }
-    for (int i = threadIdx.x; i < cnt; i += 256) {
-        const float w = params[off + i];
-        float g = grads[off + i] * grad_scale;
-        if (l2 != 0.f) g += 2.f * l2 * pbar * (w - (eq ? eq[i] : 0.f));
-        g *= scale;
-        const float a = mu * accum[off + i] + g;
-        accum[off + i] = a;
-        const float wn = w - lr * a;
-        params[off + i] = wn;
-        if (fast) wl[i] = wn;
-        else if (emit) {
-            const int e = off + i - tbase, tap = e / cc, rem = e - tap * cc, ci = rem / Cout, co = rem - ci * Cout;
-            if (fwd >= 0) packs[fwd + tap * per_f + ((ci >> 2) * Cout + co) * 4 + (ci & 3)] = wn;
-            if (bwd >= 0) packs[bwd + (8 - tap) * per_b + ((co >> 2) * Cin + ci) * 4 + (co & 3)] = wn;
+    // A segment has at most TM_Q * 256 elements (host: 2048).  Every operand of the thread's TM_Q elements is
+    // requested before the first is used (clamped addresses, no control flow): one memory round trip per
+    // workgroup -- as a rolled loop over `cnt` each iteration's three loads waited for the previous
+    // iteration's stores (12 us for 8 MB; the loop stays for longer segments).
+    constexpr int TM_Q = 8;
+    for (int i0 = 0; i0 < cnt; i0 += TM_Q * 256) {
+        float wq[TM_Q], gq[TM_Q], aq[TM_Q], eqv[TM_Q];
+#pragma unroll
+        for (int q = 0; q < TM_Q; ++q) {
+            const int i = i0 + threadIdx.x + q * 256, ic = i < cnt ? i : 0;
+            wq[q] = params[off + ic]; gq[q] = grads[off + ic]; aq[q] = accum[off + ic];
+            eqv[q] = eq ? eq[ic] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < TM_Q; ++q) {
+            const int i = i0 + threadIdx.x + q * 256;
+            if (i >= cnt) continue;
+            const float w = wq[q];
+            float g = gq[q] * grad_scale;
+            if (l2 != 0.f) g += 2.f * l2 * pbar * (w - eqv[q]);
+            g *= scale;
+            const float a = mu * aq[q] + g;
+            accum[off + i] = a;
+            const float wn = w - lr * a;
+            params[off + i] = wn;
+            if (fast) wl[i] = wn;
+            else if (emit) {
+                const int e = off + i - tbase, tap = e / cc, rem = e - tap * cc, ci = rem / Cout, co = rem - ci * Cout;
+                if (fwd >= 0) packs[fwd + tap * per_f + ((ci >> 2) * Cout + co) * 4 + (ci & 3)] = wn;
+                if (bwd >= 0) packs[bwd + (8 - tap) * per_b + ((co >> 2) * Cin + ci) * 4 + (co & 3)] = wn;
+            }
         }
     }
     if (fast) {                                        // (uniform)
