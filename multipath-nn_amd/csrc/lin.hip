@@ -3,10 +3,11 @@
 // applied on load).  These launches sit on the step's critical path (forward
 // trunk -> exits -> router -> exits backward -> trunk backward) with almost no
 // arithmetic, so they are organised for latency: table-driven (one launch for
-// every exit of the tree), K split over 16 waves in the forward, and ONE
+// every exit of the tree), K split over the waves of a workgroup (and, for the
+// small batches of the training step, over workgroups) in the forward, and ONE
 // backward kernel that produces dX, dW and db (and the fused BatchNorm-backward
-// reductions) from one load of X on MFMA tiles (row groups add their dW/db
-// partials with fp32 atomics).
+// reductions) from one load of X on MFMA tiles.  Where workgroups share an
+// output they meet through a ticket and a fixed-order sum: no float atomics.
 #include "common.h"
 
 // ------------------------------- forward ------------------------------------

@@ -238,8 +238,9 @@ extern "C" int mpnn_bn_finalize(const double *sums, const double *reds, float *s
 }
 
 // ---------------------------------------------------------------------------
-// mpnn_talr_momentum_step.  seg: 6 ints per work item
-// (offset, count, node, is_router, l2 as float bits, -).
+// mpnn_talr_momentum_step.  seg: MPNN_SEG_INTS ints per work item (include/mpnn_hip.h):
+// offset, count (<= 2048), node, is_router, l2 as float bits, w_eq offset | -1, and for conv weights
+// the tensor's base, Cin, Cout and the offsets of its forward / backward packs.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void talr_momentum_k(float *__restrict__ params, float *__restrict__ accum,
                                                        const float *__restrict__ grads, const int *__restrict__ seg,
