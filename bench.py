@@ -113,6 +113,93 @@ def cpu_baseline(batch, seconds=24.0):
                        'oracle/ref_net.py torch-CPU fp32' % (cnt, batch, med * 1e3, threads, all_cores, tries))
 
 
+def spawn_ranks(n_ranks):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_ranks),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL between processes needs it on this stack
+    env.setdefault('OMP_NUM_THREADS', '4')
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def time_replays(run, reps, chunk=10):
+    """Median ms per call of `run` over reps calls: HIP events on the launch stream around chunks."""
+    st = torch.cuda.current_stream()
+    k = max(1, reps // chunk)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+    evs[0].record(st)
+    for i in range(k):
+        for _ in range(chunk):
+            run()
+        evs[i + 1].record(st)
+    torch.cuda.synchronize()
+    per = np.array([evs[i].elapsed_time(evs[i + 1]) / chunk for i in range(k)])
+    return float(np.median(per))
+
+
+def measure_dp_structure(net, eng, feed, single_ms):
+    """What the data-parallel STRUCTURE costs before any wire time: the step as the multi-GPU run executes
+    it -- one graph per gradient-bucket section, an asynchronous RCCL all-reduce per bucket between the
+    replays, stream waits, a graph for the optimizer -- with a ONE-rank RCCL process group, beside the
+    single-graph step of the headline."""
+    import torch.distributed as dist
+    from lib import _dp
+    _dp.init(backend='nccl', force=True)
+    try:
+        _dp.attach(net, force=True)
+        for _ in range(5):
+            net.train.run(feed)
+        torch.cuda.synchronize()
+        ms = time_replays(lambda: net.train.run(feed), 200)
+        return {'ms_per_step': ms, 'ms_per_step_single_graph': single_ms, 'ratio': ms / single_ms,
+                'sections': len(eng.dp_buckets), 'collectives_per_step': len(eng.dp_buckets), 'rccl_ranks': dist.get_world_size(),
+                'what': 'forced 1-rank RCCL group: section graphs + async bucket all-reduces + optimizer graph, 200 steps'}
+    finally:
+        _dp.detach(net)
+        dist.destroy_process_group()
+
+
+def time_configs(dev, n, reps=200):
+    """SURVEY 8(d)'s other timing configurations, full training steps at batch n (one hipGraph per step),
+    `reps` replays each after 5 warm-up steps: img/s and ms/step.  The headline stays cifar10-ac k_cpt=0."""
+    import arch_and_hypers as A
+    kv = torch.from_numpy(np.random.default_rng(0).choice(A.k_cpts, n).astype(np.float32)).to(dev)
+    table = [
+        ('sr_chain8', A.sr_chain(8), 3, lambda net: {}),
+        ('ac_k6.4e-8', A.ac_chain(k_cpt=6.4e-8, seed=1234), 3, lambda net: {net.τ: A.τ_ds(0)}),
+        ('cr_k0', A.cr_chain(k_cpt=0.0, seed=1234), 3, lambda net: {net.τ: A.τ_cr(0)}),
+        ('ac_dyn_kcpt', A.ac_chain(dyn_k_cpt=True, seed=1234), 3, lambda net: {net.τ: A.τ_ds(0), net.k_cpt: kv}),
+        ('mnist_sr', A.sr_chain(8), 1, lambda net: {}),
+    ]
+    out = {}
+    for name, make, c0, extra in table:
+        try:
+            net = make((32, 32, c0), (10,))
+            net.to(dev)
+            eng = net.engine()
+            g = torch.Generator().manual_seed(7)
+            eng._ensure_capacity(n, train=True)
+            eng.x0[:n].copy_(torch.rand((n, 32, 32, c0), generator=g).to(dev))
+            eng.y[:n].copy_(torch.nn.functional.one_hot(torch.randint(0, 10, (n,), generator=g), 10).float().to(dev))
+            feed = {net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr', net.λ_lrn: A.λ_lrn(0)}
+            feed.update(extra(net))
+            for _ in range(5):
+                net.train.run(feed)
+            torch.cuda.synchronize()
+            ms = time_replays(lambda: net.train.run(feed), reps)
+            out[name] = {'images_per_s': n / (ms * 1e-3), 'ms_per_step': ms}
+            del net, eng
+        except Exception as e:                      # a config that cannot run must not take the headline down
+            out[name] = {'error': repr(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -124,12 +211,25 @@ def main():
                     help='multi-stream DAG schedule (measured slower under hipGraph: cross-stream edges cost more than the overlap gains)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-batch', type=int, default=4096, help='batch of the routed / dense evaluation measurement')
+    ap.add_argument('--no-configs', action='store_true', help='skip the SURVEY 8(d) config table (extra.configs)')
+    ap.add_argument('--no-dp-structure', action='store_true', help='skip the 1-rank RCCL structure measurement (dp_structure)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` by itself: this process becomes the launcher.  It never touches the
+        # GPU (no HIP call before the children exist), starts N ranks through torch.distributed.run --
+        # exactly the driver's multi-GPU command -- relays their output (rank 0 prints the JSON line)
+        # and exits with their code.
+        return spawn_ranks(args.gpus)
 
     import torch.distributed as dist
     import arch_and_hypers as A
     from lib import _dp
     rank, world = _dp.init()
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d, but the process group has %d rank(s): launch with torch.distributed.run '
+                         '--nproc-per-node %d, or run `python bench.py --gpus %d` with WORLD_SIZE unset (it spawns the ranks)'
+                         % (args.gpus, world, args.gpus, args.gpus))
     local = _dp.local_device()
     dev = 'cuda:%d' % local
     torch.cuda.set_device(local)
@@ -206,6 +306,15 @@ def main():
               'ms_p95': float(np.percentile(per, 95)), 'images_per_s_median': n * world / (float(np.median(per)) * 1e-3),
               'what': 'replays after the headline region (rank 0\'s clock), HIP events around chunks of %d steps' % CH}
 
+    dp_structure, cfg_table = None, None
+    if world == 1 and not args.no_dp_structure and not args.streams:
+        try:
+            dp_structure = measure_dp_structure(net, eng, feed, steady['ms_median'])
+        except Exception as e:
+            dp_structure = {'error': repr(e)}
+    if rank == 0 and world == 1 and not args.no_configs:
+        cfg_table = time_configs(dev, n)
+
     out = None
     if rank == 0:
         # routed FLOPs/s = images/s x 2 x moc (scripts/train-nets:120), moc from an 'ev' pass
@@ -232,6 +341,7 @@ def main():
         x_tr, y_tr = eng.x0[:n].clone(), eng.y[:n].clone()
         eng.x0[:nb_].copy_(xe); eng.y[:nb_].copy_(ye)
         big = {net.x0: eng.x0[:nb_], net.y: eng.y[:nb_]}
+        bias_keep = [(ℓ.router.comps[-1].params.b, ℓ.router.comps[-1].params.b.numpy().copy()) for ℓ in net.switches]
         set_exit_fractions(net, big, nb_, [1.0 / 8] * 7)
         d_ms = time_eval(big, False, 20)
         hist_d = [float(l.p_ev.mean()) for l in leaves]
@@ -252,6 +362,8 @@ def main():
                          'router_state': 'synthetic: exit biases calibrated to 1/8 of the batch per exit'},
               'compaction': True}
         eng.x0[:n].copy_(x_tr); eng.y[:n].copy_(y_tr)             # the training batch back in place
+        for b_, v_ in bias_keep:                                    # ... and the router biases (replicas stay identical)
+            b_.assign(v_)
         # dominant kernel FAMILY (one kernel symbol, or the instantiations of one template): in-situ
         # per-launch HIP-event timing on the launch stream, whole steps run eagerly
         ops = eng.time_step_ops('tr', n, reps=20)
@@ -320,6 +432,7 @@ def main():
             'conv_kernels': {'tflops': conv_fl / (conv_ms * 1e-3) / 1e12, 'sum_ms': conv_ms,
                              'all_launches_sum_ms': total_ms, 'n_launches': len(ops)},
             'routed_flops_per_s': value * 2 * moc, 'moc': moc, 'eval': ev, 'steady_state': steady,
+            'dp_structure': dp_structure, 'extra': {'configs': cfg_table},
             'launch_floor': {'kernels_per_step': n_launch, 'us_per_step': floor_us, 'us_per_kernel': floor_us / n_launch,
                              'what': 'hipGraph of that many 1-workgroup kernels'},
         }
@@ -334,4 +447,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

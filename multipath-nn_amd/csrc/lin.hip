@@ -143,7 +143,11 @@ __global__ __launch_bounds__(LFW * 64) void lin_fwd_k(const mpnn_lin_fwd_args *_
             const int o = tid + q * NT_;
             if (o < 512) __hip_atomic_store(part + slice * 512 + o, vsum[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (= wait for the stores; see the header comment)
+        // every wave waits until ITS write-through stores have been acknowledged (vmcnt(0)) before the
+        // barrier in front of the ticket: the workgroup-scope fence alone lowers to lgkmcnt(0) only, and the
+        // ticket could then become visible before other waves' partials (different L2 channels)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         if (tid == 0) ticket = __hip_atomic_fetch_add(a.kcnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __syncthreads();
@@ -379,7 +383,8 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
                 for (int q = 0; q < 4; ++q)
                     __hip_atomic_store(mine + (wid * 16 + 4 * g + q) * 32 + set * 16 + li, accW[set][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (blockIdx.x == 0 && tid < 32) __hip_atomic_store(mine + 2048 + tid, dbt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (= wait for the stores; see lin_fwd_k)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // store acknowledgement of EVERY wave before the ticket (see lin_fwd_k)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             if (tid == 0) ticket = __hip_atomic_fetch_add(a.kcnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __syncthreads();

@@ -89,6 +89,9 @@ def attach(net, force=False):
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return net
     eng = net.engine()
+    if not hasattr(eng, 'dp_buckets'):
+        raise NotImplementedError('%s has no gradient buckets: data-parallel training covers the multiscale chain / tree '
+                                  'engine (lib/_plan.py), not the single-scale Conv engine' % type(eng).__name__)
     eng.world = dist.get_world_size()
     eng.allreduce = allreduce_async
     eng._graphs.clear()                        # graphs captured so far folded the optimizer into the step
@@ -98,4 +101,12 @@ def attach(net, force=False):
         else:
             dist.broadcast(buf, src=0)
     eng.invalidate_packs()
+    return net
+
+
+def detach(net):
+    """Back to single-process training (bench: after the 1-rank structure measurement)."""
+    eng = net.engine()
+    eng.world, eng.allreduce = 1, None
+    eng._graphs.clear()
     return net

@@ -517,7 +517,11 @@ class Engine:
         """Launch lists of one (mode, batch size).  routed ('ev' only): the routed evaluation -- every
         block runs on the sample list its parent's router produced on the device (see _program_ev)."""
         routed = bool(routed) and mode != 'tr' and bool(self.switches) and self.net._net_kind != 'sr'
-        dp = mode == 'tr' and self.allreduce is not None and not self.multi_stream
+        if mode == 'tr' and self.allreduce is not None and self.multi_stream:
+            # one section would fork and re-join the same side streams twice inside one capture (ROCm 7.2 crashes in
+            # hipStreamEndCapture), and the DAG schedule has no bucket boundaries to overlap the collectives with
+            raise NotImplementedError('data-parallel training runs on the single-stream schedule (MPNN_STREAMS=0)')
+        dp = mode == 'tr' and self.allreduce is not None
         key = (mode, n, self.multi_stream, self.group_fwd, routed, dp)
         if key in self._progs:
             return self._progs[key]
@@ -1314,7 +1318,7 @@ class Engine:
         a real step.  Returns [(what, tag, flops, mean_ms)] in launch order."""
         prog = self.program(mode, n)
         train = mode == 'tr'
-        ops = [o for o in list(prog['fwd']) + (list(prog['bwd']) if train else []) if o.what not in ('fork', 'join')]
+        ops = [o for o in list(prog['fwd']) + (list(prog['bwd']) if train else []) if o.what not in ('fork', 'join', 'bucket')]
         st = torch.cuda.current_stream()
         tot = [0.0] * len(ops)
         for rep in range(reps + 1):
@@ -1338,7 +1342,7 @@ class Engine:
         Returns {what: (launches, flops, mean_ms_per_step)}."""
         prog = self.program(mode, n)
         train = mode == 'tr'
-        ops = [o for o in list(prog['fwd']) + (list(prog['bwd']) if train else []) if o.what not in ('fork', 'join')]
+        ops = [o for o in list(prog['fwd']) + (list(prog['bwd']) if train else []) if o.what not in ('fork', 'join', 'bucket')]
         runs = []
         for op in ops:
             if runs and runs[-1][0] == op.what:

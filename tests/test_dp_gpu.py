@@ -178,3 +178,28 @@ def test_bench_two_ranks_functional_on_one_gpu(tmp_path):
     assert line['n_gpus'] == 2 and line['config']['global_batch'] == 256 and line['config']['rccl_ranks'] == 2
     assert set(line['config']['allreduce']) == {'exit', 'mid', 'end'}
     assert line['value'] > 0 and line['steady_state']['steps'] == 400
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus 2` with no torchrun environment (the shape of the driver's single-GPU command
+    with a larger N): the parent process starts the two ranks itself, relays rank 0's line and the exit code."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(MPNN_DP_BACKEND='gloo', MPNN_DP_ONE_GPU='1')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3',
+           '--no-cpu-baseline', '--eval-batch', '256']
+    out = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['rccl_ranks'] == 2 and line['config']['global_batch'] == 256
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus(tmp_path):
+    """--gpus must be the number of ranks that actually run: a 1-rank process group under --gpus 2 is an error,
+    not a silent single-GPU number."""
+    import subprocess
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                         env=env, cwd=str(tmp_path), capture_output=True, timeout=600)
+    assert out.returncode != 0 and b'--gpus 2' in out.stderr

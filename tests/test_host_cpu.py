@@ -164,6 +164,36 @@ def test_isa_has_no_uncovered_mfma_result_reads():
     assert not bad, bad[:5]
 
 
+def test_isa_ticket_follows_store_acknowledgement():
+    """lin.hip's cross-workgroup hand-offs (K-slices of lin_fwd_k, row groups of lin_bwd_k): between the last
+    write-through (sc0 sc1) store of a partial tile and the ticket atomic every wave executes
+    `s_waitcnt vmcnt(0)` and then the workgroup barrier -- otherwise the ticket can become visible before
+    another wave's partials (MI355X_MICROARCH.md, "Valid forms")."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('hipcc') is None:
+        pytest.skip('hipcc not available')
+    csrc = os.path.join(ROOT, 'multipath-nn_amd', 'csrc')
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, 'lin.s')
+        subprocess.check_call(['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'),
+                               '-munsafe-fp-atomics', '--cuda-device-only', '-S', os.path.join(csrc, 'lin.hip'), '-o', out],
+                              cwd=csrc, stderr=subprocess.DEVNULL)
+        lines = [l.strip() for l in open(out)]
+    tickets = [k for k, l in enumerate(lines) if l.split()[:1] in (['flat_atomic_add'], ['global_atomic_add']) and 'sc0 sc1' in l]
+    assert len(tickets) >= 2, tickets                       # lin_fwd_k<4, true> and lin_bwd_k<..., true>
+    for k in tickets:
+        j = k
+        while j > 0 and not ('_store_dword' in lines[j] and 'sc0 sc1' in lines[j]):
+            j -= 1
+        assert j > 0, 'ticket without a preceding write-through store'
+        between = lines[j + 1:k]
+        w = [i for i, l in enumerate(between) if l.startswith('s_waitcnt') and 'vmcnt(0)' in l]
+        b = [i for i, l in enumerate(between) if l.startswith('s_barrier')]
+        assert w and b and w[0] < b[-1], (lines[j], between)
+
+
 def test_slab_item_size_keeps_one_load_batch_per_thread():
     """The planner's item size for mpnn_slab_reduce: a power of two in [64, MPNN_SLAB_ITEM] such that the
     kernel's slab groups (256 threads / (item / 4) element quads, at most 16) leave a thread <= 16 slabs
@@ -178,3 +208,32 @@ def test_slab_item_size_keeps_one_load_batch_per_thread():
             g2 = min(16, 256 // (2 * item // 4))
             assert -(-split // g2) > 16, (split, item)
     assert _hip.slab_item_size(4096) == 64
+
+
+def test_bench_launcher_spawns_ranks_without_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset becomes a launcher: torch.distributed.run with N ranks
+    on 127.0.0.1, the original arguments passed through, the children's exit code returned -- and no HIP call
+    in the parent (torch.cuda stays uninitialised)."""
+    import importlib
+    import subprocess
+    import torch
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen['cmd'], seen['env'] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1'])
+    assert bench.main() == 7
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-6:] == ['--gpus', '4', '--steps', '3', '--warmup', '1'] and cmd[-7].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert not torch.cuda.is_initialized()

@@ -130,6 +130,7 @@ def test_product_matches_the_reference_graph_code(key):
             assert np.abs(r - g('r')).max() <= 2e-4 * (1 + np.abs(g('r')).max())
     net.eval(feed)
     check('ev')
+    before = np.array([M.digest(p.numpy()) for _, p in params])
     net.train.run({**feed, net.mode: 'tr', net.λ_lrn: M.LR})
     torch.cuda.synchronize()
     check('tr')
@@ -140,3 +141,21 @@ def test_product_matches_the_reference_graph_code(key):
     zero_grad = np.array([n_.startswith('b_') for n_, _ in params])         # MultiscaleConvMax biases: d/db == 0 through BatchNorm
     tol = np.where(zero_grad, 2e-3, 5e-4)
     assert (err <= tol).all(), (key, [(params[i][0], float(err[i])) for i in np.argwhere(err > tol)[:, 0][:5]])
+    # The UPDATE itself (after - before; ~1e-2 of the values, so the check above holds it to a few percent
+    # only): the linear digest entries (sum, three samples) of every trainable tensor's update against the
+    # reference-graph vectors, 2e-3 of the update's scale.  The golden "before" is the injected float64 value,
+    # the device's its fp32 rounding; each side subtracts its own.
+    rng = np.random.RandomState(seed)
+    before64 = np.array([M.digest(M.param_value(n_, p.shape, rng)) for n_, p in params])
+    lin = [0, 2, 3, 4]
+    upd_dev, upd_ref = (after - before)[:, lin], (gold - before64)[:, lin]
+    trainable = np.array([p.trainable for _, p in params])
+    # per-tensor scale: the update's largest linear-digest entry, floored by what fp32 rounding of the VALUE
+    # allows (|sum| of a tensor of thousands of elements carries ~1e-7 of sum|v|)
+    floor = 3e-7 * np.abs(gold[:, 1:2])
+    uscale = np.abs(upd_ref).max(1, keepdims=True)
+    uerr = (np.abs(upd_dev - upd_ref) - floor).max(1) / (1e-30 + uscale[:, 0])
+    chk = trainable & ~zero_grad & (uscale[:, 0] > 0)
+    worst = np.argsort(-np.where(chk, uerr, -1))[:5]
+    print('%s: worst update errors (of the update scale): %s' % (key, [(params[i][0], float(uerr[i])) for i in worst]))
+    assert (uerr[chk] <= 2e-3).all(), (key, [(params[i][0], float(uerr[i])) for i in np.argwhere(chk & (uerr > 2e-3))[:, 0][:8]])

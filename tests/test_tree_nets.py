@@ -54,6 +54,13 @@ def test_reference_tree_one_step_vs_oracle(kind):
     run_case(mk, 6, lambda net, t: {net.τ: 0.5 if kind == 'ac' else 0.05}, steps=1, tol=5e-4)
 
 
+def test_reference_tree_one_step_at_the_training_batch():
+    """ac_tree (arch_and_hypers.py:99-127) at the training batch of arch_and_hypers.py:35: one full step of the
+    47-block tree at n = 128 against the oracle (the small cases above run at n = 6 and 12)."""
+    import arch_and_hypers as A
+    run_case(A.ac_tree(k_cpt=4e-9), 128, lambda net, t: {net.τ: 0.5}, steps=1, tol=5e-4)
+
+
 def test_reference_tree_routed_eval_equals_dense():
     import arch_and_hypers as A
     from test_routed_eval import check_routed_equals_dense
