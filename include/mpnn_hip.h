@@ -210,6 +210,28 @@ int mpnn_msconv_wgrad(const mpnn_wgrad_args *args, void *stream);
  * (NULL: none) and the weight gradients -- as ONE launch of independent workgroups. */
 int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *horz, const mpnn_dgrad_vert_args *vert,
                           const mpnn_wgrad_args *wgrad, void *stream);
+/* One DEPENDENCY LEVEL of the backward pass as one launch: g(b, S) (block b, absolute scale S) is final once
+ * the child block's dgrad-horz B(b+1, S) and the coarser scale's dgrad-vert B(b, S+1) have run, so the
+ * mpnn_msconv_bwd_scale triples with equal (blocks from the end) + (scales from the coarsest) are mutually
+ * independent (autodiff of layer_types.py:181-185; the reference leaves the order to TensorFlow's executor,
+ * net_types.py:35).  Members must not write the same output map (tree nets: siblings that accumulate into one
+ * parent map go to different launches).  The CALLER budgets the workgroups: wg_horz / wg_vert = workgroups per
+ * 16-channel tile row of the two input-gradient bodies, wgrad->n_split = pixel split of the weight gradients;
+ * mpnn_msconv_bwd_level_slots gives the workgroups that are resident at once for a set of member shapes
+ * (H, W, Cout of g), or MPNN_E_SHAPE when no kernel variant covers the set.
+ * The member records live in DEVICE memory: _prepare fills `count` records of _record_size() bytes in host
+ * memory, the caller copies them to the device once per plan and passes the device pointer to every launch. */
+#define MPNN_BWD_LEVEL_MAX 4
+typedef struct {
+    const mpnn_dgrad_horz_args *horz;    /* NULL: none */
+    const mpnn_dgrad_vert_args *vert;    /* NULL: none */
+    const mpnn_wgrad_args *wgrad;
+    int wg_horz, wg_vert;
+} mpnn_bwd_member;
+int mpnn_msconv_bwd_level_record_size(void);
+int mpnn_msconv_bwd_level_slots(const int *H, const int *W, const int *Cout, int count);
+int mpnn_msconv_bwd_level_prepare(const mpnn_bwd_member *members, int count, void *host_records);
+int mpnn_msconv_bwd_level(const mpnn_bwd_member *members, int count, const void *dev_records, void *stream);
 /* Number of 64-pixel tiles (upper bound of n_split) for a map, or MPNN_E_SHAPE. */
 int mpnn_wgrad_tiles(int n, int H, int W);
 /* dst[i] = sum_{s<n_split} src[s*stride + i].  table: 6 ints per work item:

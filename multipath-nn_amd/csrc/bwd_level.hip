@@ -1,0 +1,188 @@
+// mpnn_msconv_bwd_level: one DEPENDENCY LEVEL of the backward pass as one launch.
+//
+// g(b, S) (block b, absolute scale S) is final once B(b+1, S) (dgrad-horz of the child block) and
+// B(b, S+1) (dgrad-vert of the coarser scale) have run, so the launches B(b, S) = {dgrad-horz, dgrad-vert,
+// weight gradients of g(b, S)} with equal (depth from the end) + (scales from the coarsest) do not depend
+// on each other: the 20 backward launches of the 8-block chain are 11 levels.  A level's small members
+// (4x4 / 8x8 maps: a few dozen workgroups that are nothing but their ~8 us prologue chain) run beside the
+// large one instead of after it.  Autodiff of layer_types.py:181-185 as in wgrad.hip; the bodies are the
+// same (conv_kernel.h, bwd_bodies.h).
+//
+// Members (<= MPNN_BWD_LEVEL_MAX) are records in DEVICE memory (a run-time index into a by-value argument
+// array would put the whole block in scratch); a workgroup finds its member from the first-workgroup table,
+// then its body as in bwd_scale_k.  The HOST decides how many workgroups every body gets (the caller's
+// budget: lib/_plan.py shares the resident slots of the variant between the members); nothing here is
+// sized implicitly.  One instantiation per set of map geometries present (GKMASK) and per set of
+// weight-gradient tile widths (OTMASK: bit 0 = 16-channel groups, bit 1 = 64-channel groups), so that a
+// level only pays the registers of the bodies it runs.
+#include "bwd_bodies.h"
+
+struct BwdRec { BwdScaleP q; int gk, wide, r0, r1; };
+struct BwdLevelQ { int n; int w0[MPNN_BWD_LEVEL_MAX]; };
+
+template <int GK, int OT>
+__device__ __forceinline__ void level_wgrad(const BwdRec *__restrict__ r, int l, char *smem) {
+    constexpr int GS = OT * 16 + 4;
+    const WgP w = r->q.w;
+    const int gxw = r->q.gxw, nchw = r->q.nchw;
+    const int rr = l / gxw, bx = l - rr * gxw;
+    const int chunk = rr % nchw, bz = rr / nchw;
+    f32x4 *tile = (f32x4 *)smem;
+    float *gt = (float *)(smem + 4 * WGeom<GK>::PS * 16);
+    float *cA = gt + 64 * GS;
+    if (chunk >= ((w.c.a.C + 15) >> 4)) wgrad_body<GK, OT, 1>(w, tile, gt, cA, bx, chunk, bz, gxw);
+    else                                 wgrad_body<GK, OT, 0>(w, tile, gt, cA, bx, chunk, bz, gxw);
+}
+
+template <int GK, int OTMASK>
+__device__ __forceinline__ void level_member(const BwdRec *__restrict__ r, int id, char *smem) {
+    const int gxh = r->q.gxh, gxv = r->q.gxv;
+    const int wh = r->q.gyh * gxh, wv = r->q.gyv * gxv;
+    if (id < wh) {
+        const ConvP p = r->q.h;
+        const int by = id / gxh, bx = id - by * gxh;
+        conv_body<GK, 1, 1, 4, 1, false, EPI_DGH_BN, 1>(p, bx, by, gxh, smem);
+    } else if (id < wh + wv) {
+        const ConvP p = r->q.v;
+        const int l = id - wh, by = l / gxv, bx = l - by * gxv;
+        conv_body<GK, 1, 1, 4, 1, false, EPI_DGV, 1>(p, bx, by, gxv, smem);
+    } else {
+        const int l = id - wh - wv;
+        if constexpr (OTMASK == 3) {
+            if (r->wide) level_wgrad<GK, 4>(r, l, smem);
+            else         level_wgrad<GK, 1>(r, l, smem);
+        } else if constexpr (OTMASK == 2) level_wgrad<GK, 4>(r, l, smem);
+        else level_wgrad<GK, 1>(r, l, smem);
+    }
+}
+
+template <int GK, int OTMASK> struct LevelSmem {
+    static constexpr int GS = (OTMASK & 2 ? 4 : 1) * 16 + 4;
+    static constexpr int CB = ConvSmem<GK, 4, 16, 1>::BYTES;
+    static constexpr int WB = 4 * WGeom<GK>::PS * 16 + 64 * GS * 4 + (128 * 3 + (OTMASK & 2 ? 4 : 1) * 16 * 5) * 4;
+    static constexpr int BYTES = CB > WB ? CB : WB;
+};
+template <int GKMASK, int OTMASK> struct LevelSmemAll {
+    static constexpr int A = (GKMASK & 1) ? LevelSmem<0, OTMASK>::BYTES : 0;
+    static constexpr int B = (GKMASK & 2) ? LevelSmem<1, OTMASK>::BYTES : 0;
+    static constexpr int C = (GKMASK & 4) ? LevelSmem<2, OTMASK>::BYTES : 0;
+    static constexpr int BYTES = A > B ? (A > C ? A : C) : (B > C ? B : C);
+};
+
+#ifndef MPNN_OCC_LEVEL
+#define MPNN_OCC_LEVEL 3     // waves per SIMD of the levels without 64-channel weight-gradient groups
+#endif
+template <int GKMASK, int OTMASK>
+__global__ __launch_bounds__(256, (OTMASK & 2) ? 2 : MPNN_OCC_LEVEL) void bwd_level_k(const BwdRec *__restrict__ tab, const BwdLevelQ lq) {
+    __shared__ __attribute__((aligned(16))) char smem[LevelSmemAll<GKMASK, OTMASK>::BYTES];
+    const int id = blockIdx.x;
+    int m = 0, w0 = 0;
+#pragma unroll
+    for (int k = 1; k < MPNN_BWD_LEVEL_MAX; ++k)
+        if (k < lq.n && id >= lq.w0[k]) { m = k; w0 = lq.w0[k]; }
+    const BwdRec *__restrict__ r = tab + m;
+    const int gk = r->gk;
+    trace_note(11, m + 1);
+    if constexpr ((GKMASK & 1) != 0) { if (gk == 0) { level_member<0, OTMASK>(r, id - w0, smem); return; } }
+    if constexpr ((GKMASK & 2) != 0) { if (gk == 1) { level_member<1, OTMASK>(r, id - w0, smem); return; } }
+    if constexpr ((GKMASK & 4) != 0) { if (gk == 2) { level_member<2, OTMASK>(r, id - w0, smem); return; } }
+}
+
+// ------------------------------- host ----------------------------------------
+typedef void (*LevelKern)(const BwdRec *, const BwdLevelQ);
+template <int OTMASK>
+static LevelKern level_kernel_ot(int gkmask) {
+    switch (gkmask) {
+        case 1: return bwd_level_k<1, OTMASK>;
+        case 2: return bwd_level_k<2, OTMASK>;
+        case 3: return bwd_level_k<3, OTMASK>;
+        case 4: return bwd_level_k<4, OTMASK>;
+        case 5: return bwd_level_k<5, OTMASK>;
+        case 6: return bwd_level_k<6, OTMASK>;
+        case 7: return bwd_level_k<7, OTMASK>;
+    }
+    return nullptr;
+}
+static LevelKern level_kernel(int gkmask, int otmask) {
+    return (otmask & 2) ? level_kernel_ot<3>(gkmask) : level_kernel_ot<1>(gkmask);
+}
+
+static int geom_kind(int H, int W) {
+    if (W >= 16 && (W % 16) == 0 && (H % 4) == 0) return 0;
+    if (W == 8 && H == 8) return 1;
+    if (W == 4 && H == 4) return 2;
+    return -1;
+}
+
+int mpnn_trace_install_level(void *buf) { return mpnn_trace_install(buf); }
+
+extern "C" int mpnn_msconv_bwd_level_record_size(void) { return (int)sizeof(BwdRec); }
+
+extern "C" int mpnn_msconv_bwd_level_slots(const int *H, const int *W, const int *Cout, int count) {
+    if (!H || !W || !Cout || count < 1 || count > MPNN_BWD_LEVEL_MAX) return MPNN_E_ARG;
+    int gkmask = 0, otmask = 0;
+    for (int k = 0; k < count; ++k) {
+        const int gk = geom_kind(H[k], W[k]);
+        if (gk < 0 || (Cout[k] % 16)) return MPNN_E_SHAPE;
+        gkmask |= 1 << gk;
+        otmask |= (Cout[k] % 64) == 0 ? 2 : 1;
+    }
+    return resident_slots((const void *)level_kernel(gkmask, otmask), 0, 256, (otmask & 2) ? 2 : 0);
+}
+
+// records + first-workgroup table + kernel variant of a level; total = workgroups of the launch
+static int level_build(const mpnn_bwd_member *mem, int count, BwdRec *recs, BwdLevelQ &lq, int &gkmask, int &otmask, int &total) {
+    if (!mem || count < 1 || count > MPNN_BWD_LEVEL_MAX) return MPNN_E_ARG;
+    gkmask = otmask = total = 0;
+    lq.n = count;
+    for (int k = 0; k < count; ++k) {
+        const mpnn_bwd_member &m = mem[k];
+        if (!m.wgrad || m.wgrad->n <= 0) return MPNN_E_ARG;
+        BwdRec &r = recs[k];
+        r = BwdRec{};
+        int split = 1;
+        const int rc = mpnn_fill_bwd_scale(m.horz, m.vert, m.wgrad, r.q, split);
+        if (rc) return rc;
+        const mpnn_wgrad_args *w = m.wgrad;
+        r.gk = geom_kind(w->H, w->W);
+        if (r.gk < 0) return MPNN_E_SHAPE;
+        r.wide = (w->Cout % 64) == 0;
+        const int tiles = mpnn_wgrad_tiles(w->n, w->H, w->W);
+        auto clampx = [&](int g) { return g < 1 ? 1 : (g > tiles ? tiles : g); };
+        BwdScaleP &q = r.q;
+        q.gyh = m.horz ? q.h.Cout / 16 : 0;
+        q.gyv = m.vert ? q.v.Cout / 16 : 0;
+        q.gxh = m.horz ? clampx(m.wg_horz) : 0;
+        q.gxv = m.vert ? clampx(m.wg_vert) : 0;
+        q.h.n_tiles = q.v.n_tiles = tiles;
+        q.gxw = split;
+        q.nchw = ((q.w.c.a.C + 15) >> 4) + (q.w.c.v ? ((q.w.c.Cv + 15) >> 4) : 0);
+        const int gyw = q.nchw * (w->Cout / (r.wide ? 64 : 16));
+        lq.w0[k] = total;
+        total += q.gyh * q.gxh + q.gyv * q.gxv + gyw * q.gxw;
+        gkmask |= 1 << r.gk;
+        otmask |= r.wide ? 2 : 1;
+    }
+    return 0;
+}
+
+extern "C" int mpnn_msconv_bwd_level_prepare(const mpnn_bwd_member *members, int count, void *host_records) {
+    if (!host_records) return MPNN_E_ARG;
+    BwdLevelQ lq = {};
+    int gkmask, otmask, total;
+    return level_build(members, count, (BwdRec *)host_records, lq, gkmask, otmask, total);
+}
+
+extern "C" int mpnn_msconv_bwd_level(const mpnn_bwd_member *members, int count, const void *dev_records, void *stream) {
+    if (!dev_records) return MPNN_E_ARG;
+    BwdRec recs[MPNN_BWD_LEVEL_MAX];
+    BwdLevelQ lq = {};
+    int gkmask, otmask, total;
+    const int rc = level_build(members, count, recs, lq, gkmask, otmask, total);
+    if (rc) return rc;
+    LevelKern kern = level_kernel(gkmask, otmask);
+    if (!kern) return MPNN_E_SHAPE;
+    hipLaunchKernelGGL(kern, dim3(total), dim3(256), 0, (hipStream_t)stream, (const BwdRec *)dev_records, lq);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,6 +1,7 @@
 // Shared device helpers for the multipath-nn MI355X (gfx950) kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "mpnn_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -18,12 +19,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // device at once (occupancy x compute units), cached per kernel instantiation.  The persistent grids
 // are sized to this: workgroups beyond it only start when earlier ones exit, which serialises the
 // bodies of a fused launch (measured: the weight-gradient workgroups of bwd_scale started 8-13 us late).
-static int resident_slots(const void *kernel, int dyn_lds, int threads = 256) {
-    struct Entry { const void *fn; int lds, slots; };            // (a kernel is always queried with the same block size)
+static int resident_slots(const void *kernel, int dyn_lds, int threads = 256, int max_per_cu = 0) {
+    struct Entry { const void *fn; int lds, slots, cap; };            // (a kernel is always queried with the same block size)
     static Entry cache[64];
     static int n_cached = 0;
     for (int i = 0; i < n_cached; ++i)
-        if (cache[i].fn == kernel && cache[i].lds == dyn_lds) return cache[i].slots;
+        if (cache[i].fn == kernel && cache[i].lds == dyn_lds && cache[i].cap == max_per_cu) return cache[i].slots;
     int per_cu = 0, dev = 0, cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, (size_t)dyn_lds) != hipSuccess || per_cu < 1)
         per_cu = 2;
@@ -41,8 +42,9 @@ static int resident_slots(const void *kernel, int dyn_lds, int threads = 256) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
+    if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;      // (the caller wants fewer, larger shares)
     const int slots = per_cu * cus;
-    if (n_cached < 64) cache[n_cached++] = Entry{kernel, dyn_lds, slots};
+    if (n_cached < 64) cache[n_cached++] = Entry{kernel, dyn_lds, slots, max_per_cu};
     return slots;
 }
 

@@ -21,212 +21,16 @@
 // forward conv but with plane stride == 1 mod 8 slots so that the 16 channels x
 // 2 pixel groups of a ds_read_b32 wave-half fall on 32 distinct banks; the g
 // tile as [64 pixels][OT*16 + 4].
-#include <type_traits>
-#ifndef MPNN_WG_SETS
-#define MPNN_WG_SETS 1
-#endif
-#include "conv_kernel.h"
-
-struct WgP {
-    ConvP c;                 // a, v, Cv, n, H, W, Cout
-    const float *g;
-    const float *g_s;  mpnn_act g_bn;  const double *g_red;  int g_nslot;  int g_on;   // g = bn_bwd_apply(dz) on load
-    float *dwa, *dwv, *db;   // partial-sum destinations of split 0
-    long split_stride;       // floats between consecutive splits' destinations
-    int n_tiles;
-};
-
-template <int GK> struct WGeom;
-template <> struct WGeom<0> { static constexpr int PS = 113; };
-template <> struct WGeom<1> { static constexpr int PS = 113; };
-template <> struct WGeom<2> { static constexpr int PS = 145; };
-
-template <int GK, int OT>
-__device__ __forceinline__ void load_g(f32x4 *gr, f32x4 *gs, const WgP &p, int n0, int y0, int x0, int co0, int tid) {
-#pragma unroll
-    for (int k = 0; k < OT; ++k) {
-        const int i = tid + k * 256;                   // 64 * OT * 4 items
-        const int q = i % (OT * 4), pi = i / (OT * 4);
-        int img, ty, tx;
-        mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
-        const int n = n0 + img;
-        // unconditional loads from a clamped address (no branch -> no vmcnt wait between items)
-        const bool live = n < p.c.n;
-        const size_t off = live ? (((size_t)n * p.c.H + y0 + ty) * p.c.W + x0 + tx) * p.c.Cout + co0 + q * 4 : 0;
-        gr[k] = *(const f32x4 *)(p.g + off);          // raw: out-of-range images are zeroed when stored
-        if (p.g_on) gs[k] = *(const f32x4 *)(p.g_s + off);    // (uniform)
-    }
-}
-
-template <int GK, int OT, int PART>
-__device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt, float *cA,
-                                           const int bx, const int by, const int bz, const int gx) {
-    using G = Geom<GK>;
-    constexpr int PS = WGeom<GK>::PS, R = G::R, HR = G::TH + 2;
-    constexpr int GS = OT * 16 + 4;                  // g tile row stride (floats)
-    constexpr int XN = XItems<GK>::N;
-    const ConvP &c = p.c;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably wave-uniform
-    const int g = lane >> 4, li = lane & 15;
-    const int nchA = (c.a.C + 15) >> 4;
-    constexpr int part = PART;
-    const int ch = part ? by - nchA : by;
-    const int C = part ? c.Cv : c.a.C;
-    const int co0 = bz * OT * 16;
-    int np = (C - ch * 16 + 3) >> 2;
-    np = np > 4 ? 4 : np;
-    const bool bias_wave = wid == 1 && by == 0;           // slot ti = 2 of wave 1 is tap 9: unused
-    trace_stamp(0);
-
-    f32x4 acc[3][OT];
-#pragma unroll
-    for (int ti = 0; ti < 3; ++ti)
-#pragma unroll
-        for (int nt = 0; nt < OT; ++nt) acc[ti][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float *tf = (const float *)tile;
-    const int a_lane = (li >> 2) * PS * 4 + (li & 3);      // plane + component of channel li
-    const float one_hot = li == 0 ? 1.f : 0.f;
-    // Tap slots of this wave: {wid, wid+4, wid+8}; slot 2 of waves 1-3 has no tap (9..11): it runs a
-    // clamped duplicate whose result is dropped (wave 1 / chunk 0 uses it for the bias gradient), so
-    // the hot loop is branch-free and every wave issues the same 3 MFMAs per step.
-    int tap_off[3];
-#pragma unroll
-    for (int ti = 0; ti < 3; ++ti) {
-        const int tap = min(wid + 4 * ti, 8);
-        tap_off[ti] = (tap / 3) * R + (tap % 3);
-    }
-
-    if (part == 0 && c.a.mode != MPNN_ACT_IDENTITY) {
-        for (int cc = tid; cc < c.a.C; cc += 256) {
-            const BnC k = bn_coef(c.a, cc);
-            cA[cc * 3] = k.m; cA[cc * 3 + 1] = k.gamma * k.rstd; cA[cc * 3 + 2] = k.beta;
-        }
-    }
-
-    float *cG = cA + 128 * 3;                        // [OT*16][5]: BatchNorm-backward coefficients of this cout group
-    if (p.g_on) {
-        const double inv = 1.0 / (double)p.g_bn.cnt;
-        for (int cc = tid - 128; cc >= 0 && cc < OT * 16; cc += 256) {     // waves 2-3: beside the table above
-            const int co = co0 + cc;
-            const BnC k = bn_coef(p.g_bn, co);
-            float *e = cG + cc * 5;
-            e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
-            double r0, r1;
-            slot_sum2(p.g_red, 2 * c.Cout, co, c.Cout + co, p.g_nslot, r0, r1);
-            e[3] = (float)(r0 * inv); e[4] = (float)(r1 * inv);
-        }
-    }
-
-    __syncthreads();
-    trace_stamp(1);
-    // Two register sets, prefetch distance two tiles: while tile t is in LDS under the MFMAs, tile
-    // t + gx is landed / landing in the other set and tile t + 2 gx is requested into the set that was
-    // just written to LDS.  (With one set the loop waited a full memory round trip per tile.)
-    // (64-channel groups, OT > 1, keep one set: two would not fit the register file.)
-    constexpr int NS = OT == 1 ? MPNN_WG_SETS : 1;   // register sets = prefetch distance in tiles
-    f32x4 xrS[NS][XN][1], grS[NS][OT], gsS[NS][OT];
-    int on0[NS], oy0[NS], ox0[NS];
-    auto request = [&](auto sel, int t) {
-        constexpr int S = decltype(sel)::value;
-        tile_origin<GK>(c, t, on0[S], oy0[S], ox0[S]);
-        load_x<GK, PART, 1>(xrS[S], c, on0[S], oy0[S], ox0[S], ch * 16, np, tid);
-        load_g<GK, OT>(grS[S], gsS[S], p, on0[S], oy0[S], ox0[S], co0, tid);
-    };
-    auto tile_step = [&](auto sel, int t) {
-        constexpr int S = decltype(sel)::value;
-        f32x4 (*xr)[1] = xrS[S];
-        f32x4 *gr = grS[S], *gs = gsS[S];
-        const int o_n0 = on0[S];
-        lds_barrier();                                 // previous tile's LDS reads are done
-        store_x<GK, PS, PART, 1>(tile, xr, c, cA, on0[S], oy0[S], ox0[S], ch * 16, np, tid);
-#pragma unroll
-        for (int k = 0; k < OT; ++k) {
-            const int i = tid + k * 256;
-            const int q = i % (OT * 4), pi = i / (OT * 4);
-            int img, ty, tx;
-            mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (o_n0 + img < c.n) {                    // (out-of-range images stay exactly zero)
-                v = gr[k];
-                if (p.g_on) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float *e = cG + (q * 4 + j) * 5;
-                        const float xh = (gs[k][j] - e[0]) * e[1];
-                        v[j] = e[2] * (v[j] - e[3] - xh * e[4]);
-                    }
-                }
-            }
-            *(f32x4 *)(gt + pi * GS + q * 4) = v;
-        }
-        lds_barrier();
-        if (t == bx) trace_stamp(2);
-        if (t + NS * gx < p.n_tiles) request(sel, t + NS * gx);      // flies under NS tiles of MFMAs
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            float bq[4][OT], aq[4][3];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int img, ty, tx;
-                mtile_pix<GK>(kc, 4 * g + j, img, ty, tx);
-                const int slot = (img * HR + ty) * R + tx;
-#pragma unroll
-                for (int nt = 0; nt < OT; ++nt) bq[j][nt] = gt[(kc * 16 + 4 * g + j) * GS + nt * 16 + li];
-#pragma unroll
-                for (int ti = 0; ti < 3; ++ti) aq[j][ti] = tf[(slot + tap_off[ti]) * 4 + a_lane];
-                if (bias_wave) aq[j][2] = one_hot;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int ti = 0; ti < 3; ++ti)
-#pragma unroll
-                    for (int nt = 0; nt < OT; ++nt)
-                        acc[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j][ti], bq[j][nt], acc[ti][nt], 0, 0, 0);
-        }
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, NS - 1>;
-    if (bx < p.n_tiles) request(S0{}, bx);
-    if (NS == 2 && bx + gx < p.n_tiles) request(S1{}, bx + gx);
-    for (int t = bx; t < p.n_tiles; t += NS * gx) {
-        tile_step(S0{}, t);
-        if (NS == 2 && t + gx < p.n_tiles) tile_step(S1{}, t + gx);
-    }
-
-    trace_stamp(4);
-    mfma_drain();
-    // D layout: col = li (cout), row = g*4 + r (input channel of the chunk).
-    const size_t soff = (size_t)bx * p.split_stride;
-    float *dw = (part ? p.dwv : p.dwa) + soff;
-#pragma unroll
-    for (int ti = 0; ti < 3; ++ti) {
-        const int tap = wid + 4 * ti;
-        if (tap >= 9) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cin = ch * 16 + g * 4 + r;
-            if (cin >= C) continue;
-#pragma unroll
-            for (int nt = 0; nt < OT; ++nt)
-                dw[((size_t)tap * C + cin) * c.Cout + co0 + nt * 16 + li] = acc[ti][nt][r];
-        }
-    }
-    if (bias_wave && g == 0) {
-#pragma unroll
-        for (int nt = 0; nt < OT; ++nt) p.db[soff + co0 + nt * 16 + li] = acc[2][nt][0];
-    }
-    trace_stamp(5);
-    trace_note(6, 8); trace_note(7, bx < p.n_tiles ? (p.n_tiles - 1 - bx) / gx + 1 : 0);
-}
+#include "bwd_bodies.h"
 
 template <int GK, int OT>
 __global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
     constexpr int PS = WGeom<GK>::PS, GS = OT * 16 + 4;
-    __shared__ f32x4 tile[4 * PS];
-    __shared__ float gt[64 * GS];
-    __shared__ float cA[128 * 3 + OT * 16 * 5];
+    // one arena: the tile and g buffers are contiguous (the 16-channel body's final reduction uses them as one)
+    __shared__ __attribute__((aligned(16))) char smem[4 * PS * 16 + 64 * GS * 4 + (128 * 3 + OT * 16 * 5) * 4];
+    f32x4 *tile = (f32x4 *)smem;
+    float *gt = (float *)(smem + 4 * PS * 16);
+    float *cA = gt + 64 * GS;
     if ((int)blockIdx.y >= ((p.c.a.C + 15) >> 4)) wgrad_body<GK, OT, 1>(p, tile, gt, cA, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
     else                                           wgrad_body<GK, OT, 0>(p, tile, gt, cA, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
@@ -240,10 +44,6 @@ __global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
 //   [gyh, gyh+gyv)      dgrad-vert tiles
 //   [gyh+gyv, ...)      wgrad (chunk, 16-cout group) pairs
 // ---------------------------------------------------------------------------
-struct BwdScaleP {
-    ConvP h, v;  WgP w;
-    int gyh, gyv, gxh, gxv, gxw, nchw;           // nchw = channel chunks (A + V) of the wgrad
-};
 
 #ifndef MPNN_OCC_BWD
 #define MPNN_OCC_BWD 3       // waves per SIMD asked of the narrow backward kernel (4 = 128 VGPRs spilled 26-42 registers)
@@ -364,7 +164,9 @@ extern "C" int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad
     const bool hv = has_vert != 0;
     const void *k = gk == 0 ? (const void *)bwd_scale_kernel<0>(wide, deep, hv)
                   : gk == 1 ? (const void *)bwd_scale_kernel<1>(wide, deep, hv) : (const void *)bwd_scale_kernel<2>(wide, deep, hv);
-    return resident_slots(k, 0);
+    // 64-channel weight-gradient groups: two workgroups per CU (the deep layers have at most 256 input-gradient
+    // workgroups; a third resident workgroup per CU only buys a finer weight-gradient split, i.e. more slabs)
+    return resident_slots(k, 0, 256, wide ? 2 : 0);
 }
 
 template <int GK>
@@ -384,7 +186,7 @@ static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hip
     void (*kern)(const BwdScaleP) = bwd_scale_kernel<GK>(wide, deep, has_v);
     // Fit the grid to what is resident at once: the weight-gradient rows keep their split x rows
     // workgroups (the slabs are sized for them), the two dgrad bodies share the rest by work.
-    const long slots = resident_slots((const void *)kern, 0);
+    const long slots = resident_slots((const void *)kern, 0, 256, wide ? 2 : 0);
     long avail = slots - (long)split * gyw;
     if (avail < slots / 4) avail = slots / 4;
     const long units = (q.w.c.Cout + 15) >> 4;          // g's 16-channel chunks: units per dgrad tile
@@ -404,12 +206,10 @@ static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hip
     return 0;
 }
 
-extern "C" int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *h, const mpnn_dgrad_vert_args *v,
-                                     const mpnn_wgrad_args *w, void *stream) {
+int mpnn_fill_bwd_scale(const mpnn_dgrad_horz_args *h, const mpnn_dgrad_vert_args *v, const mpnn_wgrad_args *w,
+                        BwdScaleP &q, int &split) {
     if (!w) return MPNN_E_ARG;
-    if (w->n <= 0) return 0;
-    BwdScaleP q = {};
-    int split = 1, rc = fill_wgrad(w, q.w, split);
+    int rc = fill_wgrad(w, q.w, split);
     if (rc) return rc;
     if (w->Cout % 16) return MPNN_E_SHAPE;
     if (h) {
@@ -421,6 +221,17 @@ extern "C" int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *h, const mpnn_d
         if ((rc = mpnn_fill_dgrad_vert(v, q.v))) return rc;
         if (v->H != w->H || v->W != w->W || v->n != w->n || (v->Cout % 16) || (v->Cg & 3)) return MPNN_E_ARG;
     }
+    return 0;
+}
+
+extern "C" int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *h, const mpnn_dgrad_vert_args *v,
+                                     const mpnn_wgrad_args *w, void *stream) {
+    if (!w) return MPNN_E_ARG;
+    if (w->n <= 0) return 0;
+    BwdScaleP q = {};
+    int split = 1;
+    const int rc = mpnn_fill_bwd_scale(h, v, w, q, split);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (w->W >= 16 && (w->W % 16) == 0 && (w->H % 4) == 0) return bwd_scale_launch<0>(q, h, v, split, st);
     if (w->W == 8 && w->H == 8) return bwd_scale_launch<1>(q, h, v, split, st);

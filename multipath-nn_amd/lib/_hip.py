@@ -68,6 +68,14 @@ class WgradArgs(C.Structure):
                 ('split_stride', C.c_long), ('n', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cout', C.c_int), ('n_split', C.c_int)]
 
 
+BWD_LEVEL_MAX = 4              # MPNN_BWD_LEVEL_MAX: members of one mpnn_msconv_bwd_level launch
+
+
+class BwdMember(C.Structure):
+    _fields_ = [('horz', C.POINTER(DgradHorzArgs)), ('vert', C.POINTER(DgradVertArgs)), ('wgrad', C.POINTER(WgradArgs)),
+                ('wg_horz', C.c_int), ('wg_vert', C.c_int)]
+
+
 class LinFwdArgs(C.Structure):
     _fields_ = [('a', Act), ('HW', C.c_int), ('w', P * 2), ('b', P * 2), ('y', P * 2), ('M', C.c_int * 2),
                 ('k_cpt', P), ('alpha_cpt', C.c_float), ('extra_col', C.c_int * 2), ('n', C.c_int),
@@ -148,6 +156,10 @@ _SIGS = {
     'mpnn_msconv_dgrad_pair': [C.POINTER(DgradHorzArgs), C.POINTER(DgradVertArgs), P],
     'mpnn_msconv_wgrad': [C.POINTER(WgradArgs), P],
     'mpnn_msconv_bwd_scale': [C.POINTER(DgradHorzArgs), C.POINTER(DgradVertArgs), C.POINTER(WgradArgs), P],
+    'mpnn_msconv_bwd_level_record_size': [],
+    'mpnn_msconv_bwd_level_slots': [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int],
+    'mpnn_msconv_bwd_level_prepare': [C.POINTER(BwdMember), C.c_int, P],
+    'mpnn_msconv_bwd_level': [C.POINTER(BwdMember), C.c_int, P, P],
     'mpnn_wgrad_tiles': [C.c_int, C.c_int, C.c_int],
     'mpnn_slab_reduce': [P, P, P, C.c_int, P],
     'mpnn_lin_fwd': [P, C.c_int, C.c_int, P],

@@ -87,6 +87,7 @@ class Engine:
         self.use_graph = bool(int(os.environ.get('MPNN_GRAPH', '1')))     # hipGraph replay of the step (0: eager launches)
         self.multi_stream = bool(int(os.environ.get('MPNN_STREAMS', '0')))
         self.group_fwd = bool(int(os.environ.get('MPNN_FWD_GROUP', '1')))   # wavefront-grouped forward launches
+        self.bwd_levels = bool(int(os.environ.get('MPNN_BWD_LEVELS', '1')))  # one backward launch per dependency level
         self._streams = []
         self._event_keep = []
         self.n_streams = 1
@@ -513,6 +514,126 @@ class Engine:
         want = min(want, max(1, (12 << 20) // w_bytes))         # keep a layer's slab under ~12 MB
         return max(1, min(tiles, want))
 
+    # ------------------------------------------------------------------ backward schedule
+    def _bwd_deps(self, b, i):
+        """(block, scale) triples B(.) that must have run before B(b, i) = {dgrad-horz, dgrad-vert, weight gradients
+        of g(b, i)}: the coarser scale of the block (its dgrad-vert turns dz(b, i) into g(b, i)), the child blocks'
+        launches at this scale (their dgrad-horz writes dz(b, i)), and -- because the dgrad-vert of B(b, i) converts
+        dz(b, i-1) into g(b, i-1) IN PLACE -- the child blocks' launches at the finer scale as well."""
+        deps = []
+        if i < b.L - 1:
+            deps.append((b, i + 1))
+        for c in b.children:
+            for j, src in enumerate(c.in_map):
+                if src == i or (src == i - 1 and i > 0 and b.has_dz[i - 1]):
+                    deps.append((c, j))
+        return deps
+
+    def _bwd_schedule(self, order, n):
+        """Launch groups of the backward pass: [[((kb, b, i), budget), ...], ...] in execution order.  Triples of one
+        dependency level run as ONE launch (mpnn_msconv_bwd_level) when a kernel variant covers their shapes, they
+        write different maps (tree nets: siblings accumulate into one parent map -> consecutive launches) and there
+        are at most MPNN_BWD_LEVEL_MAX of them; budget = workgroups of each body (None: a plain mpnn_msconv_bwd_scale
+        launch, which sizes itself)."""
+        level = {}
+        for kb, b, i in order:                               # (a topological order)
+            level[(id(b), i)] = 1 + max([level[(id(d), j)] for d, j in self._bwd_deps(b, i)], default=-1)
+        by_level = {}
+        for m in order:
+            by_level.setdefault(level[(id(m[1]), m[2])], []).append(m)
+        groups = []
+        for d in sorted(by_level):
+            pend = list(by_level[d])
+            while pend:
+                grp, targets, rest = [], set(), []
+                for m in pend:
+                    kb, b, i = m
+                    tgt = (id(b.parent), b.in_map[i]) if b.parent is not None else None
+                    if len(grp) < _hip.BWD_LEVEL_MAX and (tgt is None or tgt not in targets):
+                        grp.append(m)
+                        targets.add(tgt)
+                    else:
+                        rest.append(m)
+                pend = rest
+                bud = self._level_budget(grp, n) if len(grp) > 1 else None
+                if bud is None:
+                    groups += [[(m, None)] for m in grp]
+                else:
+                    groups.append(list(zip(grp, bud)))
+        return groups
+
+    # Budget model of a level launch: relative latency of one work item of a body (a dgrad unit = a 16-channel chunk
+    # of g for one 64-pixel tile and one 16-channel output row; a weight-gradient tile), from the phase traces
+    # (profiles/): dgrad-vert units carry the max-pool / BatchNorm-backward epilogue, 64-channel weight-gradient
+    # groups four times the MFMAs of 16-channel ones.
+    _LAT = dict(h=1.0, v=1.4, w1=1.0, w4=2.6)
+
+    def _level_budget(self, grp, n):
+        """Workgroups of every body of a level launch: the assignment that minimises the longest serial chain
+        (items per workgroup x item latency) over all bodies with everything resident at once -- small members get
+        (nearly) one item per workgroup, the large member the rest.  None: no kernel variant covers the shapes."""
+        lib = self.lib
+        H = (C.c_int * len(grp))(*[b.H[i] for _, b, i in grp])
+        W = (C.c_int * len(grp))(*[b.W[i] for _, b, i in grp])
+        Co = (C.c_int * len(grp))(*[b.C[i] for _, b, i in grp])
+        slots = lib.mpnn_msconv_bwd_level_slots(H, W, Co, len(grp))
+        if slots <= 0:
+            return None
+        bodies = []                                          # (member, kind, rows, tiles, latency per item)
+        for k, (kb, b, i) in enumerate(grp):
+            tiles = lib.mpnn_wgrad_tiles(n, b.H[i], b.W[i])
+            units = b.C[i] // 16
+            if b.parent is not None:
+                bodies.append((k, 'h', b.parent.C[b.in_map[i]] // 16, tiles, self._LAT['h'] * units))
+            if i > 0:
+                bodies.append((k, 'v', b.C[i - 1] // 16, tiles, self._LAT['v'] * units))
+            ot = 4 if b.C[i] % 64 == 0 else 1
+            nch = (b.Cin[i] + 15) // 16 + ((b.C[i - 1] + 15) // 16 if i > 0 else 0)
+            bodies.append((k, 'w', nch * (b.C[i] // (16 * ot)), tiles, self._LAT['w%d' % ot]))
+        if sum(rows for _, _, rows, _, _ in bodies) > slots:
+            return None
+
+        def fit(T):                                          # workgroups per row of each body for a chain of at most T
+            gx = []
+            for _, _, rows, tiles, lat in bodies:
+                per = int(T / lat + 1e-9)
+                if per < 1:
+                    return None
+                gx.append(-(-tiles // per))
+            return gx if sum(g * body[2] for g, body in zip(gx, bodies)) <= slots else None
+        cands = sorted({lat * j for _, _, _, tiles, lat in bodies for j in range(1, tiles + 1)})
+        lo, hi = 0, len(cands) - 1
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if fit(cands[mid]) is not None:
+                hi = mid
+            else:
+                lo = mid + 1
+        gx = fit(cands[lo])
+        if gx is None:
+            return None
+        # left-over slots: to the bodies with the longest chain
+        used = sum(g * body[2] for g, body in zip(gx, bodies))
+        while True:
+            cand = [q for q in range(len(gx)) if gx[q] < bodies[q][3] and used + bodies[q][2] <= slots]
+            if not cand:
+                break
+            q = max(cand, key=lambda q: -(-bodies[q][3] // gx[q]) * bodies[q][4])
+            gx[q] += 1
+            used += bodies[q][2]
+        if os.environ.get('MPNN_PLAN_DEBUG'):
+            print('level budget: %d slots, chain %.1f; ' % (slots, cands[lo]) + '; '.join(
+                'm%d %s rows %d tiles %d -> gx %d (%d wgs, %d items/wg)' % (k, kind, rows, tiles, g, g * rows, -(-tiles // g))
+                for (k, kind, rows, tiles, lat), g in zip(bodies, gx)))
+        out = [dict(gxh=0, gxv=0, split=1) for _ in grp]
+        for (k, kind, rows, tiles, lat), g in zip(bodies, gx):
+            if kind == 'w':
+                kb, b, i = grp[k]
+                w_bytes = 4 * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
+                g = max(1, min(g, max(1, (12 << 20) // w_bytes)))      # keep a layer's slab under ~12 MB
+            out[k]['gxh' if kind == 'h' else 'gxv' if kind == 'v' else 'split'] = int(g)
+        return out
+
     def program(self, mode, n, routed=False):
         """Launch lists of one (mode, batch size).  routed ('ev' only): the routed evaluation -- every
         block runs on the sample list its parent's router produced on the device (see _program_ev)."""
@@ -522,7 +643,7 @@ class Engine:
             # hipStreamEndCapture), and the DAG schedule has no bucket boundaries to overlap the collectives with
             raise NotImplementedError('data-parallel training runs on the single-stream schedule (MPNN_STREAMS=0)')
         dp = mode == 'tr' and self.allreduce is not None
-        key = (mode, n, self.multi_stream, self.group_fwd, routed, dp)
+        key = (mode, n, self.multi_stream, self.group_fwd, routed, dp, self.bwd_levels)
         if key in self._progs:
             return self._progs[key]
         self._ensure_capacity(n, mode == 'tr')
@@ -722,7 +843,8 @@ class Engine:
             return prog
 
         # ---- backward ----
-        slab_plan = dict(size=0, table=[], ptrs=[])
+        slab_plan = dict(size=0)
+        level_fix = []
         if n_exit:
             bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
             bwd.append(call(lib.mpnn_lin_bwd_rs if n <= 512 else lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
@@ -730,14 +852,19 @@ class Engine:
             bwd.append(marker('bucket', 'exit'))       # head + router gradients are final: their all-reduce starts here
         bwd.append(marker('fork'))
         dz_written = set()
-        mid_items = None
-        for kb, b in enumerate(reversed(self.blocks)):
+        slab_members = []                                   # (is_cut_block, table rows, [(args, field, offset)])
+        use_levels = self.bwd_levels and not self.multi_stream
+        cut_kb = self.dp_cut_block if dp else None
+
+        def make_block(kb, b):
+            """Argument builders of one block's backward launches (bound to THIS block)."""
             cp = b.conv.params
             L1 = b.L - 1
+            pre = []
             # coarsest scale without a child block: its dy is the exit's dX alone
             if not b.children and (self.multi_stream or not b.has_exit):
                 ctx = self._bn_ctx(b, L1, n, with_red=False)
-                bwd.append(call(lib.mpnn_bn_bwd_reduce, 'bn_bwd_reduce', b.dx.data_ptr(), C.byref(ctx),
+                pre.append(call(lib.mpnn_bn_bwd_reduce, 'bn_bwd_reduce', b.dx.data_ptr(), C.byref(ctx),
                                 b.dzg[L1].data_ptr(), self.dred[b.sum_off[L1]:].data_ptr(),
                                 n * b.H[L1] * b.W[L1], stream=sid[b.H[L1]]))
             # g of the coarsest scale = BatchNorm backward of dz: its own launch in the multi-stream
@@ -745,7 +872,7 @@ class Engine:
             g_ctx = None
             if self.multi_stream:
                 ctx = self._bn_ctx(b, L1, n)
-                bwd.append(call(lib.mpnn_bn_bwd_apply, 'bn_bwd_apply', b.dzg[L1].data_ptr(), C.byref(ctx),
+                pre.append(call(lib.mpnn_bn_bwd_apply, 'bn_bwd_apply', b.dzg[L1].data_ptr(), C.byref(ctx),
                                 n * b.H[L1] * b.W[L1], stream=sid[b.H[L1]], records=Gn(b, L1)))
             else:
                 g_ctx = C.pointer(self._bn_ctx(b, L1, n))
@@ -785,9 +912,7 @@ class Engine:
                 keep.append(a)
                 return a
 
-            fl_v = lambda i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * b.C[i - 1]
-            fl_h = lambda i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * b.parent.C[b.in_map[i]]
-            def wgrad_args(i):
+            def wgrad_args(i, split=None):
                 a = _hip.WgradArgs()
                 a.a = self._act_of_input(b, i, n, act_mode)
                 pa = getattr(cp, 'w_horz_%i' % i)
@@ -799,7 +924,8 @@ class Engine:
                 if i == L1 and g_ctx is not None:
                     a.g_ctx = g_ctx
                 a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
-                split = self._wsplit(b, i, n, fused=not self.multi_stream)
+                if split is None:
+                    split = self._wsplit(b, i, n, fused=not self.multi_stream)
                 a.n_split = split
                 if split == 1:
                     a.dwa, a.db = pa.grad.data_ptr(), pb.grad.data_ptr()
@@ -808,68 +934,120 @@ class Engine:
                 else:
                     sizes = [pa.size, pv.size if pv is not None else 0, pb.size]
                     stride = (sum(sizes) + 3) // 4 * 4
-                    base = slab_plan['size']
+                    off = slab_plan['size']
                     slab_plan['size'] += split * stride
-                    off = base
+                    rows, ptrs = [], []
                     for prm, sz in zip((pa, pv, pb), sizes):
                         if prm is None:
                             continue
                         item = _hip.slab_item_size(split)
                         for k in range(0, sz, item):
-                            slab_plan['table'] += [off + k, prm.offset + k, min(item, sz - k), split, stride, 0]
-                        slab_plan['ptrs'].append((a, {id(pa): 'dwa', id(pb): 'db'}.get(id(prm), 'dwv'), off))
+                            rows += [off + k, prm.offset + k, min(item, sz - k), split, stride, 0]
+                        ptrs.append((a, {id(pa): 'dwa', id(pb): 'db'}.get(id(prm), 'dwv'), off))
                         off += sz
+                    slab_members.append((cut_kb is not None and kb <= cut_kb, rows, ptrs))
                     a.split_stride = stride
                 keep.append(a)
                 return a
 
-            fl_w = lambda i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
-            if not self.multi_stream:
-                # One launch per scale, coarsest first: everything that consumes g(b,i) -- dgrad-horz,
-                # dgrad-vert (which produces g(b,i-1) for the next launch) and the weight gradients.
-                for i in range(L1, -1, -1):
+            return pre, vert_args, horz_args, wgrad_args
+
+        fl_v = lambda b, i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * b.C[i - 1]
+        fl_h = lambda b, i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * b.parent.C[b.in_map[i]]
+        fl_w = lambda b, i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
+        tag_b = lambda b, i: 'h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])
+        mid_pos = None                                      # index in bwd of the 'mid' slab reduction (filled in below)
+        if not self.multi_stream:
+            # One launch per (block, scale) -- dgrad-horz, dgrad-vert (which produces g(b,i-1)) and the weight
+            # gradients of g(b,i) -- or, with use_levels, one launch per DEPENDENCY LEVEL of those triples
+            # (_bwd_schedule): the reversed block order with scales coarsest first is a topological order.
+            order = [(kb, b, i) for kb, b in enumerate(reversed(self.blocks)) for i in range(b.L - 1, -1, -1)]
+            groups = self._bwd_schedule(order, n) if use_levels else [[(m, None)] for m in order]
+            fns = {kb: make_block(kb, b) for kb, b in enumerate(reversed(self.blocks))}
+            started = set()
+            last_cut = max([g for g, grp in enumerate(groups) for (kb, b, i), _ in grp if cut_kb is not None and kb <= cut_kb],
+                           default=None)
+            for g, grp in enumerate(groups):
+                for (kb, b, i), _ in grp:
+                    if kb not in started:
+                        started.add(kb)
+                        bwd.extend(fns[kb][0])
+                built = []
+                for (kb, b, i), bud in grp:
+                    pre, vert_args, horz_args, wgrad_args = fns[kb]
                     h = horz_args(i) if b.parent is not None else None
                     v = vert_args(i) if i > 0 else None
-                    fl = fl_w(i) + (fl_h(i) if h is not None else 0) + (fl_v(i) if v is not None else 0)
+                    w = wgrad_args(i, None if bud is None else bud['split'])
+                    fl = fl_w(b, i) + (fl_h(b, i) if h is not None else 0) + (fl_v(b, i) if v is not None else 0)
+                    built.append((h, v, w, bud, fl, tag_b(b, i)))
+                if len(built) == 1 and built[0][3] is None:
+                    h, v, w, _, fl, tag = built[0]
                     bwd.append(call(lib.mpnn_msconv_bwd_scale, 'bwd_scale',
                                     C.byref(h) if h is not None else None, C.byref(v) if v is not None else None,
-                                    C.byref(wgrad_args(i)), flops=fl,
-                                    tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])))
-                if dp and kb == self.dp_cut_block:
-                    first = len(slab_plan['table']) // 6
-                    if first:
-                        mid_items = (len(bwd), first)
-                        bwd.append(None)                      # mpnn_slab_reduce of the items so far (filled in below)
+                                    C.byref(w), flops=fl, tag=tag))
+                else:
+                    mem = (_hip.BwdMember * len(built))()
+                    for m, (h, v, w, bud, fl, tag) in zip(mem, built):
+                        m.horz = C.pointer(h) if h is not None else None
+                        m.vert = C.pointer(v) if v is not None else None
+                        m.wgrad = C.pointer(w)
+                        m.wg_horz, m.wg_vert = bud['gxh'], bud['gxv']
+                    rec_bytes = lib.mpnn_msconv_bwd_level_record_size()
+                    host = (C.c_char * (rec_bytes * len(built)))()
+                    keep.append(mem)
+                    # (the slab pointers inside the wgrad records are only known once every slab is laid out:
+                    # the records are prepared and uploaded after the loop)
+                    level_fix.append((mem, len(built), host, rec_bytes))
+                    dev_rec = torch.empty(rec_bytes * len(built), dtype=torch.uint8, device=self.dev)
+                    keep.append(dev_rec)
+                    level_fix[-1] += (dev_rec,)
+                    bwd.append(call(lib.mpnn_msconv_bwd_level, 'bwd_scale', mem, len(built), dev_rec.data_ptr(),
+                                    flops=sum(x[4] for x in built), tag=' | '.join(x[5] for x in built)))
+                if last_cut is not None and g == last_cut:
+                    if any(c for c, _, _ in slab_members):
+                        mid_pos = len(bwd)
+                        bwd.append(None)                      # mpnn_slab_reduce of the cut blocks' items (filled in below)
                     bwd.append(marker('bucket', 'mid'))
-            else:
+        else:
+            for kb, b in enumerate(reversed(self.blocks)):
+                pre, vert_args, horz_args, wgrad_args = make_block(kb, b)
+                bwd.extend(pre)
+                L1 = b.L - 1
                 for i in range(L1, 0, -1):
-                    bwd.append(call(lib.mpnn_msconv_dgrad_vert, 'dgrad_vert', C.byref(vert_args(i)), flops=fl_v(i),
+                    bwd.append(call(lib.mpnn_msconv_dgrad_vert, 'dgrad_vert', C.byref(vert_args(i)), flops=fl_v(b, i),
                                     tag='h%d %d->%d' % (b.H[i], b.C[i], b.C[i - 1]),
                                     stream=sid[b.H[i - 1]], waits=[Gn(b, i)], records=Gn(b, i - 1)))
                 if b.parent is not None:
                     for i in range(b.L):
-                        bwd.append(call(lib.mpnn_msconv_dgrad_horz, 'dgrad_horz', C.byref(horz_args(i)), flops=fl_h(i),
+                        bwd.append(call(lib.mpnn_msconv_dgrad_horz, 'dgrad_horz', C.byref(horz_args(i)), flops=fl_h(b, i),
                                         tag='h%d %d->%d' % (b.H[i], b.C[i], b.parent.C[b.in_map[i]]),
                                         stream=sid[b.H[i]]))
                 for i in range(b.L):
-                    bwd.append(call(lib.mpnn_msconv_wgrad, 'wgrad', C.byref(wgrad_args(i)), flops=fl_w(i),
-                                    tag='h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i]),
-                                    stream=wg_streams[i % 2], waits=[Gn(b, i)]))
+                    bwd.append(call(lib.mpnn_msconv_wgrad, 'wgrad', C.byref(wgrad_args(i)), flops=fl_w(b, i),
+                                    tag=tag_b(b, i), stream=wg_streams[i % 2], waits=[Gn(b, i)]))
         bwd.append(marker('join'))
         if slab_plan['size']:
             slab = torch.empty(slab_plan['size'], device=self.dev)
-            for a, field, off in slab_plan['ptrs']:
-                setattr(a, field, slab[off:].data_ptr())
-            tab = torch.tensor(slab_plan['table'], dtype=torch.int32, device=self.dev)
+            rows, first = [], 0
+            for want_cut in (True, False):                  # the cut blocks' items first: the 'mid' reduction takes a prefix
+                for is_cut, r, ptrs in slab_members:
+                    if is_cut == want_cut:
+                        rows += r
+                        for a, field, off in ptrs:
+                            setattr(a, field, slab[off:].data_ptr())
+                if want_cut:
+                    first = len(rows) // 6
+            tab = torch.tensor(rows, dtype=torch.int32, device=self.dev)
             keep += [slab, tab]
-            n_items, first = len(slab_plan['table']) // 6, 0
-            if mid_items is not None:
+            n_items = len(rows) // 6
+            if mid_pos is not None:
                 # data parallel: the conv gradients of the blocks the backward finished first are reduced
                 # from their slabs at the bucket boundary (their all-reduce then overlaps the rest of the
                 # backward pass); the launch that ends the backward takes the remaining items
-                pos, first = mid_items
-                bwd[pos] = call(lib.mpnn_slab_reduce, 'slab_reduce', slab.data_ptr(), self.G.data_ptr(),
-                                tab.data_ptr(), first)
+                bwd[mid_pos] = call(lib.mpnn_slab_reduce, 'slab_reduce', slab.data_ptr(), self.G.data_ptr(),
+                                    tab.data_ptr(), first)
+            else:
+                first = 0
             # slab reduction + BatchNorm finalisation (moving averages, dgamma/dbeta): one launch
             bwd.append(call(lib.mpnn_backward_finish, 'backward_finish', slab.data_ptr(), self.G.data_ptr(),
                             tab[6 * first:].data_ptr(), n_items - first, self.dsum.data_ptr(), self.dred.data_ptr(),
@@ -878,6 +1056,10 @@ class Engine:
             bwd.append(call(lib.mpnn_bn_finalize, 'bn_finalize', self.dsum.data_ptr(), self.dred.data_ptr(),
                             self.S.data_ptr(), self.G.data_ptr(), self.bn_table.data_ptr(), self.n_bn,
                             self.bn_decay, n))
+        # member records of the level launches: every pointer is final now
+        for mem, cnt, host, rec_bytes, dev_rec in level_fix:
+            _hip.check(lib.mpnn_msconv_bwd_level_prepare(mem, cnt, C.cast(host, C.c_void_p)), 'bwd_level records')
+            dev_rec.copy_(torch.frombuffer(bytearray(host.raw), dtype=torch.uint8))
         if dp:
             bwd.append(marker('bucket', 'end'))
         return prog

@@ -35,7 +35,7 @@ def test_ctypes_structs_match_the_c_layout():
     from lib import _hip
     pairs = [('mpnn_act', _hip.Act), ('mpnn_conv_fwd_args', _hip.ConvFwdArgs), ('mpnn_bn_ctx', _hip.BnCtx),
              ('mpnn_dgrad_horz_args', _hip.DgradHorzArgs), ('mpnn_dgrad_vert_args', _hip.DgradVertArgs),
-             ('mpnn_wgrad_args', _hip.WgradArgs), ('mpnn_lin_fwd_args', _hip.LinFwdArgs),
+             ('mpnn_wgrad_args', _hip.WgradArgs), ('mpnn_bwd_member', _hip.BwdMember), ('mpnn_lin_fwd_args', _hip.LinFwdArgs),
              ('mpnn_lin_bwd_args', _hip.LinBwdArgs), ('mpnn_exit_tail_args', _hip.ExitTailArgs),
              ('mpnn_exit_tail_bwd_args', _hip.ExitTailBwdArgs), ('mpnn_route_args', _hip.RouteArgs),
              ('mpnn_exit_ev_args', _hip.ExitEvArgs), ('mpnn_conv_nhwc_fwd_args', _hip.ConvNhwcFwdArgs),
@@ -58,7 +58,7 @@ def test_ctypes_structs_match_the_c_layout():
         assert nums[1:] == [getattr(cls, f).offset for f, _ in cls._fields_], cname
     for name, val in re.findall(r'#define (MPNN_\w+)\s+\(?(-?\d+)\)?', open(HEADER).read()):
         py = {'MPNN_BN_SLOTS': _hip.BN_SLOTS, 'MPNN_MAX_NODES': _hip.MAX_NODES, 'MPNN_MAX_SINKS': _hip.MAX_SINKS,
-              'MPNN_HYP_N': _hip.HYP_N, 'MPNN_HYP_TAU': _hip.HYP_TAU, 'MPNN_HYP_EPS': _hip.HYP_EPS,
+              'MPNN_HYP_N': _hip.HYP_N, 'MPNN_BWD_LEVEL_MAX': _hip.BWD_LEVEL_MAX, 'MPNN_HYP_TAU': _hip.HYP_TAU, 'MPNN_HYP_EPS': _hip.HYP_EPS,
               'MPNN_NET_CRITIC': _hip.NET_CRITIC, 'MPNN_ACT_BN_MOVING': _hip.ACT_BN_MOVING,
               'MPNN_SLAB_ITEM': _hip.SLAB_ITEM, 'MPNN_LIN_KSLICES': _hip.LIN_KSLICES, 'MPNN_SEG_INTS': _hip.SEG_INTS,
               'MPNN_LIN_RSPLIT': _hip.LIN_RSPLIT, 'MPNN_LIN_RS_TILE': _hip.LIN_RS_TILE}.get(name)

@@ -158,4 +158,25 @@ def test_product_matches_the_reference_graph_code(key):
     chk = trainable & ~zero_grad & (uscale[:, 0] > 0)
     worst = np.argsort(-np.where(chk, uerr, -1))[:5]
     print('%s: worst update errors (of the update scale): %s' % (key, [(params[i][0], float(uerr[i])) for i in worst]))
-    assert (uerr[chk] <= 2e-3).all(), (key, [(params[i][0], float(uerr[i])) for i in np.argwhere(chk & (uerr > 2e-3))[:, 0][:8]])
+    over = np.argwhere(chk & (uerr > 2e-3))[:, 0]
+    if len(over):
+        # The vectors come from a FREE float64 run: where the fp32 device decided a max-pool near-tie or a ReLU
+        # sign differently, the tensors downstream of that element legitimately differ.  Count those decisions
+        # (device vs the oracle's free run, which reproduces the vectors to 1e-9): without one, nothing may exceed.
+        from oracle.ref_net import RefNet
+        from test_net_parity import count_flips
+        ref = RefNet(net)
+        rng = np.random.RandomState(seed)
+        vals = {id(p): M.param_value(n_, p.shape, rng) for n_, p in params}
+        ref.load_params(vals)
+        kw = {}
+        if case['tau'] is not None:
+            kw['τ'] = case['tau']
+        if kc is not None:
+            kw['k_cpt'] = kc
+        free = ref.forward(x0, y, 'tr', **kw)
+        before_t = {id(p): torch.tensor(np.asarray(vals[id(p)], np.float32)) for _, p in params}
+        flips, decisions = count_flips(net.engine(), free, len(x0), before_t)
+        print('%s: %d of %d decisions differ from the free float64 run; %d tensors beyond 2e-3' % (key, flips, decisions, len(over)))
+        assert 0 < flips <= max(3, 1e-4 * decisions) and len(over) <= 4 * flips and uerr[over].max() <= 0.1, \
+            (key, flips, [(params[i][0], float(uerr[i])) for i in over[:8]])

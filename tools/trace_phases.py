@@ -54,8 +54,10 @@ for op in ops:
     for _, dlt in ev_t:
         cur += dlt; peak = max(peak, cur)
     print('\n%s [%s]  event %.1f us, first start -> last exit %.1f us, %d workgroups, peak concurrency %d' % (op.what, op.tag, e0.elapsed_time(e1) * 1e3, span, len(rows), peak))
-    for kind in sorted(set(rows[:, 6])):
-        r = rows[rows[:, 6] == kind]
+    for mem, kind in sorted(set(zip(rows[:, 11], rows[:, 6]))):
+        r = rows[(rows[:, 6] == kind) & (rows[:, 11] == mem)]
+        if mem:
+            print(' member %d:' % (mem - 1))
         rel = (r[:, :6] - t0) / 100.0
         rel2 = (r[:, 8:11] - t0) / 100.0
         units = r[:, 7]
