@@ -349,6 +349,11 @@ typedef struct {
     float bn_eps, bn_decay;
     int mode;                                         /* MPNN_ACT_BN_BATCH / _MOVING */
     int n;
+    /* Optional: accumulators of the launch that FOLLOWS (mpnn_route adds the TALR node statistics and the loss
+     * sums with atomics): this record's head workgroup clears clear_f[0 .. n_clear_f) and clear_d[0 .. n_clear_d).
+     * A training step then needs no clearing launch (the BatchNorm slot sums are cleared by their last reader,
+     * mpnn_backward_finish / mpnn_bn_finalize). */
+    float *clear_f;  int n_clear_f;  double *clear_d;  int n_clear_d;
 } mpnn_exit_tail_args;
 int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int count, int n_max,
                        void *stream);
@@ -453,9 +458,12 @@ int mpnn_compact_by_branch(const float *p_ev, int n, int *idx_out, int *count_ou
  * mavg_off, vavg_off (floats in `state`), C, pixels per image, gamma_goff,
  * beta_goff (floats in `grads`), nslot.  gamma_goff = -1 marks a BatchNorm whose output
  * nobody consumes: no gradients and -- as in the reference, whose tf.assign of the
- * averages only executes when the output is needed -- no moving-average update. */
-int mpnn_bn_finalize(const double *sums, const double *reds, float *state, float *grads,
-                     const int *table, int n_bn, float decay, int n_img, void *stream);
+ * averages only executes when the output is needed -- no moving-average update.
+ * sums_keep (NULL: off): this launch is the LAST reader of the step's slot sums; with sums_keep set it copies
+ * the forward sums there (same layout: the step's batch statistics stay inspectable) and leaves `sums` and
+ * `reds` CLEARED, so that the next training step needs no clearing launch. */
+int mpnn_bn_finalize(double *sums, double *reds, float *state, float *grads,
+                     const int *table, int n_bn, float decay, int n_img, double *sums_keep, void *stream);
 
 /* ---- TALR + L2 + momentum (net_types.py:24-37, tf.train.MomentumOptimizer) --
  * For every trainable element: g = grad + 2*k_l2*pbar_node*(w - w_eq)  (w_eq: the identity part of a
@@ -489,8 +497,8 @@ int mpnn_augment_batch(const float *x_src, const float *y_src, const int *draw,
 /* mpnn_slab_reduce and mpnn_bn_finalize in ONE launch (same arguments and semantics; the two are
  * independent of each other and both end the backward pass). */
 int mpnn_backward_finish(const float *slabs, float *grads, const int *slab_table, int n_items,
-                         const double *sums, const double *reds, float *state, const int *bn_table,
-                         int n_bn, float decay, int n_img, void *stream);
+                         double *sums, double *reds, float *state, const int *bn_table,
+                         int n_bn, float decay, int n_img, double *sums_keep, void *stream);
 
 /* Workgroups of the mpnn_msconv_bwd_scale kernel (the variant for this shape, with or without a
  * dgrad-vert body) for an H x W x Cout scale that are resident on the

@@ -122,14 +122,15 @@ __device__ __forceinline__ BnC bn_coef(const mpnn_act &b, int c) {
 
 // One BatchNorm of mpnn_bn_finalize (table record t: see misc.hip): moving averages from the forward
 // sums, dgamma / dbeta from the backward reductions.  Shared by bn_finalize_k and backward_finish_k.
-__device__ __forceinline__ void bn_finalize_body(const double *__restrict__ sums, const double *__restrict__ reds,
+__device__ __forceinline__ void bn_finalize_body(double *__restrict__ sums, double *__restrict__ reds,
                                                  float *__restrict__ state, float *__restrict__ grads,
-                                                 const int *__restrict__ t, float decay, int n_img) {
-    const int C = t[3];
+                                                 const int *__restrict__ t, float decay, int n_img,
+                                                 double *__restrict__ sums_keep) {
+    const int C = t[3], ns = t[7];
     const double inv = 1.0 / ((double)t[4] * (double)n_img);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const double mean = slot_sum(sums + t[0], 2 * C, c, t[7]) * inv;
-        double var = slot_sum(sums + t[0], 2 * C, C + c, t[7]) * inv - mean * mean;
+        const double mean = slot_sum(sums + t[0], 2 * C, c, ns) * inv;
+        double var = slot_sum(sums + t[0], 2 * C, C + c, ns) * inv - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         // A BatchNorm whose output nobody consumes (t[5] < 0: a scale the child block drops and no exit
         // reads) keeps its moving averages: in the reference the two tf.assign hang off the OUTPUT by
@@ -140,8 +141,19 @@ __device__ __forceinline__ void bn_finalize_body(const double *__restrict__ sums
             *v = decay * *v + (1.f - decay) * (float)var;
         }
         if (reds && grads && t[5] >= 0) {
-            grads[t[6] + c] = (float)slot_sum(reds + t[0], 2 * C, c, t[7]);          // dbeta  = sum dz
-            grads[t[5] + c] = (float)slot_sum(reds + t[0], 2 * C, C + c, t[7]);      // dgamma = sum dz * xhat
+            grads[t[6] + c] = (float)slot_sum(reds + t[0], 2 * C, c, ns);          // dbeta  = sum dz
+            grads[t[5] + c] = (float)slot_sum(reds + t[0], 2 * C, C + c, ns);      // dgamma = sum dz * xhat
+        }
+        // This is the LAST reader of the step's slot sums: with sums_keep set it leaves them cleared for the next
+        // step (the forward convs and the backward epilogues add to them with atomics), so that a training step
+        // needs no clearing launch of its own.
+        // (sums_keep: a copy of the forward sums for whoever wants to look at the step's batch statistics afterwards)
+        if (!sums_keep) continue;
+        for (int s = 0; s < ns; ++s) {
+            const int i0 = t[0] + s * 2 * C + c, i1 = i0 + C;
+            sums_keep[i0] = sums[i0];  sums_keep[i1] = sums[i1];
+            sums[i0] = 0.0;  sums[i1] = 0.0;
+            if (reds) { reds[i0] = 0.0;  reds[i1] = 0.0; }
         }
     }
 }

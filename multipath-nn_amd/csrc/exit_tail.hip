@@ -106,6 +106,9 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
     const int tid = threadIdx.x, n = a.n;
     trace_stamp(0); trace_note(6, 12);
     if (blockIdx.x & 1) {
+        // (optional) the accumulators mpnn_route adds to: cleared here, one launch ahead of it
+        if (a.clear_f) for (int k = tid; k < a.n_clear_f; k += 256) a.clear_f[k] = 0.f;
+        if (a.clear_d) for (int k = tid; k < a.n_clear_d; k += 256) a.clear_d[k] = 0.0;
         // ---- the head: Softmax + CrossEntropyError, one sample per thread ----
         if (!a.z) return;
         const int nc = a.n_cls;

@@ -222,17 +222,17 @@ extern "C" int mpnn_bn_bwd_apply(float *dz_inout, const mpnn_bn_ctx *ctx, long n
 // reductions in `reds`), mavg_off, vavg_off (floats in `state`), C,
 // pixels per image, gamma_goff, beta_goff (floats in `grads`; -1: skip), -.
 // ---------------------------------------------------------------------------
-__global__ void bn_finalize_k(const double *__restrict__ sums, const double *__restrict__ reds,
+__global__ void bn_finalize_k(double *__restrict__ sums, double *__restrict__ reds,
                               float *__restrict__ state, float *__restrict__ grads,
-                              const int *__restrict__ table, float decay, int n_img) {
-    bn_finalize_body(sums, reds, state, grads, table + blockIdx.x * 8, decay, n_img);
+                              const int *__restrict__ table, float decay, int n_img, double *__restrict__ sums_keep) {
+    bn_finalize_body(sums, reds, state, grads, table + blockIdx.x * 8, decay, n_img, sums_keep);
 }
 
-extern "C" int mpnn_bn_finalize(const double *sums, const double *reds, float *state, float *grads,
-                                const int *table, int n_bn, float decay, int n_img, void *stream) {
+extern "C" int mpnn_bn_finalize(double *sums, double *reds, float *state, float *grads,
+                                const int *table, int n_bn, float decay, int n_img, double *sums_keep, void *stream) {
     if (n_bn <= 0) return 0;
     hipLaunchKernelGGL(bn_finalize_k, dim3(n_bn), dim3(128), 0, (hipStream_t)stream, sums, reds, state, grads, table,
-                       decay, n_img);
+                       decay, n_img, sums_keep);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

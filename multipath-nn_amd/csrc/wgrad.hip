@@ -309,19 +309,19 @@ __global__ __launch_bounds__(256) void slab_reduce_k(const float *__restrict__ s
 // mpnn_bn_finalize -- as one (they are independent of each other).
 __global__ __launch_bounds__(256) void backward_finish_k(const float *__restrict__ slabs, float *__restrict__ grads,
                                                          const int *__restrict__ slab_table, int n_items,
-                                                         const double *__restrict__ sums, const double *__restrict__ reds,
+                                                         double *__restrict__ sums, double *__restrict__ reds,
                                                          float *__restrict__ state, const int *__restrict__ bn_table,
-                                                         float decay, int n_img) {
+                                                         float decay, int n_img, double *__restrict__ sums_keep) {
     if ((int)blockIdx.x < n_items) slab_item(slabs, grads, slab_table + blockIdx.x * 6);
-    else bn_finalize_body(sums, reds, state, grads, bn_table + (blockIdx.x - n_items) * 8, decay, n_img);
+    else bn_finalize_body(sums, reds, state, grads, bn_table + (blockIdx.x - n_items) * 8, decay, n_img, sums_keep);
 }
 
 extern "C" int mpnn_backward_finish(const float *slabs, float *grads, const int *slab_table, int n_items,
-                                    const double *sums, const double *reds, float *state, const int *bn_table,
-                                    int n_bn, float decay, int n_img, void *stream) {
+                                    double *sums, double *reds, float *state, const int *bn_table,
+                                    int n_bn, float decay, int n_img, double *sums_keep, void *stream) {
     if (n_items < 0 || n_bn < 0 || n_items + n_bn == 0) return n_items + n_bn == 0 ? 0 : MPNN_E_ARG;
     hipLaunchKernelGGL(backward_finish_k, dim3(n_items + n_bn), dim3(256), 0, (hipStream_t)stream, slabs, grads, slab_table,
-                       n_items, sums, reds, state, bn_table, decay, n_img);
+                       n_items, sums, reds, state, bn_table, decay, n_img, sums_keep);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

@@ -95,7 +95,8 @@ class ExitTailArgs(C.Structure):
                 ('g1', P), ('b1', P), ('m1', P), ('v1', P), ('w2', P), ('bias2', P),
                 ('g2', P), ('b2', P), ('m2', P), ('v2', P), ('w3', P), ('bias3', P),
                 ('h2', P), ('r', P), ('r_stride', C.c_int), ('bn_save', P),
-                ('bn_eps', C.c_float), ('bn_decay', C.c_float), ('mode', C.c_int), ('n', C.c_int)]
+                ('bn_eps', C.c_float), ('bn_decay', C.c_float), ('mode', C.c_int), ('n', C.c_int),
+                ('clear_f', P), ('n_clear_f', C.c_int), ('clear_d', P), ('n_clear_d', C.c_int)]
 
 
 class ExitTailBwdArgs(C.Structure):
@@ -145,7 +146,7 @@ _SIGS = {
     'mpnn_msconv_fwd': [C.POINTER(ConvFwdArgs), P],
     'mpnn_msconv_fwd_group': [C.POINTER(ConvFwdArgs), P, C.c_int, P],
     'mpnn_debug_set_trace': [P],
-    'mpnn_backward_finish': [P, P, P, C.c_int, P, P, P, P, C.c_int, C.c_float, C.c_int, P],
+    'mpnn_backward_finish': [P, P, P, C.c_int, P, P, P, P, C.c_int, C.c_float, C.c_int, P, P],
     'mpnn_augment_batch': [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P],
     'mpnn_msconv_bwd_scale_slots': [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     'mpnn_bn_relu_fwd': [C.POINTER(Act), P, C.c_long, P],
@@ -172,7 +173,7 @@ _SIGS = {
     'mpnn_exit_ev': [P, C.c_int, C.c_int, P],
     'mpnn_exit_ev_check': [C.POINTER(ExitEvArgs)],
     'mpnn_compact_by_branch': [P, C.c_int, P, P, P],
-    'mpnn_bn_finalize': [P, P, P, P, P, C.c_int, C.c_float, C.c_int, P],
+    'mpnn_bn_finalize': [P, P, P, P, P, C.c_int, C.c_float, C.c_int, P, P],
     'mpnn_talr_momentum_step': [P, P, P, P, C.c_int, P, P, C.c_int, C.c_float, C.c_float, P, P, P],
     'mpnn_conv_nhwc_fwd': [C.POINTER(ConvNhwcFwdArgs), P],
     'mpnn_conv_nhwc_dgrad': [C.POINTER(ConvNhwcDgradArgs), P],

@@ -88,6 +88,8 @@ class Engine:
         self.multi_stream = bool(int(os.environ.get('MPNN_STREAMS', '0')))
         self.group_fwd = bool(int(os.environ.get('MPNN_FWD_GROUP', '1')))   # wavefront-grouped forward launches
         self.bwd_levels = bool(int(os.environ.get('MPNN_BWD_LEVELS', '1')))  # one backward launch per dependency level
+        self.fold_clear = bool(int(os.environ.get('MPNN_FOLD_CLEAR', '1')))  # no clearing launch in a training step
+        self._acc_clean = False          # the step's accumulators (slot sums, TALR statistics, loss) are cleared
         self._streams = []
         self._event_keep = []
         self.n_streams = 1
@@ -351,6 +353,8 @@ class Engine:
         self._zarena = torch.zeros(zb + gb, dtype=torch.uint8, device=dev)
         z64 = self._zarena[:zb].view(torch.float64)
         self.dsum, self.dred, self.loss = z64[:nd], z64[nd:2 * nd], z64[2 * nd:2 * nd + 4]
+        # the forward sums of the LAST completed training step (the live ones are cleared by their last reader)
+        self.dsum_last = torch.zeros(nd, dtype=torch.float64, device=dev)
         n_g = self.G.numel()
         self.G = self._zarena[zb:zb + n_g * 4].view(torch.float32)
         self.node_stat = self.G[n_g - self.node_stat.numel():]
@@ -508,7 +512,8 @@ class Engine:
             has_dgrad = 1 if (b.in_map is not None or i > 0) else 0
             slots = self.lib.mpnn_msconv_bwd_scale_slots(b.H[i], b.W[i], b.C[i], has_dgrad, 1 if i > 0 else 0)
             if slots > 0:
-                budget = min(512, slots // 2 if has_dgrad else slots)      # (a third / a quarter: measured slower)
+                div = float(os.environ.get('MPNN_WG_DIV', '2'))
+                budget = min(512, int(slots / div) if has_dgrad else slots)      # (a third / a quarter: measured slower)
         want = max(1, budget // (nch * groups))
         w_bytes = 4 * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
         want = min(want, max(1, (12 << 20) // w_bytes))         # keep a layer's slab under ~12 MB
@@ -566,7 +571,7 @@ class Engine:
     # of g for one 64-pixel tile and one 16-channel output row; a weight-gradient tile), from the phase traces
     # (profiles/): dgrad-vert units carry the max-pool / BatchNorm-backward epilogue, 64-channel weight-gradient
     # groups four times the MFMAs of 16-channel ones.
-    _LAT = dict(h=1.0, v=1.4, w1=1.0, w4=2.6)
+    _LAT = dict(h=1.0, v=1.4, w1=float(os.environ.get('MPNN_LAT_W1', '1.0')), w4=float(os.environ.get('MPNN_LAT_W4', '2.6')))
 
     def _level_budget(self, grp, n):
         """Workgroups of every body of a level launch: the assignment that minimises the longest serial chain
@@ -643,7 +648,7 @@ class Engine:
             # hipStreamEndCapture), and the DAG schedule has no bucket boundaries to overlap the collectives with
             raise NotImplementedError('data-parallel training runs on the single-stream schedule (MPNN_STREAMS=0)')
         dp = mode == 'tr' and self.allreduce is not None
-        key = (mode, n, self.multi_stream, self.group_fwd, routed, dp, self.bwd_levels)
+        key = (mode, n, self.multi_stream, self.group_fwd, routed, dp, self.bwd_levels, self.fold_clear)
         if key in self._progs:
             return self._progs[key]
         self._ensure_capacity(n, mode == 'tr')
@@ -823,6 +828,12 @@ class Engine:
             tb.f = tf
             lin_f.append(lf); lin_b.append(lb); tail_f.append(tf); tail_b.append(tb)
         n_exit = len(lin_f)
+        # A training step without a clearing launch: the slot sums are cleared by their last reader (the launch that
+        # ends the backward pass), the accumulators of mpnn_route by the launch before it (see run()).
+        fold = mode == 'tr' and n_exit > 0 and self.fold_clear
+        if fold:
+            tail_f[0].clear_f, tail_f[0].n_clear_f = self.node_stat.data_ptr(), self.node_stat.numel()
+            tail_f[0].clear_d, tail_f[0].n_clear_d = self.loss.data_ptr(), self.loss.numel()
         t_lf, t_lb = _hip.to_device_table(lin_f, self.dev), _hip.to_device_table(lin_b, self.dev)
         t_tf, t_tb = _hip.to_device_table(tail_f, self.dev), _hip.to_device_table(tail_b, self.dev)
         keep += [t_lf, t_lb, t_tf, t_tb]
@@ -837,7 +848,7 @@ class Engine:
         ra = self._route_args(n, mode, self.loss)
         fwd.append(call(lib.mpnn_route, 'route', C.byref(ra)))
 
-        prog = dict(fwd=fwd, bwd=bwd, n=n, mode=mode)
+        prog = dict(fwd=fwd, bwd=bwd, n=n, mode=mode, fold=fold)
         self._progs[key] = prog
         if mode != 'tr':
             return prog
@@ -1026,6 +1037,7 @@ class Engine:
                     bwd.append(call(lib.mpnn_msconv_wgrad, 'wgrad', C.byref(wgrad_args(i)), flops=fl_w(b, i),
                                     tag=tag_b(b, i), stream=wg_streams[i % 2], waits=[Gn(b, i)]))
         bwd.append(marker('join'))
+        keep_ptr = self.dsum_last.data_ptr() if fold else None
         if slab_plan['size']:
             slab = torch.empty(slab_plan['size'], device=self.dev)
             rows, first = [], 0
@@ -1051,11 +1063,11 @@ class Engine:
             # slab reduction + BatchNorm finalisation (moving averages, dgamma/dbeta): one launch
             bwd.append(call(lib.mpnn_backward_finish, 'backward_finish', slab.data_ptr(), self.G.data_ptr(),
                             tab[6 * first:].data_ptr(), n_items - first, self.dsum.data_ptr(), self.dred.data_ptr(),
-                            self.S.data_ptr(), self.bn_table.data_ptr(), self.n_bn, self.bn_decay, n))
+                            self.S.data_ptr(), self.bn_table.data_ptr(), self.n_bn, self.bn_decay, n, keep_ptr))
         else:
             bwd.append(call(lib.mpnn_bn_finalize, 'bn_finalize', self.dsum.data_ptr(), self.dred.data_ptr(),
                             self.S.data_ptr(), self.G.data_ptr(), self.bn_table.data_ptr(), self.n_bn,
-                            self.bn_decay, n))
+                            self.bn_decay, n, keep_ptr))
         # member records of the level launches: every pointer is final now
         for mem, cnt, host, rec_bytes, dev_rec in level_fix:
             _hip.check(lib.mpnn_msconv_bwd_level_prepare(mem, cnt, C.cast(host, C.c_void_p)), 'bwd_level records')
@@ -1399,25 +1411,40 @@ class Engine:
             if hasattr(h, 'wait'):
                 h.wait()
 
+    def batch_stat_sums(self):
+        """fp64 slot sums (sum x, sum x^2 per BatchNorm, layout of the finalize table) of the last training step."""
+        return self.dsum_last if getattr(self, '_last_fold', False) else self.dsum
+
+    def _clear_if_needed(self, prog, train):
+        """Clear the step's accumulators unless the previous training step left them cleared (programs with
+        prog['fold']: slot sums cleared by the launch that ends the backward pass, TALR statistics and loss sums
+        by the launch in front of mpnn_route).  Evaluation programs always clear their own arena."""
+        if not train:
+            self._begin(False)
+        elif not (prog.get('fold') and self._acc_clean):
+            self._begin(True)
+
     def _phase_a(self, prog, train):
         """Everything of a step except the optimizer (eager launches).  Data parallel: the all-reduce
         of each gradient bucket is issued as soon as its section is queued -- lib/_dp.py returns an
         asynchronous handle, so the collective runs on RCCL's stream beside the rest of the backward
         pass; all handles are waited for (a stream-level dependency) before the optimizer."""
-        self._begin(train)
+        self._clear_if_needed(prog, train)
+        if train:
+            self._acc_clean = False                # (until the whole backward pass has been queued)
         if not (train and self.allreduce is not None):
             self._launch(prog['fwd'], 0)
             if train:
                 self._launch(prog['bwd'], 1)
+                self._acc_clean = bool(prog.get('fold'))
             return
         handles = []
         for k, (ops, bucket) in enumerate(self._sections(prog, train)):
             self._launch(ops, k)
             if bucket is not None:
                 handles.append(self._reduce_bucket(bucket))
-        if not any(op.what == 'bucket' for op in prog['bwd']):       # (multi-stream schedule: one bucket, the whole of G)
-            handles.append(self.allreduce(self.G))
         self._wait(handles)
+        self._acc_clean = bool(prog.get('fold'))
 
     def run(self, feed, train, routed=False):
         if len(self._event_keep) > 4096:
@@ -1443,6 +1470,8 @@ class Engine:
         else:
             self._run_graphed(prog, do_bwd, n)
         self.last_n, self.last_mode = n, mode
+        if train:
+            self._last_fold = bool(prog.get('fold'))
         self._bind_views(n)
 
     def _run_graphed(self, prog, train, n):
@@ -1458,8 +1487,12 @@ class Engine:
             self._graphs[key] = 'warm'
             return
         dp = train and self.allreduce is not None
+        fold = train and bool(prog.get('fold'))
         if g == 'warm':
             torch.cuda.synchronize()
+            if fold and not self._acc_clean:           # (captured without a clearing launch: start from cleared accumulators)
+                self._begin(True)
+                self._acc_clean = True
             if not dp:                                     # one process: ONE graph per step
                 ga = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga, capture_error_mode=CAPTURE_MODE):
@@ -1475,7 +1508,7 @@ class Engine:
                     gk = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gk, capture_error_mode=CAPTURE_MODE):
                         if k == 0:
-                            self._begin(train)
+                            self._clear_if_needed(prog, train)
                         self._launch(ops, k)
                     secs.append((gk, bucket))
                 gb = torch.cuda.CUDAGraph()
@@ -1483,16 +1516,20 @@ class Engine:
                     self._opt(n)
                 g = self._graphs[key] = (secs, gb)
         secs, gb = g
+        if fold and not self._acc_clean:               # something outside run() left the accumulators dirty
+            self._begin(True)
+        if train:
+            self._acc_clean = False
         handles = []
         for gk, bucket in secs:
             gk.replay()
             if bucket is not None:
                 handles.append(self._reduce_bucket(bucket))
         if dp:
-            if not any(b is not None for _, b in secs):
-                handles.append(self.allreduce(self.G))
             self._wait(handles)
             gb.replay()
+        if train:
+            self._acc_clean = fold
 
     def time_step_ops(self, mode, n, reps=10):
         """In-situ per-launch timing: whole steps run eagerly (no graph), every launch bracketed by
@@ -1514,6 +1551,7 @@ class Engine:
             if rep:                               # first pass warms code objects
                 for k, (e0, e1) in enumerate(evs):
                     tot[k] += e0.elapsed_time(e1)
+        self._acc_clean = False
         return [(op.what, op.tag, op.flops, t / reps) for op, t in zip(ops, tot)]
 
     def time_family_blocks(self, mode, n, reps=10):
@@ -1548,6 +1586,7 @@ class Engine:
                 for what, group, e0, e1 in evs:
                     a = acc.setdefault(what, [0, 0.0, 0.0])
                     a[0] += len(group); a[1] += sum(o.flops for o in group); a[2] += e0.elapsed_time(e1)
+        self._acc_clean = False
         return {k: (v[0] // reps, v[1] / reps, v[2] / reps) for k, v in acc.items()}
 
     def time_ops(self, mode, n, reps=20):
@@ -1558,6 +1597,7 @@ class Engine:
         ops = [o for o in list(prog['fwd']) + (list(prog['bwd']) if mode == 'tr' else []) if o.what not in ('fork', 'join')]
         st = torch.cuda.current_stream()
         out = []
+        self._acc_clean = False
         self._zero(mode == 'tr')
         self._pack()
         for op in ops:                        # state made valid by running the whole step once

@@ -35,7 +35,7 @@ def from_product(net, n, before):
                 forced[('pool', id(conv), i)] = O.pool2_argfirst(s.cpu().numpy())
             bn = b.bns[i].params
             act = _hip.act(s, b.C[i], _hip.ACT_BN_BATCH, 0,
-                           dict(sum=eng.dsum[b.sum_off[i]:], gamma=before[id(bn.γ)], beta=before[id(bn.β)],
+                           dict(sum=eng.batch_stat_sums()[b.sum_off[i]:], gamma=before[id(bn.γ)], beta=before[id(bn.β)],
                                 m_avg=bn.m_avg.data, v_avg=bn.v_avg.data, eps=float(b.bns[i].hypers.ϵ),
                                 nslot=eng._nslot(b, i)), n * b.H[i] * b.W[i])
             y = torch.empty_like(s)

@@ -18,7 +18,7 @@ def snap():
         for i in range(b.L):
             d['s%d_%d' % (k, i)] = b.s[i].clone()
             if i < b.L - 1: d['sp%d_%d' % (k, i)] = b.sp[i].clone()
-    d['dsum'] = eng.dsum.clone()
+    d['dsum'] = eng.batch_stat_sums().clone()
     return d
 
 def fwd_only(group, reps=4):
