@@ -60,6 +60,11 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     int np = (C - ch * 16 + 3) >> 2;
     np = np > 4 ? 4 : np;
     const bool bias_wave = wid == 1 && by == 0;           // slot ti = 2 of wave 1 is tap 9: unused
+    // tile sequence (see conv_body): XCD-aware when the split is a multiple of 8
+    const bool xa = c.xcd != 0 && (c.n & 31) == 0 && (gx & 7) == 0;      // (uniform)
+    const int xcd_id = blockIdx.x & 7;
+    const int tpi = GK == 0 ? (c.W >> 4) * (c.H >> 2) : 1;
+    const int sq0 = xa ? (bx >> 3) : bx, sqd = xa ? (gx >> 3) : gx, sqn = xa ? (p.n_tiles >> 3) : p.n_tiles;
     trace_stamp(0);
 
     // NINE: every wave accumulates ALL nine taps -- of its own 16-channel output tile (OT == 4: wave w owns
@@ -130,7 +135,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     int on0[NS], oy0[NS], ox0[NS];
     auto request = [&](auto sel, int t) {
         constexpr int S = decltype(sel)::value;
-        tile_origin<GK>(c, t, on0[S], oy0[S], ox0[S]);
+        tile_origin<GK>(c, xa ? xcd_tile<GK>(t, xcd_id, tpi) : t, on0[S], oy0[S], ox0[S]);
         load_x<GK, PART, 1>(xrS[S], c, on0[S], oy0[S], ox0[S], ch * 16, np, tid);
         load_g<GK, OT>(grS[S], gsS[S], p, on0[S], oy0[S], ox0[S], co0, tid);
     };
@@ -162,8 +167,8 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
             *(f32x4 *)(gt + pi * GS + q * 4) = v;
         }
         lds_barrier();
-        if (t == bx) trace_stamp(2);
-        if (t + NS * gx < p.n_tiles) request(sel, t + NS * gx);      // flies under NS tiles of MFMAs
+        if (t == sq0) trace_stamp(2);
+        if (t + NS * sqd < sqn) request(sel, t + NS * sqd);          // flies under NS tiles of MFMAs
         if constexpr (NINE) {
 #pragma unroll
             for (int kk = 0; kk < (OT == 4 ? 4 : 1); ++kk) {
@@ -223,11 +228,11 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, NS - 1>;
-    if (bx < p.n_tiles) request(S0{}, bx);
-    if (NS == 2 && bx + gx < p.n_tiles) request(S1{}, bx + gx);
-    for (int t = bx; t < p.n_tiles; t += NS * gx) {
+    if (sq0 < sqn) request(S0{}, sq0);
+    if (NS == 2 && sq0 + sqd < sqn) request(S1{}, sq0 + sqd);
+    for (int t = sq0; t < sqn; t += NS * sqd) {
         tile_step(S0{}, t);
-        if (NS == 2 && t + gx < p.n_tiles) tile_step(S1{}, t + gx);
+        if (NS == 2 && t + sqd < sqn) tile_step(S1{}, t + sqd);
     }
 
     trace_stamp(4);
@@ -300,7 +305,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     }
     }
     trace_stamp(5);
-    trace_note(6, 8); trace_note(7, bx < p.n_tiles ? (p.n_tiles - 1 - bx) / gx + 1 : 0);
+    trace_note(6, 8); trace_note(7, sq0 < sqn ? (sqn - 1 - sq0) / sqd + 1 : 0);
 }
 
 

@@ -155,6 +155,7 @@ static int level_build(const mpnn_bwd_member *mem, int count, BwdRec *recs, BwdL
         q.gxh = m.horz ? clampx(m.wg_horz) : 0;
         q.gxv = m.vert ? clampx(m.wg_vert) : 0;
         q.h.n_tiles = q.v.n_tiles = tiles;
+        q.h.xcd = q.v.xcd = q.w.c.xcd = xcd_env();
         q.gxw = split;
         q.nchw = ((q.w.c.a.C + 15) >> 4) + (q.w.c.v ? ((q.w.c.Cv + 15) >> 4) : 0);
         const int gyw = q.nchw * (w->Cout / (r.wide ? 64 : 16));

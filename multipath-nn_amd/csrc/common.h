@@ -188,6 +188,14 @@ __device__ __forceinline__ void mfma_drain() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// XCD-aware tile order of the conv bodies (ConvP::xcd): on unless MPNN_XCD=0 (A/B measurements).
+static inline int xcd_env() {
+    static const int v = [] { const char *e = getenv("MPNN_XCD"); return e ? atoi(e) : 1; }();
+    return v;
+}
+// workgroups per row for an XCD-aware launch: a multiple of 8 once there are at least 16
+static inline int xcd_round(int g) { return (xcd_env() && g >= 16) ? (g & ~7) : g; }
+
 // fp64 butterfly over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48).
 __device__ __forceinline__ double reduce_g4(double v) {
     v += __shfl_xor(v, 16);

@@ -19,7 +19,7 @@ extern "C" int mpnn_msconv_fwd(const mpnn_conv_fwd_args *a, void *stream) {
 // Rows of the grid are dealt to the members; each member runs the body of its own geometry.
 // The members' serial latency chains overlap instead of queueing as separate launches.
 // ---------------------------------------------------------------------------
-struct FwdGroupP { int gk[4], small[4], gy[4], gx[4], y0[4], w0[4]; int n; };   // w0 = first linear workgroup of a member
+struct FwdGroupP { int gk[4], small[4], gy[4], gx[4], y0[4], w0[4]; int n; int xcd; };   // w0 = first linear workgroup of a member
 
 __host__ __device__ static inline int fill_fwd(const mpnn_conv_fwd_args *a, ConvP &p) {
     if (!a || !a->a.x || !a->wa_pack || !a->out || !a->bias) return MPNN_E_ARG;
@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256, SMALL ? 3 : MPNN_OCC) void fwd_group_k(const m
     const int yy = (id - w0) / gx, bx = (id - w0) - yy * gx;
     ConvP p = {};
     fill_fwd(tab + m, p);
+    p.xcd = q.xcd;
     switch (kind) {
         case 0: p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
         case 2: p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
@@ -73,11 +74,12 @@ __global__ __launch_bounds__(256, SMALL ? 3 : MPNN_OCC) void fwd_group_k(const m
 
 // One deep small-map member alone in its launch: K-split body, 512 threads (see conv_body).
 template <int GK>
-__global__ __launch_bounds__(512) void fwd_ks_k(const mpnn_conv_fwd_args *__restrict__ tab, const int gx) {
+__global__ __launch_bounds__(512) void fwd_ks_k(const mpnn_conv_fwd_args *__restrict__ tab, const int gx, const int xcd) {
     __shared__ __attribute__((aligned(16))) char smem[ConvSmem<GK, 4, 16, 2>::BYTES];
     const int id = blockIdx.x, yy = id / gx, bx = id - yy * gx;
     ConvP p = {};
     fill_fwd(tab, p);
+    p.xcd = xcd;
     p.n_tiles = conv_grid_x<GK>(p.n, p.H, p.W);
     conv_body<GK, 1, 1, 4, 1, false, EPI_FWD, 2, true>(p, bx, yy, gx, smem);
 }
@@ -123,8 +125,9 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         int gx = hp[0].n_tiles;
         const long slots = q.gk[0] == 1 ? resident_slots((const void *)fwd_ks_k<1>, 0, 512) : resident_slots((const void *)fwd_ks_k<2>, 0, 512);
         if ((long)gx * gy > slots) gx = (int)(slots / gy > 0 ? slots / gy : 1);
-        if (q.gk[0] == 1) hipLaunchKernelGGL(fwd_ks_k<1>, dim3(gx * gy), dim3(512), 0, (hipStream_t)stream, dev_args, gx);
-        else              hipLaunchKernelGGL(fwd_ks_k<2>, dim3(gx * gy), dim3(512), 0, (hipStream_t)stream, dev_args, gx);
+        gx = xcd_round(gx);
+        if (q.gk[0] == 1) hipLaunchKernelGGL(fwd_ks_k<1>, dim3(gx * gy), dim3(512), 0, (hipStream_t)stream, dev_args, gx, xcd_env());
+        else              hipLaunchKernelGGL(fwd_ks_k<2>, dim3(gx * gy), dim3(512), 0, (hipStream_t)stream, dev_args, gx, xcd_env());
         MPNN_LAUNCH_CHECK();
         return 0;
     }
@@ -145,10 +148,11 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         long g = (slots * work[k]) / (total > 0 ? total : 1) / q.gy[k];      // workgroups per tile-row
         if (g < 1) g = 1;
         if (g > hp[k].n_tiles) g = hp[k].n_tiles;
-        q.gx[k] = (int)g;
+        q.gx[k] = xcd_round((int)g);
         if (q.gx[k] > gxm) gxm = q.gx[k];
     }
     q.n = count;
+    q.xcd = xcd_env();
     int n_wg = 0;
     for (int k = 0; k < count; ++k) { q.w0[k] = n_wg; n_wg += q.gx[k] * q.gy[k]; }
     (void)gxm; (void)rows;

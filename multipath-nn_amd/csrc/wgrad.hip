@@ -175,6 +175,7 @@ static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hip
     q.gyh = has_h ? q.h.Cout / 16 : 0;
     q.gyv = has_v ? q.v.Cout / 16 : 0;
     q.h.n_tiles = q.v.n_tiles = tiles;
+    q.h.xcd = q.v.xcd = q.w.c.xcd = xcd_env();
     q.gxw = split;
     q.nchw = ((q.w.c.a.C + 15) >> 4) + (q.w.c.v ? ((q.w.c.Cv + 15) >> 4) : 0);
     const bool wide = (q.w.c.Cout % 64) == 0;           // 64-channel weight-gradient groups for wide layers
@@ -196,7 +197,7 @@ static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hip
         long g = avail * w / (wh + wv) / gy;
         if (g < 1) g = 1;
         if (g > tiles) g = tiles;
-        return (int)g;
+        return xcd_round((int)g);
     };
     q.gxh = share(wh, q.gyh);
     q.gxv = share(wv, q.gyv);

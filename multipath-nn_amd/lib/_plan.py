@@ -517,7 +517,13 @@ class Engine:
         want = max(1, budget // (nch * groups))
         w_bytes = 4 * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
         want = min(want, max(1, (12 << 20) // w_bytes))         # keep a layer's slab under ~12 MB
-        return max(1, min(tiles, want))
+        want = max(1, min(tiles, want))
+        return self._xcd_round(want)
+
+    @staticmethod
+    def _xcd_round(g):
+        """Workgroups per row of an XCD-aware launch (conv_kernel.h, ConvP::xcd): a multiple of 8 from 16 on."""
+        return (g // 8) * 8 if (g >= 16 and os.environ.get('MPNN_XCD', '1') != '0') else g
 
     # ------------------------------------------------------------------ backward schedule
     def _bwd_deps(self, b, i):
@@ -632,6 +638,7 @@ class Engine:
                 for (k, kind, rows, tiles, lat), g in zip(bodies, gx)))
         out = [dict(gxh=0, gxv=0, split=1) for _ in grp]
         for (k, kind, rows, tiles, lat), g in zip(bodies, gx):
+            g = self._xcd_round(g)
             if kind == 'w':
                 kb, b, i = grp[k]
                 w_bytes = 4 * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
