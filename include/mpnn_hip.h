@@ -504,8 +504,10 @@ int mpnn_backward_finish(const float *slabs, float *grads, const int *slab_table
  * dgrad-vert body) for an H x W x Cout scale that are resident on the
  * device at once (occupancy x compute units; needs a GPU).  The caller gives the weight-gradient
  * split (n_split x channel chunks x cout groups workgroups) about half of them, so that the dgrad
- * and wgrad workgroups of the launch all start together.  Negative = MPNN_E_*. */
-int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad, int has_vert);
+ * and wgrad workgroups of the launch all start together.  dgrad_items = 64-pixel tiles x 16-channel rows of the
+ * two input-gradient bodies (the most workgroups they can use; 64-channel layers whose input gradients cannot fill
+ * one workgroup per CU are limited to two workgroups per CU).  Negative = MPNN_E_*. */
+int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad, int has_vert, int dgrad_items);
 
 /* Profiling aid (no reference counterpart).  Installs (or, with NULL, removes) a device buffer of
  * MPNN_TRACE_SLOTS (12) uint64 per workgroup of the largest grid to be traced: thread 0 of every

@@ -154,7 +154,20 @@ static auto bwd_scale_kernel(bool wide, bool deep, bool hasv) -> void (*)(const 
 
 // Resident workgroups of the kernel mpnn_msconv_bwd_scale runs for this shape (the caller sizes
 // the weight-gradient split, and with it the slabs, to a share of them).
-extern "C" int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad, int has_vert) {
+// 64-channel weight-gradient groups leave room for three workgroups per CU (157 registers), but a third one only
+// pays when the input-gradient bodies can use it: with at most one input-gradient workgroup per CU (the 4x4 maps of
+// the deep blocks: 32 tiles x 8 rows) it only buys a finer weight-gradient split, i.e. more slabs.
+static int wide_cap(bool wide, long dgrad_items) {
+    if (!wide) return 0;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return dgrad_items <= cus ? 2 : 0;
+}
+
+extern "C" int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad, int has_vert, int dgrad_items) {
     static const int nch_env = [] { const char *e = getenv("MPNN_CONV_NCH"); return e ? atoi(e) : 0; }();
     const bool wide = (Cout % 64) == 0;
     const int gk = (W >= 16 && (W % 16) == 0 && (H % 4) == 0) ? 0 : (W == 8 && H == 8) ? 1 : (W == 4 && H == 4) ? 2 : -1;
@@ -164,9 +177,7 @@ extern "C" int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad
     const bool hv = has_vert != 0;
     const void *k = gk == 0 ? (const void *)bwd_scale_kernel<0>(wide, deep, hv)
                   : gk == 1 ? (const void *)bwd_scale_kernel<1>(wide, deep, hv) : (const void *)bwd_scale_kernel<2>(wide, deep, hv);
-    // 64-channel weight-gradient groups: two workgroups per CU (the deep layers have at most 256 input-gradient
-    // workgroups; a third resident workgroup per CU only buys a finer weight-gradient split, i.e. more slabs)
-    return resident_slots(k, 0, 256, wide ? 2 : 0);
+    return resident_slots(k, 0, 256, wide_cap(wide, dgrad_items));
 }
 
 template <int GK>
@@ -187,7 +198,7 @@ static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hip
     void (*kern)(const BwdScaleP) = bwd_scale_kernel<GK>(wide, deep, has_v);
     // Fit the grid to what is resident at once: the weight-gradient rows keep their split x rows
     // workgroups (the slabs are sized for them), the two dgrad bodies share the rest by work.
-    const long slots = resident_slots((const void *)kern, 0, 256, wide ? 2 : 0);
+    const long slots = resident_slots((const void *)kern, 0, 256, wide_cap(wide, (long)tiles * (q.gyh + q.gyv)));
     long avail = slots - (long)split * gyw;
     if (avail < slots / 4) avail = slots / 4;
     const long units = (q.w.c.Cout + 15) >> 4;          // g's 16-channel chunks: units per dgrad tile

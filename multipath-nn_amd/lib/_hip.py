@@ -148,7 +148,7 @@ _SIGS = {
     'mpnn_debug_set_trace': [P],
     'mpnn_backward_finish': [P, P, P, C.c_int, P, P, P, P, C.c_int, C.c_float, C.c_int, P, P],
     'mpnn_augment_batch': [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P],
-    'mpnn_msconv_bwd_scale_slots': [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
+    'mpnn_msconv_bwd_scale_slots': [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     'mpnn_bn_relu_fwd': [C.POINTER(Act), P, C.c_long, P],
     'mpnn_bn_bwd_reduce': [P, C.POINTER(BnCtx), P, P, C.c_long, P],
     'mpnn_bn_bwd_apply': [P, C.POINTER(BnCtx), C.c_long, P],

@@ -510,10 +510,15 @@ class Engine:
             # about half of the workgroups that are resident at once: the dgrad bodies of the same
             # launch take the rest, and everything starts together
             has_dgrad = 1 if (b.in_map is not None or i > 0) else 0
-            slots = self.lib.mpnn_msconv_bwd_scale_slots(b.H[i], b.W[i], b.C[i], has_dgrad, 1 if i > 0 else 0)
+            dg_items = tiles * ((b.parent.C[b.in_map[i]] // 16 if b.parent is not None else 0) + (b.C[i - 1] // 16 if i > 0 else 0))
+            slots = self.lib.mpnn_msconv_bwd_scale_slots(b.H[i], b.W[i], b.C[i], has_dgrad, 1 if i > 0 else 0, dg_items)
             if slots > 0:
                 div = float(os.environ.get('MPNN_WG_DIV', '2'))
                 budget = min(512, int(slots / div) if has_dgrad else slots)      # (a third / a quarter: measured slower)
+                if has_dgrad and b.C[i] % 64 == 0 and dg_items > slots // 3:
+                    # a 64-channel layer with three workgroups per CU: the input-gradient bodies get one workgroup
+                    # per (tile, row) if that fits, the weight gradients the rest
+                    budget = min(budget, max(slots - dg_items, slots // 4))
         want = max(1, budget // (nch * groups))
         w_bytes = 4 * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
         want = min(want, max(1, (12 << 20) // w_bytes))         # keep a layer's slab under ~12 MB
