@@ -1469,10 +1469,15 @@ class Engine:
         if train and mode != 'tr':
             raise ValueError("net.train.run needs net.mode: 'tr' in the feed")
         if not train and mode == 'tr':
-            # The reference would evaluate with batch statistics AND move every BatchNorm's averages as
-            # a side effect (layer_types.py:231-236); no caller does that, and half of it (the conv
-            # moving averages) lives in the backward pass here.
-            raise ValueError("forward-only runs evaluate in mode 'ev'; mode 'tr' belongs to net.train.run")
+            # A fetch in mode 'tr' without the train op: the reference evaluates with BATCH statistics, soft routing
+            # p_tr, and moves every consumed BatchNorm's averages as a side effect of the forward pass
+            # (layer_types.py:231-236, net_types.py:50-52).  Here: the forward half of the training program, then
+            # the moving-average update of the conv BatchNorms (which otherwise rides in the launch that ends the
+            # backward pass); the router BatchNorms move theirs in mpnn_exit_tail_fwd.  No gradients, no optimizer.
+            self._forward_tr(n)
+            self.last_n, self.last_mode = n, mode
+            self._bind_views(n)
+            return
         prog = self.program(mode, n, routed)
         do_bwd = train
         if not self.use_graph:
@@ -1485,6 +1490,19 @@ class Engine:
         if train:
             self._last_fold = bool(prog.get('fold'))
         self._bind_views(n)
+
+    def _forward_tr(self, n):
+        prog = self.program('tr', n)
+        fold = bool(prog.get('fold'))
+        if not (fold and self._acc_clean):
+            self._begin(True)
+        self._acc_clean = False
+        self._launch([op for op in prog['fwd'] if op.what not in ('fork', 'join')] if not self.multi_stream else prog['fwd'], 0)
+        _hip.check(self.lib.mpnn_bn_finalize(self.dsum.data_ptr(), None, self.S.data_ptr(), None, self.bn_table.data_ptr(),
+                                             self.n_bn, self.bn_decay, n, self.dsum_last.data_ptr() if fold else None,
+                                             torch.cuda.current_stream().cuda_stream), 'bn_finalize')
+        self._last_fold = fold
+        self._acc_clean = fold
 
     def _run_graphed(self, prog, train, n):
         """First call runs eagerly (loads code objects); the second captures

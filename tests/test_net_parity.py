@@ -275,3 +275,52 @@ def test_known_answers_at_init():
     assert abs(sum(ptr) - 1) < 1e-6
     for j, p in enumerate(ptr):
         assert abs(p - 2.0 ** -(min(j, 6) + 1)) < 1e-5
+
+
+def test_forward_only_fetch_in_tr_mode():
+    """A fetch with mode 'tr' and no train op (net_types.py:50-52; the placeholders accept it): batch-statistics
+    BatchNorm, soft routing p_tr -- and, as in the reference (layer_types.py:231-236), the consumed BatchNorms move
+    their averages while parameters, momentum and gradients stay untouched."""
+    import arch_and_hypers as A
+    from oracle.ref_net import RefNet
+    net = A.ac_chain(k_cpt=1.6e-8)((32, 32, 3), (10,))
+    eng = net.engine()
+    eng.init_params(1234)
+    perturb_routers(net)
+    ref = RefNet(net)
+    ref.load_params()
+    n = 16
+    x0, y = batch(n, seed=3)
+    P0, A0, S0 = eng.P.clone(), eng.A.clone(), eng.S.clone()
+    for rep in range(2):                                   # (twice: the second run starts from cleared accumulators)
+        ref.load_params()
+        net.eval({net.x0: x0, net.y: y, net.mode: 'tr', net.τ: 0.9})
+        torch.cuda.synchronize()
+        res = ref.forward(x0, y, 'tr', τ=0.9)
+        R = lambda ℓ: res['out'][id(ℓ)]
+        for ℓ in net.layers:
+            assert np.abs(ℓ.p_tr.cpu().numpy() - R(ℓ)['p_tr'].detach().numpy()).max() < 2e-4
+        for ℓ in net.leaves:
+            ce = R(ℓ)['c_err'].detach().numpy()
+            assert np.abs(ℓ.c_err.cpu().numpy() - ce).max() < 2e-4 * (1 + np.abs(ce).max())
+        assert torch.equal(eng.P, P0) and torch.equal(eng.A, A0)
+        moved = 0
+        for b in eng.blocks:
+            for i, bn in enumerate(b.bns):
+                m, v = bn.params.m_avg.numpy(), bn.params.v_avg.numpy()
+                m_ref, v_ref = ref.state[id(bn.params.m_avg)].numpy(), ref.state[id(bn.params.v_avg)].numpy()
+                if b.has_dz[i]:
+                    m_ref, v_ref = (t.numpy() for t in R(bn)['new_avg'])
+                    moved += 1
+                assert np.abs(m - m_ref).max() <= 1e-4 * (1e-3 + np.abs(m_ref).max()), (b.H[i], i)
+                assert np.abs(v - v_ref).max() <= 1e-4 * (1e-3 + np.abs(v_ref).max()), (b.H[i], i)
+            if b.router is not None:
+                for k in (2, 5):
+                    bn = b.router.comps[k]
+                    m_ref, v_ref = (t.numpy() for t in res['out'][id(bn)]['new_avg'])
+                    assert np.abs(bn.params.m_avg.numpy() - m_ref).max() <= 1e-4 * (1e-3 + np.abs(m_ref).max())
+                    assert np.abs(bn.params.v_avg.numpy() - v_ref).max() <= 1e-4 * (1e-3 + np.abs(v_ref).max())
+        assert moved >= 10 and not torch.equal(eng.S, S0)
+    # ... and training goes on from there
+    net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.05, net.τ: 0.9})
+    assert torch.isfinite(eng.P).all() and not torch.equal(eng.P, P0)
