@@ -145,9 +145,9 @@ def time_replays(run, reps, chunk=10):
 
 def measure_dp_structure(net, eng, feed, single_ms):
     """What the data-parallel STRUCTURE costs before any wire time: the step as the multi-GPU run executes
-    it -- one graph per gradient-bucket section, an asynchronous RCCL all-reduce per bucket between the
-    replays, stream waits, a graph for the optimizer -- with a ONE-rank RCCL process group, beside the
-    single-graph step of the headline."""
+    it -- the gradient-bucket sections with an asynchronous RCCL all-reduce per bucket on the process group's
+    stream, the waits and the optimizer, captured as one hipGraph (or, where collectives do not capture, one
+    graph per section) -- with a ONE-rank RCCL process group, beside the single-graph step of the headline."""
     import torch.distributed as dist
     from lib import _dp
     _dp.init(backend='nccl', force=True)
@@ -157,9 +157,13 @@ def measure_dp_structure(net, eng, feed, single_ms):
             net.train.run(feed)
         torch.cuda.synchronize()
         ms = time_replays(lambda: net.train.run(feed), 200)
+        key = [k for k in eng._graphs if k[0] == 'tr' and k[2]][0]
+        whole = eng._graphs[key][1] == 'whole'
         return {'ms_per_step': ms, 'ms_per_step_single_graph': single_ms, 'ratio': ms / single_ms,
-                'sections': len(eng.dp_buckets), 'collectives_per_step': len(eng.dp_buckets), 'rccl_ranks': dist.get_world_size(),
-                'what': 'forced 1-rank RCCL group: section graphs + async bucket all-reduces + optimizer graph, 200 steps'}
+                'buckets': list(eng.dp_buckets), 'collectives_per_step': len(eng.dp_buckets), 'rccl_ranks': dist.get_world_size(),
+                'form': 'ONE hipGraph per step: bucket sections + RCCL all-reduces (captured on the process group\'s stream) + optimizer'
+                        if whole else 'one hipGraph per bucket section, all-reduces issued from the host, optimizer graph',
+                'what': 'forced 1-rank RCCL group, 200 steps, beside the single-process one-graph step'}
     finally:
         _dp.detach(net)
         dist.destroy_process_group()

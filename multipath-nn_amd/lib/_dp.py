@@ -94,6 +94,7 @@ def attach(net, force=False):
                                   'engine (lib/_plan.py), not the single-scale Conv engine' % type(eng).__name__)
     eng.world = dist.get_world_size()
     eng.allreduce = allreduce_async
+    eng.allreduce_capturable = dist.get_backend() == 'nccl' and eng.P.is_cuda     # RCCL collectives capture into hipGraphs
     eng._graphs.clear()                        # graphs captured so far folded the optimizer into the step
     for buf in (eng.P, eng.S, eng.A):          # identical replicas to start from
         if buf.is_cuda and dist.get_backend() == 'gloo':
@@ -107,6 +108,6 @@ def attach(net, force=False):
 def detach(net):
     """Back to single-process training (bench: after the 1-rank structure measurement)."""
     eng = net.engine()
-    eng.world, eng.allreduce = 1, None
+    eng.world, eng.allreduce, eng.allreduce_capturable = 1, None, False
     eng._graphs.clear()
     return net

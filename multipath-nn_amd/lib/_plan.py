@@ -95,6 +95,8 @@ class Engine:
         self.n_streams = 1
         self.world = 1
         self.allreduce = None            # callable(G) installed by lib/_dp.py
+        self.allreduce_capturable = False  # the collective may be captured into a hipGraph (RCCL on device tensors)
+        self.dp_one_graph = bool(int(os.environ.get('MPNN_DP_ONE_GRAPH', '1')))
         self._keep = []
         self._progs = {}
         self._graphs = {}
@@ -273,6 +275,11 @@ class Engine:
                 break
         end = off + 2 * len(self.nodes)
         self.dp_buckets = {}                                   # name -> (lo, hi); markers of the same names in the program
+        n_buckets = int(os.environ.get('MPNN_DP_BUCKETS', '3'))
+        if n_buckets <= 1:                                     # ONE all-reduce of the whole of G after the backward pass
+            conv_lo, self.dp_cut_block = 0, None
+        elif n_buckets == 2:                                   # exits | everything else
+            self.dp_cut_block = None
         if conv_lo > 0:
             self.dp_buckets['exit'] = (0, conv_lo)
         if self.dp_cut_block is not None:
@@ -1530,6 +1537,26 @@ class Engine:
                     if train:
                         self._opt(n)
                 g = self._graphs[key] = ([(ga, None)], None)
+            elif self.dp_one_graph and self.allreduce_capturable:
+                # data parallel, RCCL: the WHOLE step -- sections, the asynchronous bucket all-reduces on the process
+                # group's stream, the waits, the optimizer -- captured as ONE hipGraph (RCCL collectives are
+                # capturable; the collective stream becomes a parallel branch of the graph).  One replay per step
+                # instead of four graph launches and three collective calls from the host.
+                try:
+                    ga = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga, capture_error_mode=CAPTURE_MODE):
+                        self._phase_a(prog, train)
+                        self._opt(n)
+                    g = self._graphs[key] = ([(ga, None)], 'whole')
+                except Exception as e:                         # (a stack whose collectives do not capture: section graphs)
+                    import warnings
+                    warnings.warn('capturing the data-parallel step as one hipGraph failed (%r): falling back to one graph '
+                                  'per gradient-bucket section' % (e,))
+                    torch.cuda.synchronize()
+                    self.dp_one_graph = False
+                    self._acc_clean = False
+                    self._graphs[key] = 'warm'
+                    return self._run_graphed(prog, train, n)
             else:
                 # data parallel: one graph per section (the step up to the point where a gradient bucket
                 # is final), the bucket's all-reduce issued between the replays, and a graph for the optimizer
@@ -1555,7 +1582,7 @@ class Engine:
             gk.replay()
             if bucket is not None:
                 handles.append(self._reduce_bucket(bucket))
-        if dp:
+        if dp and gb != 'whole':
             self._wait(handles)
             gb.replay()
         if train:

@@ -107,8 +107,9 @@ def test_two_ranks_match_hand_summed_gradients():
     assert np.abs(p0 - pa).max() <= 3e-4 * scale, np.abs(p0 - pa).max()
 
 
-def _rccl_one_rank(_idx, port, out):
-    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+def _rccl_one_rank(_idx, port, out, one_graph='1'):
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      MPNN_DP_ONE_GRAPH=one_graph)
     net = _net()
     from lib import _dp
     assert _dp.init('nccl', force=True) == (0, 1)
@@ -123,6 +124,8 @@ def _rccl_one_rank(_idx, port, out):
     key = [k for k in eng._graphs if k[0] == 'tr'][0]
     secs, gb = eng._graphs[key]
     out['sections'] = [b for _, b in secs]
+    out['whole'] = gb == 'whole'
+    out['buckets'] = list(eng.dp_buckets)
     out['P'] = eng.P.cpu().numpy().copy()
     dist.destroy_process_group()
 
@@ -134,7 +137,9 @@ def test_rccl_path_on_one_gpu_matches_single_process():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_rccl_one_rank, args=(_free_port(), out), nprocs=1, join=True)
-    assert out['sections'] == ['exit', 'mid', 'end']
+    # RCCL collectives capture: the whole step (bucket sections, async all-reduces, waits, optimizer) is ONE hipGraph
+    assert out['buckets'] == ['exit', 'mid', 'end']
+    assert out['whole'] and out['sections'] == [None]
     net = _net()
     x0, y = _batch(0)
     for _ in range(4):
@@ -143,6 +148,22 @@ def test_rccl_path_on_one_gpu_matches_single_process():
     ref = net.engine().P.cpu().numpy()
     # (four steps of a net that amplifies fp32 summation-order differences -- the exit path's atomics
     # reorder between two processes; 1.6e-5 observed, as in the two-rank test below)
+    assert np.abs(out['P'] - ref).max() <= 3e-4 * np.abs(ref).max()
+
+
+def test_rccl_section_graphs_on_one_gpu():
+    """The fallback form (MPNN_DP_ONE_GRAPH=0, or a stack whose collectives do not capture): one graph per bucket
+    section, the all-reduces issued from the host between the replays, a graph for the optimizer."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_one_rank, args=(_free_port(), out, '0'), nprocs=1, join=True)
+    assert not out['whole'] and out['sections'] == ['exit', 'mid', 'end']
+    net = _net()
+    x0, y = _batch(0)
+    for _ in range(4):
+        net.train.run(_feed(net, x0, y))
+    torch.cuda.synchronize()
+    ref = net.engine().P.cpu().numpy()
     assert np.abs(out['P'] - ref).max() <= 3e-4 * np.abs(ref).max()
 
 
