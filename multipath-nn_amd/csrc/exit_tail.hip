@@ -12,7 +12,8 @@
 // phases), every per-thread array has COMPILE-TIME bounds (runtime trip counts
 // would push them to scratch memory), reductions go through LDS in a fixed
 // order -> deterministic.
-// Limits: batch <= 128 per launch, R <= 16, n_sinks <= 4, n_cls <= 16.
+// Limits: R <= 16, n_sinks <= 4, n_cls <= 16.  Batches of up to CHUNK = 128 samples run the LDS-resident
+// kernels (the shipped specs); larger ones the any-size forms router_fwd_big / router_bwd_big.
 #include "common.h"
 
 #define TR 16          // max router width
@@ -101,6 +102,148 @@ __device__ __forceinline__ void store_rows(float *dst, const float (&v)[ROWS_PT]
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Router tail for batches of MORE than CHUNK samples (any n; the reference's placeholders are (None, ...),
+// net_types.py:50-51).  Same arithmetic, one workgroup per exit, but the batch stays in global memory: every
+// thread owns the samples tid, tid + 256, ... in every pass (so it re-reads only rows it wrote itself), the
+// batch sums are wave DPP sums + four partials through LDS in a fixed order (deterministic).  Not
+// latency-tuned: the hot path of the shipped specs (batch 128) is the kernel above.
+// ---------------------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void block_sums(float (&v)[K], float *part /* [4][K] */, float *tot /* [K] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __syncthreads();                                   // (part / tot may still be read from the previous call)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float w = wave_sum_f(v[k]);
+        if (lane == 0) part[wave * K + k] = w;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) tot[k] = (part[k] + part[K + k]) + (part[2 * K + k] + part[3 * K + k]);
+    __syncthreads();
+}
+
+struct RouterW { float *w2s, *w3s, *vec; };            // LDS: W2 [TR][TR], W3 [TR][TS], g1 b1 bias2 g2 b2 [TR each] bias3 [TS]
+__device__ __forceinline__ void router_weights(const mpnn_exit_tail_args &a, const RouterW &L) {
+    const int tid = threadIdx.x, R = a.R, S = a.n_sinks;
+    const int wc = tid / TR, wj = tid & (TR - 1);
+    L.w2s[tid] = (wc < R && wj < R) ? a.w2[wc * R + wj] : 0.f;
+    if (tid < TR * TS) { const int c = tid / TS, k = tid & (TS - 1); L.w3s[tid] = (c < R && k < S) ? a.w3[c * S + k] : 0.f; }
+    if (tid < TR) {
+        const bool ok = tid < R;
+        L.vec[tid] = ok ? a.g1[tid] : 0.f; L.vec[TR + tid] = ok ? a.b1[tid] : 0.f; L.vec[2 * TR + tid] = ok ? a.bias2[tid] : 0.f;
+        L.vec[3 * TR + tid] = ok ? a.g2[tid] : 0.f; L.vec[4 * TR + tid] = ok ? a.b2[tid] : 0.f;
+    }
+    if (tid < TS) L.vec[5 * TR + tid] = tid < S ? a.bias3[tid] : 0.f;
+}
+__device__ __forceinline__ void row_load(float (&x)[TR], const float *src, int s, int R) {
+#pragma unroll
+    for (int c = 0; c < TR; ++c) x[c] = c < R ? src[(size_t)s * R + c] : 0.f;
+}
+// h2 row of one sample: relu(bn1(h1)) @ W2 + bias2 (a1 returned too)
+__device__ __forceinline__ void row_h2(const float (&h1)[TR], const RouterW &L, const float *bnp, float (&a1)[TR], float (&h2)[TR]) {
+#pragma unroll
+    for (int c = 0; c < TR; ++c) a1[c] = fmaxf(L.vec[c] * (h1[c] - bnp[c]) * bnp[TR + c] + L.vec[TR + c], 0.f);
+#pragma unroll
+    for (int j = 0; j < TR; ++j) {
+        float h = L.vec[2 * TR + j];
+#pragma unroll
+        for (int c = 0; c < TR; ++c) h += a1[c] * L.w2s[c * TR + j];
+        h2[j] = h;
+    }
+}
+// mean / rstd from the pivoted sums (as bn_stats) + the moving-average update
+__device__ __forceinline__ void stats_finish(const float *tot, const float *pv, int n, int R, const mpnn_exit_tail_args &a,
+                                             float *m_avg, float *v_avg, float *mean, float *rstd) {
+    const int tid = threadIdx.x;
+    if (tid < TR) {
+        const float inv = 1.f / (float)n, dm = tot[tid] * inv;
+        const float mu = pv[tid] + dm, var = fmaxf(tot[TR + tid] * inv - dm * dm, 0.f);
+        mean[tid] = mu;
+        rstd[tid] = rsqrtf(var + a.bn_eps);
+        if (tid < R) {
+            m_avg[tid] = a.bn_decay * m_avg[tid] + (1.f - a.bn_decay) * mu;
+            v_avg[tid] = a.bn_decay * v_avg[tid] + (1.f - a.bn_decay) * var;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ void router_fwd_big(const mpnn_exit_tail_args &a) {
+    __shared__ float w2s[TR * TR], w3s[TR * TS], vec[5 * TR + TS], bnp[4 * TR], pv[TR], part[4 * 2 * TR], tot[2 * TR];
+    const RouterW L = {w2s, w3s, vec};
+    const int tid = threadIdx.x, n = a.n, R = a.R, S = a.n_sinks;
+    router_weights(a, L);
+    if (tid < TR) pv[tid] = tid < R ? a.h1[tid] : 0.f;
+    if (tid < 4 * TR) bnp[tid] = 0.f;
+    __syncthreads();
+    const bool batch = a.mode == MPNN_ACT_BN_BATCH;
+    float acc[2 * TR];
+    if (batch) {
+#pragma unroll
+        for (int k = 0; k < 2 * TR; ++k) acc[k] = 0.f;
+        for (int s = tid; s < n; s += 256) {
+            float x[TR];
+            row_load(x, a.h1, s, R);
+#pragma unroll
+            for (int c = 0; c < TR; ++c) { const float d = x[c] - pv[c]; acc[c] += d; acc[TR + c] += d * d; }
+        }
+        block_sums<2 * TR>(acc, part, tot);
+        stats_finish(tot, pv, n, R, a, a.m1, a.v1, bnp, bnp + TR);
+    } else {
+        if (tid < R) { bnp[tid] = a.m1[tid]; bnp[TR + tid] = rsqrtf(a.v1[tid] + a.bn_eps); }
+        __syncthreads();
+    }
+    // pivot of the second BatchNorm: the h2 row of sample 0
+    if (tid == 0) {
+        float x[TR], a1[TR], h2[TR];
+        row_load(x, a.h1, 0, R);
+        row_h2(x, L, bnp, a1, h2);
+#pragma unroll
+        for (int j = 0; j < TR; ++j) pv[j] = h2[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2 * TR; ++k) acc[k] = 0.f;
+    for (int s = tid; s < n; s += 256) {
+        float x[TR], a1[TR], h2[TR];
+        row_load(x, a.h1, s, R);
+        row_h2(x, L, bnp, a1, h2);
+#pragma unroll
+        for (int j = 0; j < TR; ++j) {
+            if (j < R) a.h2[(size_t)s * R + j] = h2[j];
+            const float d = h2[j] - pv[j];
+            acc[j] += d; acc[TR + j] += d * d;
+        }
+    }
+    if (batch) {
+        block_sums<2 * TR>(acc, part, tot);
+        stats_finish(tot, pv, n, R, a, a.m2, a.v2, bnp + 2 * TR, bnp + 3 * TR);
+    } else {
+        if (tid < R) { bnp[2 * TR + tid] = a.m2[tid]; bnp[3 * TR + tid] = rsqrtf(a.v2[tid] + a.bn_eps); }
+        __syncthreads();
+    }
+    for (int s = tid; s < n; s += 256) {
+        float h2[TR];
+        row_load(h2, a.h2, s, R);                        // (rows this thread wrote itself)
+        float a2[TR];
+#pragma unroll
+        for (int c = 0; c < TR; ++c) a2[c] = fmaxf(vec[3 * TR + c] * (h2[c] - bnp[2 * TR + c]) * bnp[3 * TR + c] + vec[4 * TR + c], 0.f);
+#pragma unroll
+        for (int i = 0; i < TS; ++i) {
+            float r = vec[5 * TR + i];
+#pragma unroll
+            for (int c = 0; c < TR; ++c) r += a2[c] * w3s[c * TS + i];
+            if (i < S) a.r[(size_t)s * a.r_stride + i] = r;
+        }
+    }
+    if (a.bn_save && tid < R) {
+        a.bn_save[tid] = bnp[tid]; a.bn_save[R + tid] = bnp[TR + tid];
+        a.bn_save[2 * R + tid] = bnp[2 * TR + tid]; a.bn_save[3 * R + tid] = bnp[3 * TR + tid];
+    }
+}
+
 __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args *__restrict__ tab) {
     const mpnn_exit_tail_args a = tab[blockIdx.x >> 1];   // (by value: every field's scalar load in the entry block)
     const int tid = threadIdx.x, n = a.n;
@@ -140,7 +283,7 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
     __shared__ float w2s[TR * TR], w3s[TR * TS], vec[5 * TR + TS];
     __shared__ float h1s[CHUNK * TP], h2s[CHUNK * TP];
 
-    const bool has_router = a.h1 && n <= CHUNK;    // the host rejects n > CHUNK (MPNN_E_SHAPE)
+    const bool has_router = a.h1 && n <= CHUNK;    // (larger batches: exit_tail_fwd_big_k)
     if (!has_router) return;
     const int R = a.R, S = a.n_sinks;
     float m1o, v1o, m2o, v2o;
@@ -219,10 +362,18 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
 
 int mpnn_trace_install_tail(void *buf) { return mpnn_trace_install(buf); }
 
+// any batch size: one workgroup per exit for the router tail; the heads ride in the LDS-resident kernel's head
+// workgroups (they loop over the batch already), launched with the router halves idle
+__global__ __launch_bounds__(256) void exit_tail_fwd_big_k(const mpnn_exit_tail_args *__restrict__ tab) {
+    const mpnn_exit_tail_args a = tab[blockIdx.x];
+    if (a.h1) router_fwd_big(a);
+}
+
 extern "C" int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int count, int n_max, void *stream) {
     if (count <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    if (n_max > CHUNK) return MPNN_E_SHAPE;
+    if (n_max > CHUNK)
+        hipLaunchKernelGGL(exit_tail_fwd_big_k, dim3(count), dim3(256), 0, (hipStream_t)stream, dev_table);
     hipLaunchKernelGGL(exit_tail_fwd_k, dim3(2 * count), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;
@@ -250,6 +401,139 @@ __device__ __forceinline__ f32x4 contract(int n, FA fa, FB fb) {
     mfma_drain();
     acc += acc2;
     return acc;                                    // D[row = 4g + r][col = li] = acc[r]
+}
+
+
+// Router tail backward for batches of more than CHUNK samples (see router_fwd_big): every thread owns the samples
+// tid, tid + 256, ... and recomputes their short per-sample chains in every pass; the sums over the batch (weight /
+// bias gradients, the BatchNorm-backward reductions) are per-thread partial sums + block_sums.
+struct RowB { float a2[TR], d2[TR], xh2[TR]; };
+__device__ __forceinline__ void row_phase_a(const mpnn_exit_tail_args &a, const float *dr, int s, const RouterW &L, const float *gb /* g1 b1 g2 b2 */,
+                                            const float *bnp, float (&drv)[TS], RowB &o) {
+    const int R = a.R, S = a.n_sinks;
+    float h2[TR];
+    row_load(h2, a.h2, s, R);
+#pragma unroll
+    for (int i = 0; i < TS; ++i) drv[i] = i < S ? dr[(size_t)s * a.r_stride + i] : 0.f;
+#pragma unroll
+    for (int c = 0; c < TR; ++c) {
+        o.xh2[c] = (h2[c] - bnp[2 * TR + c]) * bnp[3 * TR + c];
+        o.a2[c] = fmaxf(gb[2 * TR + c] * o.xh2[c] + gb[3 * TR + c], 0.f);
+        float da = 0.f;
+#pragma unroll
+        for (int i = 0; i < TS; ++i) da += drv[i] * L.w3s[c * TS + i];
+        o.d2[c] = o.a2[c] > 0.f ? da : 0.f;
+    }
+}
+struct RowC { float a1[TR], dh2[TR], d1[TR], xh1[TR]; };
+__device__ __forceinline__ void row_phase_b(const mpnn_exit_tail_args &a, int s, const RouterW &L, const float *gb, const float *bnp,
+                                            const float *red, float inv_n, const RowB &rb, RowC &o) {
+    const int R = a.R;
+    float h1[TR];
+    row_load(h1, a.h1, s, R);
+#pragma unroll
+    for (int c = 0; c < TR; ++c) {
+        o.dh2[c] = gb[2 * TR + c] * bnp[3 * TR + c] * (rb.d2[c] - red[c] * inv_n - rb.xh2[c] * red[TR + c] * inv_n);
+        o.xh1[c] = (h1[c] - bnp[c]) * bnp[TR + c];
+        o.a1[c] = fmaxf(gb[c] * o.xh1[c] + gb[TR + c], 0.f);
+    }
+#pragma unroll
+    for (int c = 0; c < TR; ++c) {
+        float da1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < TR; ++j) da1 += o.dh2[j] * L.w2s[c * TR + j];
+        o.d1[c] = o.a1[c] > 0.f ? da1 : 0.f;
+    }
+}
+
+__device__ void router_bwd_big(const mpnn_exit_tail_bwd_args &b) {
+    const mpnn_exit_tail_args &a = b.f;
+    constexpr int KA = TR * TS + TS + 2 * TR, KB = 4 * TR + 3 * TR;       // sums of pass A; of one pass-B round
+    __shared__ float w2s[TR * TR], w3s[TR * TS], vec[5 * TR + TS], gb[4 * TR], bnp[4 * TR], red[4 * TR];
+    constexpr int KM = KA > KB ? KA : KB;
+    __shared__ float part[4 * KM], tot[KM];
+    const RouterW L = {w2s, w3s, vec};
+    const int tid = threadIdx.x, n = a.n, R = a.R, S = a.n_sinks;
+    const float inv_n = 1.f / (float)n;
+    router_weights(a, L);
+    if (tid < TR) {
+        const bool ok = tid < R;
+        gb[tid] = ok ? a.g1[tid] : 0.f; gb[TR + tid] = ok ? a.b1[tid] : 0.f;
+        gb[2 * TR + tid] = ok ? a.g2[tid] : 0.f; gb[3 * TR + tid] = ok ? a.b2[tid] : 0.f;
+        bnp[tid] = ok ? a.bn_save[tid] : 0.f; bnp[TR + tid] = ok ? a.bn_save[R + tid] : 0.f;
+        bnp[2 * TR + tid] = ok ? a.bn_save[2 * R + tid] : 0.f; bnp[3 * TR + tid] = ok ? a.bn_save[3 * R + tid] : 0.f;
+    }
+    __syncthreads();
+    // ---- pass A: dW3 = a2^T dr, dbias3 = sum dr, dbeta2 = sum d2, dgamma2 = sum d2 * xhat2 ----
+    {
+        float acc[KA];
+#pragma unroll
+        for (int k = 0; k < KA; ++k) acc[k] = 0.f;
+        for (int s = tid; s < n; s += 256) {
+            float drv[TS]; RowB rb;
+            row_phase_a(a, b.dr, s, L, gb, bnp, drv, rb);
+#pragma unroll
+            for (int c = 0; c < TR; ++c) {
+#pragma unroll
+                for (int i = 0; i < TS; ++i) acc[c * TS + i] += rb.a2[c] * drv[i];
+                acc[TR * TS + TS + c] += rb.d2[c];
+                acc[TR * TS + TS + TR + c] += rb.d2[c] * rb.xh2[c];
+            }
+#pragma unroll
+            for (int i = 0; i < TS; ++i) acc[TR * TS + i] += drv[i];
+        }
+        block_sums<KA>(acc, part, tot);
+        if (tid < TR * TS) { const int c = tid / TS, i = tid & (TS - 1); if (c < R && i < S) b.dw3[c * S + i] = tot[tid]; }
+        if (tid < S) b.dbias3[tid] = tot[TR * TS + tid];
+        if (tid < TR) {
+            red[tid] = tot[TR * TS + TS + tid]; red[TR + tid] = tot[TR * TS + TS + TR + tid];
+            if (tid < R) { b.db2[tid] = red[tid]; b.dg2[tid] = red[TR + tid]; }
+        }
+        __syncthreads();
+    }
+    // ---- pass B, four rounds: rows 4q .. 4q+3 of dW2 = a1^T dh2 per round (the first also dbias2 = sum dh2,
+    //      dbeta1 = sum d1, dgamma1 = sum d1 * xhat1) ----
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        float acc[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) acc[k] = 0.f;
+        for (int s = tid; s < n; s += 256) {
+            float drv[TS]; RowB rb; RowC rc;
+            row_phase_a(a, b.dr, s, L, gb, bnp, drv, rb);
+            row_phase_b(a, s, L, gb, bnp, red, inv_n, rb, rc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a1r = rc.a1[0];
+#pragma unroll
+                for (int c = 1; c < TR; ++c) a1r = (c == 4 * q + r) ? rc.a1[c] : a1r;       // (select: no run-time register index)
+#pragma unroll
+                for (int j = 0; j < TR; ++j) acc[r * TR + j] += a1r * rc.dh2[j];
+            }
+#pragma unroll
+            for (int c = 0; c < TR; ++c) {
+                acc[4 * TR + c] += rc.dh2[c];
+                acc[5 * TR + c] += rc.d1[c];
+                acc[6 * TR + c] += rc.d1[c] * rc.xh1[c];
+            }
+        }
+        block_sums<KB>(acc, part, tot);
+        if (tid < 4 * TR) { const int c = 4 * q + tid / TR, j = tid & (TR - 1); if (c < R && j < R) b.dw2[c * R + j] = tot[tid]; }
+        if (q == 0 && tid < TR) {
+            red[2 * TR + tid] = tot[5 * TR + tid]; red[3 * TR + tid] = tot[6 * TR + tid];
+            if (tid < R) { b.dbias2[tid] = tot[4 * TR + tid]; b.db1[tid] = tot[5 * TR + tid]; b.dg1[tid] = tot[6 * TR + tid]; }
+        }
+        __syncthreads();
+    }
+    // ---- pass D: dh1 (BatchNorm-1 backward) ----
+    for (int s = tid; s < n; s += 256) {
+        float drv[TS]; RowB rb; RowC rc;
+        row_phase_a(a, b.dr, s, L, gb, bnp, drv, rb);
+        row_phase_b(a, s, L, gb, bnp, red, inv_n, rb, rc);
+#pragma unroll
+        for (int c = 0; c < TR; ++c)
+            if (c < R) b.dh1[(size_t)s * R + c] = gb[c] * bnp[TR + c] * (rc.d1[c] - red[2 * TR + c] * inv_n - rc.xh1[c] * red[3 * TR + c] * inv_n);
+    }
 }
 
 __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_args *__restrict__ tab) {
@@ -286,7 +570,7 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
         trace_stamp(5);
         return;
     }
-    const bool has_router = a.h1 && n <= CHUNK;
+    const bool has_router = a.h1 && n <= CHUNK;    // (larger batches: exit_tail_bwd_big_k)
     if (!has_router) return;
 
     const int R = a.R, S = a.n_sinks;
@@ -432,10 +716,16 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
     trace_stamp(5);
 }
 
+__global__ __launch_bounds__(256) void exit_tail_bwd_big_k(const mpnn_exit_tail_bwd_args *__restrict__ tab) {
+    const mpnn_exit_tail_bwd_args b = tab[blockIdx.x];
+    if (b.f.h1) router_bwd_big(b);
+}
+
 extern "C" int mpnn_exit_tail_bwd(const mpnn_exit_tail_bwd_args *dev_table, int count, int n_max, void *stream) {
     if (count <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    if (n_max > CHUNK) return MPNN_E_SHAPE;
+    if (n_max > CHUNK)
+        hipLaunchKernelGGL(exit_tail_bwd_big_k, dim3(count), dim3(256), 0, (hipStream_t)stream, dev_table);
     hipLaunchKernelGGL(exit_tail_bwd_k, dim3(2 * count), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;

@@ -201,8 +201,6 @@ class ConvEngine:
         mode = feed.get(net.mode, net.mode.default)
         if train != (mode == 'tr'):
             raise ValueError("net.train.run feeds mode 'tr'; forward-only runs evaluate in mode 'ev'")
-        if train and n > 128:
-            raise ValueError('training batches of up to 128 samples (mpnn_exit_tail_fwd)')
         self._ensure_capacity(n)
         put = lambda dst, src: dst.copy_(src.reshape(dst.shape) if isinstance(src, torch.Tensor) else
                                          torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)).reshape(dst.shape))

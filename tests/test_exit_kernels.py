@@ -195,7 +195,7 @@ def tail_params(rng, R, S):
                 w3=(rng.standard_normal((R, S)) / 4).astype(f), bias3=(rng.standard_normal(S) * 0.1).astype(f))
 
 
-@pytest.mark.parametrize('n,S,R', [(128, 2, 16), (37, 3, 16), (16, 4, 16), (64, 2, 8)])
+@pytest.mark.parametrize('n,S,R', [(128, 2, 16), (37, 3, 16), (16, 4, 16), (64, 2, 8), (129, 2, 16), (300, 3, 16), (1000, 2, 8)])
 def test_exit_tail_fwd_bwd(n, S, R):
     lib = _hip.load()
     rng = np.random.default_rng(10 * n + S)

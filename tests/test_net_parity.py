@@ -277,6 +277,13 @@ def test_known_answers_at_init():
         assert abs(p - 2.0 ** -(min(j, 6) + 1)) < 1e-5
 
 
+def test_training_batch_256():
+    """A training batch beyond the 128 samples of arch_and_hypers.py:35 (the reference's placeholders are
+    (None, ...), net_types.py:50-51): the router tails run their any-size forms (exit_tail.hip, router_*_big)."""
+    import arch_and_hypers as A
+    run_case(A.ac_chain(k_cpt=1.6e-8), 256, lambda net, t: {net.τ: 0.8}, steps=1)
+
+
 def test_forward_only_fetch_in_tr_mode():
     """A fetch with mode 'tr' and no train op (net_types.py:50-52; the placeholders accept it): batch-statistics
     BatchNorm, soft routing p_tr -- and, as in the reference (layer_types.py:231-236), the consumed BatchNorms move
