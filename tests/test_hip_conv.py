@@ -295,9 +295,19 @@ def test_bwd_scale_slots_query():
     torch.zeros(1, device='cuda')
     lib = _hip.load()
     for H, Cc in ((4, 128), (8, 64), (16, 32), (32, 16)):
-        s = lib.mpnn_msconv_bwd_scale_slots(H, H, Cc, 1, 1)
+        s = lib.mpnn_msconv_bwd_scale_slots(H, H, Cc, 1, 1, 4096)
         assert s >= 256 and s % 256 == 0, (H, Cc, s)          # whole workgroups per CU x 256 CUs
-    assert lib.mpnn_msconv_bwd_scale_slots(5, 5, 16, 1, 0) == _hip.E_SHAPE
+    # a 64-channel layer whose input gradients cannot fill one workgroup per CU: two workgroups per CU
+    assert lib.mpnn_msconv_bwd_scale_slots(4, 4, 128, 1, 0, 256) == 512
+    assert lib.mpnn_msconv_bwd_scale_slots(8, 8, 64, 1, 0, 512) >= 512
+    assert lib.mpnn_msconv_bwd_scale_slots(5, 5, 16, 1, 0, 0) == _hip.E_SHAPE
+    # level launches: the variant covering a set of member shapes, and its record size
+    import ctypes as C
+    arr = lambda *v: (C.c_int * len(v))(*v)
+    s = lib.mpnn_msconv_bwd_level_slots(arr(32, 8), arr(32, 8), arr(16, 16), 2)
+    assert s >= 512 and s % 256 == 0
+    assert lib.mpnn_msconv_bwd_level_slots(arr(5), arr(5), arr(16), 1) == _hip.E_SHAPE
+    assert lib.mpnn_msconv_bwd_level_record_size() > 0
 
 
 @pytest.mark.parametrize('C_', [32, 128])
