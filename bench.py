@@ -379,7 +379,7 @@ def main():
         # the family's mean launch duration: one event pair around its run of consecutive launches
         cnt, fl, t_ms = eng.time_family_blocks('tr', n, reps=20)[dom_name]
         ach = fl / (t_ms * 1e-3) / 1e12
-        symbol = {'fwd_group': 'fwd_group_k', 'bwd_scale': 'bwd_scale_k<GK,OT,NCH,HASV> (all instantiations)',
+        symbol = {'fwd_group': 'fwd_group_k', 'bwd_scale': 'bwd_scale_k<GK,OT,NCH,HASV> + bwd_level_k<GKMASK,OTMASK> (all instantiations: the backward conv launches)',
                   'msconv_fwd': 'conv_k<...,EPI_FWD>'}.get(dom_name, dom_name)
         total_ms = sum(o[3] for o in ops)
         conv_fl, conv_ms = sum(o[2] for o in conv), sum(o[3] for o in conv)

@@ -88,6 +88,7 @@ class Engine:
         self.multi_stream = bool(int(os.environ.get('MPNN_STREAMS', '0')))
         self.group_fwd = bool(int(os.environ.get('MPNN_FWD_GROUP', '1')))   # wavefront-grouped forward launches
         self.bwd_levels = bool(int(os.environ.get('MPNN_BWD_LEVELS', '1')))  # one backward launch per dependency level
+        self.routed_min_batch = int(os.environ.get('MPNN_ROUTED_MIN_BATCH', '1024'))
         self.fold_clear = bool(int(os.environ.get('MPNN_FOLD_CLEAR', '1')))  # no clearing launch in a training step
         self._acc_clean = False          # the step's accumulators (slot sums, TALR statistics, loss) are cleared
         self._streams = []
@@ -661,6 +662,10 @@ class Engine:
     def program(self, mode, n, routed=False):
         """Launch lists of one (mode, batch size).  routed ('ev' only): the routed evaluation -- every
         block runs on the sample list its parent's router produced on the device (see _program_ev)."""
+        # routed='auto': routed above ROUTED_MIN_BATCH samples, dense below (the routed schedule is block-serial --
+        # 28 launches against 13 -- and only pays once the launches are throughput-bound; profiles/r03_eval_sweep.txt)
+        if routed == 'auto':
+            routed = n >= self.routed_min_batch
         routed = bool(routed) and mode != 'tr' and bool(self.switches) and self.net._net_kind != 'sr'
         if mode == 'tr' and self.allreduce is not None and self.multi_stream:
             # one section would fork and re-join the same side streams twice inside one capture (ROCm 7.2 crashes in

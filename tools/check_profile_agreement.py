@@ -6,7 +6,8 @@ import csv, json, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 b = json.load(open(sys.argv[2]))
 sym = b['roofline']['kernel'].split('<')[0].split(' ')[0]
-sel = [r for r in rows if r['Name'].replace('void ', '').startswith(sym)]
+names = (sym, 'bwd_level_k') if sym == 'bwd_scale_k' else (sym,)        # the level launches belong to the backward family
+sel = [r for r in rows if r['Name'].replace('void ', '').startswith(names)]
 calls = sum(int(r['Calls']) for r in sel)
 avg = sum(float(r['TotalDurationNs']) for r in sel) / calls / 1e3
 print('%s: rocprofv3 %d calls, average %.2f us;  bench.py (HIP events, in situ) %.2f us;  ratio %.3f'

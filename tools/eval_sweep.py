@@ -18,13 +18,13 @@ for nb in [int(a) for a in sys.argv[1:]] or [1024, 4096, 8192]:
     feed = {net.x0: eng.x0[:nb], net.y: eng.y[:nb]}
     bench.set_exit_fractions(net, feed, nb, [1 / 8] * 7)
     res = {}
-    for routed in (False, True):
+    for routed in (False, True, 'auto'):
         for _ in range(3): net.eval(feed, routed=routed)
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(10): net.eval(feed, routed=routed)
         torch.cuda.synchronize(); res[routed] = (time.perf_counter() - t) / 10 * 1e3
-    print('batch %6d: dense %.3f ms (%.2f M img/s)  routed %.3f ms (%.2f M img/s)  x%.2f' % (
-        nb, res[False], nb / res[False] / 1e3, res[True], nb / res[True] / 1e3, res[False] / res[True]))
+    print('batch %6d: dense %.3f ms (%.2f M img/s)  routed %.3f ms (%.2f M img/s)  x%.2f   routed=auto %.3f ms (x%.2f)' % (
+        nb, res[False], nb / res[False] / 1e3, res[True], nb / res[True] / 1e3, res[False] / res[True], res['auto'], res[False] / res['auto']))
     if nb == 4096:
         print('   exit histogram', [round(float(nd.layer.p_ev.mean()), 3) for nd in eng.leaves])
         prog = eng.program('ev', nb, routed=True)

@@ -8,13 +8,13 @@ wide coalesced loads on gfx950 and is doubled.
 import csv, glob, json, os, sys, time, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 d, family = sys.argv[1], sys.argv[2]
-sym = {'bwd_scale': 'bwd_scale_k<', 'fwd_group': 'fwd_group_k('}[family]
+syms = {'bwd_scale': ('bwd_scale_k<', 'bwd_level_k<'), 'fwd_group': ('fwd_group_k(',)}[family]     # (the level launches belong to the backward family)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 tot = collections.defaultdict(list)
 for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name']
-        if sym in name:
+        if any(sym in name for sym in syms):
             key = (name.split('(')[0][:40], r.get('Grid_Size', ''))
             acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
             tot[r['Counter_Name']].append(float(r['Counter_Value']))

@@ -8,7 +8,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name'].split('(')[0][:28]
-        if 'fwd_group' in name or 'bwd_scale' in name:
+        if 'fwd_group' in name or 'bwd_scale' in name or 'bwd_level' in name or 'fwd_ks' in name:
             acc[(name, r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
 print('%-28s %8s %4s %11s %9s %10s %7s %10s %9s' % ('kernel', 'grid', 'n', 'wave_cycles', 'wait_any', 'wait_inst', 'active', 'valu/mfma', 'salu/mfma'))
 for key, c in sorted(acc.items()):
