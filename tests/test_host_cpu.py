@@ -158,7 +158,7 @@ def test_isa_has_no_uncovered_mfma_result_reads():
             name = os.path.basename(src)
             out = os.path.join(tmp, name + '.s')
             subprocess.check_call(['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'),
-                                   '-munsafe-fp-atomics', '--cuda-device-only', '-S', src, '-o', out],
+                                   '-munsafe-fp-atomics', '-mllvm', '-amdgpu-kernarg-preload-count=16', '--cuda-device-only', '-S', src, '-o', out],
                                   cwd=S.CSRC, stderr=subprocess.DEVNULL)
             bad += [(name,) + site for site in S.scan(out)]
     assert not bad, bad[:5]
@@ -178,7 +178,7 @@ def test_isa_ticket_follows_store_acknowledgement():
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, 'lin.s')
         subprocess.check_call(['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'),
-                               '-munsafe-fp-atomics', '--cuda-device-only', '-S', os.path.join(csrc, 'lin.hip'), '-o', out],
+                               '-munsafe-fp-atomics', '-mllvm', '-amdgpu-kernarg-preload-count=16', '--cuda-device-only', '-S', os.path.join(csrc, 'lin.hip'), '-o', out],
                               cwd=csrc, stderr=subprocess.DEVNULL)
         lines = [l.strip() for l in open(out)]
     tickets = [k for k, l in enumerate(lines) if l.split()[:1] in (['flat_atomic_add'], ['global_atomic_add']) and 'sc0 sc1' in l]

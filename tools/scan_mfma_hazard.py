@@ -61,7 +61,7 @@ def main():
         for src in sorted(glob.glob(os.path.join(CSRC, '*.hip'))):
             out = os.path.join(tmp, os.path.basename(src) + '.s')
             subprocess.check_call(['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'),
-                                   '-munsafe-fp-atomics', '--cuda-device-only', '-S', src, '-o', out],
+                                   '-munsafe-fp-atomics', '-mllvm', '-amdgpu-kernarg-preload-count=16', '--cuda-device-only', '-S', src, '-o', out],
                                   cwd=CSRC, stderr=subprocess.DEVNULL)
             sites = scan(out)
             print('%-16s %d suspect site(s)' % (os.path.basename(src), len(sites)))
