@@ -145,3 +145,48 @@ def test_optimizer_keeps_the_weight_packs_current():
     eng._pack()
     torch.cuda.synchronize()
     assert eng._packs_fresh and torch.equal(kept, eng.packs)
+
+
+def test_backward_dependency_levels():
+    """The backward schedule (Engine._bwd_schedule): the 20 (block, scale) triples of the 8-block chain are 16
+    launches, the four two-member levels pair a large map of block b+1 with a small map of block b; no launch holds
+    two members that write the same map (tree nets: siblings accumulate into one parent map); and the level
+    launches give bit-identical results to one launch per triple."""
+    import numpy as np
+    import torch
+    import arch_and_hypers as A
+    net = A.ac_chain(k_cpt=1.6e-8)((32, 32, 3), (10,))
+    eng = net.engine()
+    eng.init_params(7)
+    order = [(kb, b, i) for kb, b in enumerate(reversed(eng.blocks)) for i in range(b.L - 1, -1, -1)]
+    groups = eng._bwd_schedule(order, 128)
+    assert sum(len(g) for g in groups) == 20 and len(groups) == 16
+    pairs = [sorted((m[1].H[m[2]] for m, _ in g), reverse=True) for g in groups if len(g) > 1]
+    assert pairs == [[16, 4], [16, 4], [16, 4], [32, 8]]
+    seen = set()
+    for g in groups:                                   # a topological order of Engine._bwd_deps
+        for (kb, b, i), _ in g:
+            assert all((id(d), j) in seen for d, j in eng._bwd_deps(b, i))
+        seen |= {(id(b), i) for (kb, b, i), _ in g}
+    tree = A.ac_tree(k_cpt=1e-9)((32, 32, 3), (10,))
+    te = tree.engine()
+    order = [(kb, b, i) for kb, b in enumerate(reversed(te.blocks)) for i in range(b.L - 1, -1, -1)]
+    for g in te._bwd_schedule(order, 16):
+        tg = [(id(b.parent), b.in_map[i]) for (kb, b, i), _ in g if b.parent is not None]
+        assert len(tg) == len(set(tg)) and len(g) <= 4
+    # levels on / off: the same arithmetic in the same order inside every body -> identical parameters
+    rng = np.random.default_rng(0)
+    x0 = rng.random((64, 32, 32, 3)).astype(np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 64)]
+    out = []
+    for levels in (True, False):
+        n2 = A.ac_chain(k_cpt=1.6e-8)((32, 32, 3), (10,))
+        e2 = n2.engine()
+        e2.init_params(7)
+        e2.bwd_levels = levels
+        n2.train.run({n2.x0: x0, n2.y: y, n2.mode: 'tr', n2.λ_lrn: 0.05, n2.τ: 1.0})
+        torch.cuda.synchronize()
+        out.append(e2.P.clone())
+    # ONE step (later steps amplify rounding chaotically); the weight-gradient split differs between the two
+    # schedules, so the slab sums round differently: agreement to fp32 rounding of the update, not bit for bit
+    assert float((out[0] - out[1]).abs().max()) <= 2e-6 * float(out[1].abs().max())
