@@ -31,6 +31,14 @@
 
 enum { EPI_FWD = 0, EPI_DGH_BN = 1, EPI_DGH_RAW = 2, EPI_DGV = 3 };
 
+// Ablation bits (skip the MFMAs / the staging / the epilogue of a unit; tools/ablate_conv.py): compiled in only with
+// -DMPNN_ABLATE -- as run-time tests they put five uniform branches into every unit of every production kernel.
+#ifdef MPNN_ABLATE
+#define MPNN_DBG(p, bit) ((p).dbg & (bit))
+#else
+#define MPNN_DBG(p, bit) 0
+#endif
+
 struct ConvP {
     mpnn_act a;                 // operand A (identity transform for dgrad)
     const float *v;  int Cv;    // operand V: the finer scale's pre-BN map, ALREADY 2x2-max-pooled by its producer
@@ -45,7 +53,7 @@ struct ConvP {
     // operand A = BatchNorm backward of dz (mpnn_bn_bwd_apply on load): A = k1*(dz - r0 - xhat*r1)
     const float *ga_s;  mpnn_act ga_bn;  const double *ga_red;  int ga_nslot;  int ga_on;
     int n_tiles;                                            // set by the launcher
-    int dbg;                                                // ablation mask (MPNN_CONV_DBG), 0 in production
+    int dbg;                                                // ablation mask (MPNN_CONV_DBG): only read in -DMPNN_ABLATE builds
     // Routed evaluation (IDX bodies): sample slot s of this launch is image idx[s] of EVERY buffer
     // (inputs, outputs, pooled map); `n` is then the device-side count of slots.  The gather and the
     // scatter are this indirection in the tile loader and the epilogue: no sub-batch is materialised.
@@ -318,9 +326,12 @@ __device__ __forceinline__ void ld_items(f32x4 (*xr)[XW], const ConvP &p, const 
 #pragma unroll
     for (int k = 0; k < ItemK<GK>::N; ++k) {
         const bool live = qin && ((tg.inb >> k) & 1);
-        const int off = live ? tg.pix[k] * C + c : 0;
-        xr[k][0] = *(const f32x4 *)(src + off);
-        if (KIND == 2 && p.ga_on) xr[k][1 % XW] = *(const f32x4 *)(src2 + off);      // (uniform)
+        // UNSIGNED 32-bit byte offset from a uniform base: the load takes the scalar-base + 32-bit-offset form
+        // (a signed element offset costs a sign extension and a 64-bit shift-add per load; the host keeps every
+        // activation tensor below 4 GB)
+        const unsigned off = live ? (unsigned)(tg.pix[k] * C + c) * 4u : 0u;
+        xr[k][0] = *(const f32x4 *)((const char *)src + off);
+        if (KIND == 2 && p.ga_on) xr[k][1 % XW] = *(const f32x4 *)((const char *)src2 + off);      // (uniform)
     }
 }
 // transform + LDS store of one chunk; `inb` is the tile's in-bounds mask the chunk was loaded with
@@ -504,7 +515,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             const int cs = KSPLIT ? kg : sc;
             const int uo = (q.ch + cs) * 16 * p.Cout;
 #pragma unroll
-            for (int k = 0; k < BN; ++k) bq[sc * BN + k] = *(const f32x4 *)(wp + (w_off(k, nch) + uo));
+            for (int k = 0; k < BN; ++k) bq[sc * BN + k] = *(const f32x4 *)((const char *)wp + (unsigned)(w_off(k, nch) + uo) * 4u);
         }
     };
     auto unit_store = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq, int buf, bool with_b) {
@@ -652,7 +663,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         // memory round trip less in the chain of every tile.
         [[maybe_unused]] float e_sv[MT][4][NT][4], e_dz[MT][4][NT][4];
         if constexpr (EPI == EPI_DGV) {
-            if ((!more || t2 != t) && !(p.dbg & 4)) {
+            if ((!more || t2 != t) && !MPNN_DBG(p, 4)) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -678,7 +689,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         // output pixels: requested before the last unit's MFMAs instead of in the epilogue.
         [[maybe_unused]] float h_sp[MT][4][NT], h_ex[MT][4][NT];
         if constexpr (EPI == EPI_DGH_BN) {
-            if ((!more || t2 != t) && !(p.dbg & 4)) {
+            if ((!more || t2 != t) && !MPNN_DBG(p, 4)) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -696,7 +707,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             }
         }
         // ----------------------------- MFMAs of unit u -----------------------------
-        if (!(p.dbg & 1)) {
+        if (!MPNN_DBG(p, 1)) {
             const f32x4 *wl = b_once ? wtile[0] : wtile[u & 1];
             const int wcol = wn * NT * 16 + li;
             if (SMALL_A && part == 0) {
@@ -751,11 +762,11 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         // ----------------------------- stage unit u+1 ------------------------------
         // BEFORE the epilogue: its wait then covers exactly the loads of unit u+2 issued above
         // (vmcnt(N)); behind the epilogue's conditional global stores the count would be unknown.
-        if (more && !(p.dbg & 2)) unit_store(n1, xn1, bn1, (u + 1) & 1, !b_once);
+        if (more && !MPNN_DBG(p, 2)) unit_store(n1, xn1, bn1, (u + 1) & 1, !b_once);
         if (u == 0) trace_stamp(9);
         // ----------------------------- epilogue of a finished tile -----------------
         // D layout: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel of the M-tile).
-        if ((!more || t2 != t) && !(p.dbg & 4)) {
+        if ((!more || t2 != t) && !MPNN_DBG(p, 4)) {
             if constexpr (KSPLIT) {                     // partial sums of the second K-group -> LDS -> first group
                 f32x4 *kred = (f32x4 *)pool_lds;         // [wave][lane]: the wave's own kilobyte of the pooling area
                 if (kg == 1) kred[wid * 64 + lane] = acc[0][0];

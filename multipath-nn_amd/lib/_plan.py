@@ -427,8 +427,9 @@ class Engine:
         dev = self.dev
         z = lambda *shape: torch.zeros(shape, device=dev)
         if n > self.n_max:
-            if n * 32 * 32 * 128 >= 2 ** 31:
-                raise ValueError('batch of %d samples: the kernels index activations with 32-bit offsets' % n)
+            biggest = max([b.H[i] * b.W[i] * b.C[i] for b in self.blocks for i in range(b.L)] + [int(np.prod(self.x0_shape))])
+            if n * biggest >= 2 ** 30:
+                raise ValueError('batch of %d samples: the kernels address an activation tensor with 32-bit byte offsets' % n)
             self.n_max = n
             self._progs.clear()
             self._graphs.clear()
