@@ -35,7 +35,7 @@ __device__ __forceinline__ void load_g(f32x4 *gr, f32x4 *gs, const WgP &p, int n
         const int n = n0 + img;
         // unconditional loads from a clamped address (no branch -> no vmcnt wait between items)
         const bool live = n < p.c.n;
-        const size_t off = live ? (((size_t)n * p.c.H + y0 + ty) * p.c.W + x0 + tx) * p.c.Cout + co0 + q * 4 : 0;
+        const unsigned off = live ? (((unsigned)n * p.c.H + y0 + ty) * p.c.W + x0 + tx) * p.c.Cout + co0 + q * 4 : 0u;
         gr[k] = *(const f32x4 *)(p.g + off);          // raw: out-of-range images are zeroed when stored
         if (p.g_on) gs[k] = *(const f32x4 *)(p.g_s + off);    // (uniform)
     }

@@ -162,12 +162,12 @@ __device__ __forceinline__ void load_x(f32x4 (*xr)[XW], const ConvP &p, int n0, 
         const bool live = ok && inb;
         const int c = c0 + q * 4;
         if (MODE == 2) {
-            const size_t off = live ? (((size_t)n * p.H + y) * p.W + x) * p.a.C + c : 0;
+            const unsigned off = live ? (((unsigned)n * p.H + y) * p.W + x) * p.a.C + c : 0u;
             xr[k][0] = *(const f32x4 *)(p.a.x + off);
             xr[k][1 % XW] = *(const f32x4 *)(p.ga_s + off);
         } else if (MODE == 0) {
             const int sh = p.a.shift, C = p.a.C;
-            const size_t base = live ? (((size_t)n * (p.H << sh) + (y << sh)) * (p.W << sh) + (x << sh)) * C : 0;
+            const unsigned base = live ? (((unsigned)n * (p.H << sh) + (y << sh)) * (p.W << sh) + (x << sh)) * C : 0u;
             if ((C & 3) == 0) {                    // uniform
                 xr[k][0] = *(const f32x4 *)(p.a.x + base + (live ? c : 0));
             } else {                               // raw image with 1 or 3 channels: clamped scalar loads
@@ -175,7 +175,7 @@ __device__ __forceinline__ void load_x(f32x4 (*xr)[XW], const ConvP &p, int n0, 
                 for (int j = 0; j < 4; ++j) xr[k][0][j] = p.a.x[base + (live && c + j < C ? c + j : 0)];
             }
         } else {                                   // pooled map of the finer scale: a plain operand
-            const size_t off = live ? (((size_t)n * p.H + y) * p.W + x) * p.Cv + c : 0;
+            const unsigned off = live ? (((unsigned)n * p.H + y) * p.W + x) * p.Cv + c : 0u;
             xr[k][0] = *(const f32x4 *)(p.v + off);
         }
     }
@@ -234,7 +234,8 @@ __device__ __forceinline__ int sel_i(int flag, int a, int b) { const int m = -fl
 // the compiler lost the address space and emitted flat loads, which also count against lgkmcnt and
 // made every LDS wait of the MFMA loop wait for the prefetch as well)
 __device__ __forceinline__ const float *sel_p(int flag, const float *a, const float *b) {
-    return a + (long)flag * (b - a);
+    const long delta = (const char *)b - (const char *)a;       // (loop-invariant at every call site)
+    return (const float *)((const char *)a + (delta & -(long)flag));
 }
 template <int GK> struct ItemK {
     static constexpr int N = XItems<GK>::N;
@@ -445,7 +446,10 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         mtile_pix<GK>(wm * MT + mt, li, img, ty, tx);
         slot0[mt] = (img * HR + ty) * R + tx;
     }
-    const int nchA = (p.a.C + 15) >> 4, nchV = p.v ? ((p.Cv + 15) >> 4) : 0;
+    // (operand V -- the pooled finer map -- exists in forward convs only: for the input-gradient bodies every
+    // operand select below folds to operand A at compile time)
+    constexpr bool HAS_V = EPI == EPI_FWD;
+    const int nchA = (p.a.C + 15) >> 4, nchV = (HAS_V && p.v) ? ((p.Cv + 15) >> 4) : 0;
     const int upt = (nchA + nchV) / NCH;            // NCH == 2: both counts are even (host-checked)
 
     // tile sequence of this workgroup: t = sq0, sq0 + sqd, ... < sqn; XCD-aware launches number the tiles of
@@ -473,7 +477,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     const int aC = p.a.C, vC = p.Cv;
     const float *const aX = p.a.x, *const vX = p.v, *const wAp = p.wa, *const wVp = p.wv;
     auto set_np = [&](UI &r) {
-        const int C = sel_i(r.part, aC, vC);
+        const int C = HAS_V ? sel_i(r.part, aC, vC) : aC;
         r.np = (C - r.ch * 16 + 3) >> 2;           // channel quads left from this chunk on (may exceed 4)
     };
     auto gen_tile = [&](UI &r, int t) {
@@ -490,8 +494,8 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     };
     auto gen_next = [&](UI &r) {
         r.ch += NCH;
-        if (r.ch >= sel_i(r.part, nchA, nchV)) {
-            if (!r.part && nchV) { r.part = 1; r.ch = 0; }
+        if (r.ch >= (HAS_V ? sel_i(r.part, nchA, nchV) : nchA)) {
+            if (HAS_V && !r.part && nchV) { r.part = 1; r.ch = 0; }
             else { gen_tile(r, r.t + sqd); return; }
         }
         set_np(r);
@@ -503,8 +507,8 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
     auto unit_load = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq) {
         // (operand selects on LOCALS: a select between two fields of the by-value kernel argument
         // was compiled to a scratch-memory table indexed by `part`)
-        const float *src = sel_p(q.part, aX, vX), *wp = sel_p(q.part, wAp, wVp);
-        const int C = sel_i(q.part, aC, vC), nch = sel_i(q.part, nchA, nchV);
+        const float *src = HAS_V ? sel_p(q.part, aX, vX) : aX, *wp = HAS_V ? sel_p(q.part, wAp, wVp) : wAp;
+        const int C = HAS_V ? sel_i(q.part, aC, vC) : aC, nch = HAS_V ? sel_i(q.part, nchA, nchV) : nchA;
 #pragma unroll
         for (int sc = 0; sc < SC; ++sc) {
             const int cs = KSPLIT ? kg : sc;           // chunk of the unit this thread group handles
@@ -674,8 +678,8 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                         const int W2 = p.W * 2;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            const size_t i00 = (((size_t)n * (p.H * 2) + 2 * y) * W2 + 2 * x) * p.Cout + cw + nt * 16;
-                            const size_t ix[4] = {i00, i00 + p.Cout, i00 + (size_t)W2 * p.Cout, i00 + (size_t)W2 * p.Cout + p.Cout};
+                            const unsigned i00 = (((unsigned)n * (p.H * 2) + 2 * y) * W2 + 2 * x) * p.Cout + cw + nt * 16;
+                            const unsigned ix[4] = {i00, i00 + p.Cout, i00 + (unsigned)W2 * p.Cout, i00 + (unsigned)W2 * p.Cout + p.Cout};
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 e_sv[mt][r][nt][k] = p.sprev[ix[k]];
@@ -699,7 +703,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                         const int n = n0 + img < p.n ? n0 + img : 0, y = y0 + ty, x = x0 + tx;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + cw + nt * 16;
+                            const unsigned idx = (((unsigned)n * p.H + y) * p.W + x) * p.Cout + cw + nt * 16;
                             h_sp[mt][r][nt] = p.sprev[idx];
                             h_ex[mt][r][nt] = p.extra ? p.extra[idx] : 0.f;
                         }
@@ -789,18 +793,18 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                         const int cl = co - co0;
                         float val = acc[mt][nt][r];
                         if (EPI == EPI_FWD) {
-                            const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
+                            const unsigned idx = (((unsigned)n * p.H + y) * p.W + x) * p.Cout + co;
                             val += bias_r[nt];
                             p.out[idx] = val;
                             s1[nt] += val; s2[nt] += val * val;
                             if (GK != 2 && p.pool_out) pool_lds[((wm * MT + mt) * 16 + g * 4 + r) * CT + cl] = val;
                         } else if (EPI == EPI_DGH_RAW) {
-                            const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
+                            const unsigned idx = (((unsigned)n * p.H + y) * p.W + x) * p.Cout + co;
                             if (p.extra) val += p.extra[idx];
                             if (p.acc_out) val += p.out[idx];
                             p.out[idx] = val;
                         } else if (EPI == EPI_DGH_BN) {
-                            const size_t idx = (((size_t)n * p.H + y) * p.W + x) * p.Cout + co;
+                            const unsigned idx = (((unsigned)n * p.H + y) * p.W + x) * p.Cout + co;
                             const float *e = cE + cl * 5;
                             const float d = h_sp[mt][r][nt] - e[0];
                             const float yv = d * e[2] + e[3];
@@ -810,9 +814,9 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                         } else {  // EPI_DGV: val = d(pooled fine map) at coarse pixel (y, x)
                             const float *e = cE + cl * 5;
                             const int W2 = p.W * 2;
-                            const size_t i00 = (((size_t)n * (p.H * 2) + 2 * y) * W2 + 2 * x) * p.Cout + co;
-                            const size_t ix[4] = {i00, i00 + p.Cout, i00 + (size_t)W2 * p.Cout,
-                                                  i00 + (size_t)W2 * p.Cout + p.Cout};
+                            const unsigned i00 = (((unsigned)n * (p.H * 2) + 2 * y) * W2 + 2 * x) * p.Cout + co;
+                            const unsigned ix[4] = {i00, i00 + p.Cout, i00 + (unsigned)W2 * p.Cout,
+                                                  i00 + (unsigned)W2 * p.Cout + p.Cout};
                             float sv[4];
 #pragma unroll
                             for (int k = 0; k < 4; ++k) sv[k] = e_sv[mt][r][nt][k];
@@ -843,7 +847,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
                         const float *q0 = pool_lds + ((2 * py) * ROW + 2 * px) * CT + c;
                         const float m4 = fmaxf(fmaxf(q0[0], q0[CT]), fmaxf(q0[ROW * CT], q0[ROW * CT + CT]));
                         const int np0 = IDX ? cu.im[0] : n0;          // (one image per tile in these geometries)
-                        p.pool_out[(((size_t)np0 * H2 + (y0 >> 1) + py) * W2 + (x0 >> 1) + px) * p.Cout + co0 + c] = m4;
+                        p.pool_out[(((unsigned)np0 * H2 + (y0 >> 1) + py) * W2 + (x0 >> 1) + px) * p.Cout + co0 + c] = m4;
                     }
                 }
             }
