@@ -24,23 +24,6 @@ template <> struct WGeom<0> { static constexpr int PS = 113; };
 template <> struct WGeom<1> { static constexpr int PS = 113; };
 template <> struct WGeom<2> { static constexpr int PS = 145; };
 
-template <int GK, int OT>
-__device__ __forceinline__ void load_g(f32x4 *gr, f32x4 *gs, const WgP &p, int n0, int y0, int x0, int co0, int tid) {
-#pragma unroll
-    for (int k = 0; k < OT; ++k) {
-        const int i = tid + k * 256;                   // 64 * OT * 4 items
-        const int q = i % (OT * 4), pi = i / (OT * 4);
-        int img, ty, tx;
-        mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
-        const int n = n0 + img;
-        // unconditional loads from a clamped address (no branch -> no vmcnt wait between items)
-        const bool live = n < p.c.n;
-        const unsigned off = live ? (((unsigned)n * p.c.H + y0 + ty) * p.c.W + x0 + tx) * p.c.Cout + co0 + q * 4 : 0u;
-        gr[k] = *(const f32x4 *)(p.g + off);          // raw: out-of-range images are zeroed when stored
-        if (p.g_on) gs[k] = *(const f32x4 *)(p.g_s + off);    // (uniform)
-    }
-}
-
 template <int GK, int OT, int PART>
 __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt, float *cA,
                                            const int bx, const int by, const int bz, const int gx) {
@@ -132,39 +115,101 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     // (64-channel groups, OT > 1, keep one set: two would not fit the register file.)
     constexpr int NS = OT == 1 ? MPNN_WG_SETS : 1;   // register sets = prefetch distance in tiles
     f32x4 xrS[NS][XN][1], grS[NS][OT], gsS[NS][OT];
-    int on0[NS], oy0[NS], ox0[NS];
+    int on0[NS];
+    unsigned inbS[NS];                                // in-bounds bits of the x items of the tile held in set S
+    // Lean staging (as conv_body): what does not depend on the tile -- an item's LDS slot and halo pixel, a g item's
+    // pixel and channel quad -- is computed ONCE per kernel; a tile costs a few multiply-adds per item.
+    ItemK<GK> ik;
+    item_consts<GK, PS>(ik, tid);
+    int g_geo[OT], g_lds[OT], g_c4[OT];               // img << 16 | ty << 8 | tx ; float index in gt ; channel offset
+#pragma unroll
+    for (int k = 0; k < OT; ++k) {
+        const int i = tid + k * 256;                   // 64 * OT * 4 items
+        const int q = i % (OT * 4), pi = i / (OT * 4);
+        int img, ty, tx;
+        mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
+        g_geo[k] = (img << 16) | (ty << 8) | tx;
+        g_lds[k] = pi * GS + q * 4;
+        g_c4[k] = q * 4;
+    }
+    const int xc = ch * 16 + ik.q * 4;                 // first channel of this thread's x items
+    const bool xq_in = ik.q < np;
+    const int sh = PART == 0 ? c.a.shift : 0;          // ToPyramid's strided pick (block 0); 0 elsewhere
+    const int xC = PART == 0 ? c.a.C : c.Cv;
+    const float *const xsrc = PART == 0 ? c.a.x : c.v;
     auto request = [&](auto sel, int t) {
         constexpr int S = decltype(sel)::value;
-        tile_origin<GK>(c, xa ? xcd_tile<GK>(t, xcd_id, tpi) : t, on0[S], oy0[S], ox0[S]);
-        load_x<GK, PART, 1>(xrS[S], c, on0[S], oy0[S], ox0[S], ch * 16, np, tid);
-        load_g<GK, OT>(grS[S], gsS[S], p, on0[S], oy0[S], ox0[S], co0, tid);
+        int n0, y0, x0;
+        tile_origin<GK>(c, xa ? xcd_tile<GK>(t, xcd_id, tpi) : t, n0, y0, x0);
+        on0[S] = n0;
+        unsigned inb = 0;
+#pragma unroll
+        for (int k = 0; k < XN; ++k) {
+            const int n = n0 + (ik.geo[k] >> 16), y = y0 + ((ik.geo[k] >> 8) & 255) - 1, x = x0 + (ik.geo[k] & 255) - 1;
+            const bool ok = ((ik.ok >> k) & 1) && xq_in && n < c.n && (unsigned)y < (unsigned)c.H && (unsigned)x < (unsigned)c.W;
+            inb |= (ok ? 1u : 0u) << k;
+            // unconditional loads from a clamped address (no branch -> no vmcnt wait between items)
+            const unsigned pix = ok ? (((unsigned)n * (c.H << sh) + (y << sh)) * (c.W << sh) + (x << sh)) * xC : 0u;
+            if (PART == 1 || (xC & 3) == 0) {          // (uniform)
+                xrS[S][k][0] = *(const f32x4 *)((const char *)xsrc + (pix + (ok ? xc : 0)) * 4u);
+            } else {                                   // raw image with 1 or 3 channels: clamped scalar loads
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xrS[S][k][0][j] = xsrc[pix + (ok && xc + j < xC ? xc + j : 0)];
+            }
+        }
+        inbS[S] = inb;
+#pragma unroll
+        for (int k = 0; k < OT; ++k) {
+            const int n = n0 + (g_geo[k] >> 16);
+            const bool live = n < c.n;
+            const unsigned off = live ? (((unsigned)n * c.H + y0 + ((g_geo[k] >> 8) & 255)) * c.W + x0 + (g_geo[k] & 255)) * c.Cout + co0 + g_c4[k] : 0u;
+            grS[S][k] = *(const f32x4 *)((const char *)p.g + off * 4u);          // raw: out-of-range images are zeroed when stored
+            if (p.g_on) gsS[S][k] = *(const f32x4 *)((const char *)p.g_s + off * 4u);    // (uniform)
+        }
     };
     auto tile_step = [&](auto sel, int t) {
         constexpr int S = decltype(sel)::value;
         f32x4 (*xr)[1] = xrS[S];
         f32x4 *gr = grS[S], *gs = gsS[S];
         const int o_n0 = on0[S];
+        const unsigned inb = inbS[S];
         lds_barrier();                                 // previous tile's LDS reads are done
-        store_x<GK, PS, PART, 1>(tile, xr, c, cA, on0[S], oy0[S], ox0[S], ch * 16, np, tid);
+#pragma unroll
+        for (int k = 0; k < XN; ++k) {
+            const bool live = (inb >> k) & 1;
+            f32x4 v = xr[k][0];
+            if (PART == 0) {
+                if (c.a.mode != MPNN_ACT_IDENTITY) {   // (uniform)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float *cc = cA + (xc + j) * 3;
+                        const float tv = fmaxf((v[j] - cc[0]) * cc[1] + cc[2], 0.f);
+                        v[j] = (xc + j < xC) ? tv : 0.f;
+                    }
+                } else if (xC & 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (xc + j < xC) ? v[j] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = live ? v[j] : 0.f;
+            if ((ik.ok >> k) & 1) tile[ik.slot[k]] = v;
+        }
 #pragma unroll
         for (int k = 0; k < OT; ++k) {
-            const int i = tid + k * 256;
-            const int q = i % (OT * 4), pi = i / (OT * 4);
-            int img, ty, tx;
-            mtile_pix<GK>(pi >> 4, pi & 15, img, ty, tx);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (o_n0 + img < c.n) {                    // (out-of-range images stay exactly zero)
+            if (o_n0 + (g_geo[k] >> 16) < c.n) {       // (out-of-range images stay exactly zero)
                 v = gr[k];
                 if (p.g_on) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float *e = cG + (q * 4 + j) * 5;
+                        const float *e = cG + (g_c4[k] + j) * 5;
                         const float xh = (gs[k][j] - e[0]) * e[1];
                         v[j] = e[2] * (v[j] - e[3] - xh * e[4]);
                     }
                 }
             }
-            *(f32x4 *)(gt + pi * GS + q * 4) = v;
+            *(f32x4 *)(gt + g_lds[k]) = v;
         }
         lds_barrier();
         if (t == sq0) trace_stamp(2);

@@ -130,98 +130,8 @@ template <int GK> struct XItems {
     static constexpr int N = (NHP8 * 4 + 255) / 256;      // items per thread
 };
 
-template <int GK>
-__device__ __forceinline__ bool x_item(int i, int n0, int y0, int x0, int np, const ConvP &p,
-                                       int &q, int &lds_slot, int &n, int &y, int &x, bool &inb) {
-    using X = XItems<GK>;
-    using G = Geom<GK>;
-    q = (i >> 3) & 3;
-    const int hp = ((i >> 5) << 3) + (i & 7);
-    if (hp >= X::NHP) return false;
-    const int img = hp / (X::HR * X::HC);
-    const int rem = hp - img * (X::HR * X::HC);
-    const int hy = rem / X::HC, hx = rem - hy * X::HC;
-    n = n0 + img; y = y0 + hy - 1; x = x0 + hx - 1;
-    lds_slot = (img * X::HR + hy) * G::R + hx;
-    inb = q < np && n < p.n && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-    return true;
-}
-
-// BRANCH-FREE: every item issues its load unconditionally from a clamped (always valid) address;
-// out-of-range items are zeroed by store_x.  With a branch around each load hipcc waits
-// vmcnt(0) between items and a thread's loads serialise (one full latency each: measured
-// 1.5 us per unit, more than the unit's MFMAs).
-template <int GK, int MODE, int XW>
-__device__ __forceinline__ void load_x(f32x4 (*xr)[XW], const ConvP &p, int n0, int y0, int x0, int c0, int np, int tid) {
-    using X = XItems<GK>;
-    static_assert(MODE != 2 || XW >= 2, "BatchNorm-backward-on-load needs two raw registers per item");
-#pragma unroll
-    for (int k = 0; k < X::N; ++k) {
-        int q, slot, n, y, x; bool inb;
-        const bool ok = x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb);
-        const bool live = ok && inb;
-        const int c = c0 + q * 4;
-        if (MODE == 2) {
-            const unsigned off = live ? (((unsigned)n * p.H + y) * p.W + x) * p.a.C + c : 0u;
-            xr[k][0] = *(const f32x4 *)(p.a.x + off);
-            xr[k][1 % XW] = *(const f32x4 *)(p.ga_s + off);
-        } else if (MODE == 0) {
-            const int sh = p.a.shift, C = p.a.C;
-            const unsigned base = live ? (((unsigned)n * (p.H << sh) + (y << sh)) * (p.W << sh) + (x << sh)) * C : 0u;
-            if ((C & 3) == 0) {                    // uniform
-                xr[k][0] = *(const f32x4 *)(p.a.x + base + (live ? c : 0));
-            } else {                               // raw image with 1 or 3 channels: clamped scalar loads
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xr[k][0][j] = p.a.x[base + (live && c + j < C ? c + j : 0)];
-            }
-        } else {                                   // pooled map of the finer scale: a plain operand
-            const unsigned off = live ? (((unsigned)n * p.H + y) * p.W + x) * p.Cv + c : 0u;
-            xr[k][0] = *(const f32x4 *)(p.v + off);
-        }
-    }
-}
-
-template <int GK, int PS, int MODE, int XW>
-__device__ __forceinline__ void store_x(f32x4 *tile, const f32x4 (*xr)[XW], const ConvP &p, const float *cA,
-                                        int n0, int y0, int x0, int c0, int np, int tid) {
-    using X = XItems<GK>;
-#pragma unroll
-    for (int k = 0; k < X::N; ++k) {
-        int q, slot, n, y, x; bool inb;
-        if (!x_item<GK>(tid + k * 256, n0, y0, x0, np, p, q, slot, n, y, x, inb)) continue;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (inb) {
-            if (MODE == 2) {                       // cA rows: m, rstd, k1, r0, r1
-                const int c = c0 + q * 4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float *cc = cA + (c + j) * 5;
-                    const float xh = (xr[k][1 % XW][j] - cc[0]) * cc[1];
-                    v[j] = cc[2] * (xr[k][0][j] - cc[3] - xh * cc[4]);
-                }
-            } else if (MODE == 0) {
-                v = xr[k][0];
-                const int c = c0 + q * 4;
-                if (p.a.mode != MPNN_ACT_IDENTITY) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float *cc = cA + (c + j) * 3;
-                        v[j] = (c + j < p.a.C) ? fmaxf((v[j] - cc[0]) * cc[1] + cc[2], 0.f) : 0.f;
-                    }
-                } else if (p.a.C & 3) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (c + j < p.a.C) ? v[j] : 0.f;
-                }
-            } else {
-                v = xr[k][0];
-            }
-        }
-        tile[q * PS + slot] = v;
-    }
-}
-
 // ---------------------------------------------------------------------------
-// Lean staging for conv_body.  Everything about an item that does not depend on the tile (its LDS
+// Lean staging (conv_body; wgrad_body in bwd_bodies.h does the same).  Everything about an item that does not depend on the tile (its LDS
 // slot, its halo pixel) is computed ONCE per kernel (ItemK); everything that depends on the tile
 // but not on the channel chunk (pixel index, in-bounds bit) once per TILE (TileGeo); a unit then
 // costs one multiply-add per item for its address.  (x_item recomputed all of it for every item
