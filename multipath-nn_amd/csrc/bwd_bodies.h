@@ -107,6 +107,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         }
     }
 
+    if constexpr (XItems<GK>::INTERIOR) zero_halo(tile, 4 * PS, tid, 256);       // the halo ring: zero for the whole kernel
     __syncthreads();
     trace_stamp(1);
     // Two register sets, prefetch distance two tiles: while tile t is in LDS under the MFMAs, tile
@@ -146,7 +147,8 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
 #pragma unroll
         for (int k = 0; k < XN; ++k) {
             const int n = n0 + (ik.geo[k] >> 16), y = y0 + ((ik.geo[k] >> 8) & 255) - 1, x = x0 + (ik.geo[k] & 255) - 1;
-            const bool ok = ((ik.ok >> k) & 1) && xq_in && n < c.n && (unsigned)y < (unsigned)c.H && (unsigned)x < (unsigned)c.W;
+            const bool ok = ((ik.ok >> k) & 1) && xq_in && n < c.n &&
+                            (XItems<GK>::INTERIOR || ((unsigned)y < (unsigned)c.H && (unsigned)x < (unsigned)c.W));
             inb |= (ok ? 1u : 0u) << k;
             // unconditional loads from a clamped address (no branch -> no vmcnt wait between items)
             const unsigned pix = ok ? (((unsigned)n * (c.H << sh) + (y << sh)) * (c.W << sh) + (x << sh)) * xC : 0u;
