@@ -589,9 +589,10 @@ class Engine:
 
     # Budget model of a level launch: relative latency of one work item of a body (a dgrad unit = a 16-channel chunk
     # of g for one 64-pixel tile and one 16-channel output row; a weight-gradient tile), from the phase traces
-    # (profiles/): dgrad-vert units carry the max-pool / BatchNorm-backward epilogue, 64-channel weight-gradient
-    # groups four times the MFMAs of 16-channel ones.
-    _LAT = dict(h=1.0, v=1.4, w1=float(os.environ.get('MPNN_LAT_W1', '1.0')), w4=float(os.environ.get('MPNN_LAT_W4', '2.6')))
+    # (profiles/) and a sweep of the step time (tools/knob_sweep.sh): dgrad-vert units carry the max-pool /
+    # BatchNorm-backward epilogue, a 16-channel weight-gradient tile is cheaper than a dgrad unit (nine-tap
+    # accumulation, lean staging), 64-channel groups have four times its MFMAs.
+    _LAT = dict(h=1.0, v=1.4, w1=float(os.environ.get('MPNN_LAT_W1', '0.75')), w4=float(os.environ.get('MPNN_LAT_W4', '2.6')))
 
     def _level_budget(self, grp, n):
         """Workgroups of every body of a level launch: the assignment that minimises the longest serial chain
