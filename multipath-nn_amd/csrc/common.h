@@ -188,6 +188,9 @@ __device__ __forceinline__ void mfma_drain() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// conv_first.hip: launches the record if it is the first conv of a net (0), or declines (1)
+int mpnn_first_conv_launch(const mpnn_conv_fwd_args *a, hipStream_t st);
+
 // XCD-aware tile order of the conv bodies (ConvP::xcd): on unless MPNN_XCD=0 (A/B measurements).
 static inline int xcd_env() {
     static const int v = [] { const char *e = getenv("MPNN_XCD"); return e ? atoi(e) : 1; }();

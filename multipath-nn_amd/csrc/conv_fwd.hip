@@ -109,6 +109,8 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         q.y0[k] = rows;
         rows += q.gy[k];
     }
+    // the first conv of a net (image -> 16 channels, no operand V): its own wave-per-tile kernel (conv_first.hip)
+    if (count == 1 && mpnn_first_conv_launch(&args[0], (hipStream_t)stream) == 0) return 0;
     // Share the resident workgroup slots between the members in proportion to their work, so that
     // every member is resident from the start.
     const int bytes[3] = {ConvSmem<0, 4, 16>::BYTES, ConvSmem<1, 4, 16>::BYTES, ConvSmem<2, 4, 16>::BYTES};

@@ -389,6 +389,31 @@ def test_one_member_group_equals_single_launch(shape):
     close(grp[0], ref, 2e-5)
 
 
+@pytest.mark.parametrize('case', [(32, 32, 3, 0, 11), (32, 32, 1, 0, 5), (16, 16, 4, 0, 7), (32, 32, 3, 1, 3), (16, 48, 2, 0, 4), (32, 32, 3, 0, 64)])
+@pytest.mark.parametrize('want_pool', [False, True])
+def test_first_conv_kernel(case, want_pool):
+    """The first conv of a net (image -> 16 channels, no operand V) runs in its own wave-per-tile kernel when
+    it is launched as a one-member group (conv_first.hip): outputs and the pooled map BIT-IDENTICAL to the
+    general body's (mpnn_msconv_fwd), the statistics the same sums in another order; against the oracle."""
+    import hiputil as U
+    from lib import _hip
+    H, W, ca, shift, n = case
+    rng = np.random.default_rng(H * 7 + W + ca + shift + n)
+    x = rng.standard_normal((n, H << shift, W << shift, ca)).astype(np.float32)
+    wh = (rng.standard_normal((3, 3, ca, 16)) / np.sqrt(9 * ca)).astype(np.float32)
+    b = (rng.standard_normal(16) * 0.1).astype(np.float32)
+    one = U.conv_fwd(x, wh, b, None, None, None, _hip.ACT_IDENTITY, shift, 1, want_pool=want_pool)
+    grp = U.conv_fwd(x, wh, b, None, None, None, _hip.ACT_IDENTITY, shift, 1, want_pool=want_pool, group=True)
+    assert np.array_equal(grp[0], one[0])
+    if want_pool:
+        assert np.array_equal(grp[2], one[2])
+    close(grp[1], one[1], 1e-5)
+    ref = O.conv_same(x[:, ::1 << shift, ::1 << shift, :].astype(np.float64), wh.astype(np.float64)) + b
+    close(grp[0], ref, 2e-5)
+    close(grp[1][:16], ref.sum(axis=(0, 1, 2)), 1e-4)
+    close(grp[1][16:], (ref * ref).sum(axis=(0, 1, 2)), 1e-4)
+
+
 def _hip_mode():
     from lib import _hip
     return _hip.ACT_BN_BATCH
