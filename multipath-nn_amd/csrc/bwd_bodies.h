@@ -94,7 +94,9 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     }
 
     float *cG = cA + 128 * 3;                        // [OT*16][5]: BatchNorm-backward coefficients of this cout group
-    if (p.g_on) {
+    if (p.g_on && p.g_bn.mode == MPNN_ACT_BN_BATCH) {    // (training: every input of a row in one round trip)
+        for (int cc = tid - 128; cc >= 0 && cc < OT * 16; cc += 256) bn_bwd_row(p.g_bn, p.g_red, p.g_nslot, co0 + cc, false, cG + cc * 5);
+    } else if (p.g_on) {
         const double inv = 1.0 / (double)p.g_bn.cnt;
         for (int cc = tid - 128; cc >= 0 && cc < OT * 16; cc += 256) {     // waves 2-3: beside the table above
             const int co = co0 + cc;

@@ -120,6 +120,43 @@ __device__ __forceinline__ BnC bn_coef(const mpnn_act &b, int c) {
     return k;
 }
 
+// The five BatchNorm-backward coefficients of one channel -- mean, rstd, gamma * rstd and the two backward reductions
+// scaled by 1 / count (or beta, 0 with want_beta) -- with EVERY input requested before the first is used: gamma, beta,
+// the slot sums and the slot reductions are ONE memory round trip (bn_coef followed by slot_sum2 was two to three
+// dependent ones, and the coefficient tables are the first thing every backward workgroup waits for).
+// Same summation order as bn_coef / slot_sum2 (slots ascending from 0.0): identical bits.  Batch-statistics mode only
+// (the callers fall back to bn_coef otherwise).
+// (Splitting this into a request half and a finish half with the first tile's loads issued in between -- so that the
+// tables cost no round trip of their own -- was measured SLOWER, 493 -> 498 us per step: 66 more live registers in the
+// prologue, spills in the 64-channel weight-gradient variants, and the prologue is bound by its instruction count, not
+// by the round trip.)
+__device__ __forceinline__ void bn_bwd_row(const mpnn_act &b, const double *red, int red_nslot, int c, bool want_beta, float *e) {
+    const int C2 = 2 * b.C, ns = b.nslot, rn = red ? red_nslot : 0;
+    const double *rp = red ? red : b.sum;              // (clamped loads need a valid address)
+    const float gamma = b.gamma[c], beta = b.beta[c];
+    double a0[8], a1[8], q0[8], q1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { const int ss = s < ns ? s : 0; a0[s] = b.sum[ss * C2 + c]; a1[s] = b.sum[ss * C2 + b.C + c]; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { const int ss = s < rn ? s : 0; q0[s] = rp[ss * C2 + c]; q1[s] = rp[ss * C2 + b.C + c]; }
+    double s1 = 0.0, s2 = 0.0, r0 = 0.0, r1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s < ns) { s1 += a0[s]; s2 += a1[s]; }
+        if (s < rn) { r0 += q0[s]; r1 += q1[s]; }
+    }
+    for (int s = 8; s < ns; ++s) { s1 += b.sum[s * C2 + c]; s2 += b.sum[s * C2 + b.C + c]; }          // (more than 8 slots: rare)
+    for (int s = 8; s < rn; ++s) { r0 += rp[s * C2 + c]; r1 += rp[s * C2 + b.C + c]; }
+    const double inv = 1.0 / (double)b.cnt;
+    const double mean = s1 * inv;
+    double var = s2 * inv - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = rsqrtf((float)var + b.eps);
+    e[0] = (float)mean; e[1] = rstd; e[2] = gamma * rstd;
+    if (want_beta) { e[3] = beta; e[4] = 0.f; }
+    else { e[3] = (float)(r0 * inv); e[4] = (float)(r1 * inv); }
+}
+
 // One BatchNorm of mpnn_bn_finalize (table record t: see misc.hip): moving averages from the forward
 // sums, dgamma / dbeta from the backward reductions.  Shared by bn_finalize_k and backward_finish_k.
 __device__ __forceinline__ void bn_finalize_body(double *__restrict__ sums, double *__restrict__ reds,

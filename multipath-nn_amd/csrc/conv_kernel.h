@@ -539,21 +539,30 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             cA[c * 3] = k.m; cA[c * 3 + 1] = k.gamma * k.rstd; cA[c * 3 + 2] = k.beta;
         }
     }
+    // (training: batch statistics -- bn_bwd_row requests every input of a row at once; other modes: the general path)
     if (EPI != EPI_FWD && p.ga_on) {
-        const double inv = 1.0 / (double)p.ga_bn.cnt;
-        for (int c = tid; c < p.a.C; c += 256) {
-            const BnC k = bn_coef(p.ga_bn, c);
-            float *e = cA + c * 5;
-            e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
-            double r0, r1;
-            slot_sum2(p.ga_red, 2 * p.a.C, c, p.a.C + c, p.ga_nslot, r0, r1);
-            e[3] = (float)(r0 * inv); e[4] = (float)(r1 * inv);
+        if (p.ga_bn.mode == MPNN_ACT_BN_BATCH) {               // (uniform)
+            for (int c = tid; c < p.a.C; c += 256) bn_bwd_row(p.ga_bn, p.ga_red, p.ga_nslot, c, false, cA + c * 5);
+        } else {
+            const double inv = 1.0 / (double)p.ga_bn.cnt;
+            for (int c = tid; c < p.a.C; c += 256) {
+                const BnC k = bn_coef(p.ga_bn, c);
+                float *e = cA + c * 5;
+                e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
+                double r0, r1;
+                slot_sum2(p.ga_red, 2 * p.a.C, c, p.a.C + c, p.ga_nslot, r0, r1);
+                e[3] = (float)(r0 * inv); e[4] = (float)(r1 * inv);
+            }
         }
     }
     if (EPI == EPI_DGH_BN || EPI == EPI_DGV) {
         for (int c = tid - 128; c >= 0 && c < CT; c += 256) {     // waves 2-3: beside the table above
-            const BnC k = bn_coef(p.pbn, co0 + c);
             float *e = cE + c * 5;
+            if (p.pbn.mode == MPNN_ACT_BN_BATCH) {             // (uniform)
+                bn_bwd_row(p.pbn, EPI == EPI_DGV ? p.red : nullptr, p.red_nslot, co0 + c, EPI == EPI_DGH_BN, e);
+                continue;
+            }
+            const BnC k = bn_coef(p.pbn, co0 + c);
             e[0] = k.m; e[1] = k.rstd; e[2] = k.gamma * k.rstd;
             if (EPI == EPI_DGH_BN) { e[3] = k.beta; e[4] = 0.f; }
             else {

@@ -1,4 +1,6 @@
-"""Per-launch table of the DENSE evaluation program at a statistics-pass batch (HIP events around every launch)."""
+"""Per-launch table of the evaluation program at a statistics-pass batch (HIP events around every launch).
+    python tools/eval_table.py [batch] [routed]        (default: the dense program)
+"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'multipath-nn_amd'))
@@ -12,7 +14,8 @@ eng._ensure_capacity(nb, train=False)
 eng.x0[:nb].copy_(x); eng.y[:nb].copy_(y)
 feed = {net.x0: eng.x0[:nb], net.y: eng.y[:nb]}
 for _ in range(3): net.eval(feed)
-prog = eng.program('ev', nb, routed=False)
+routed = len(sys.argv) > 2 and sys.argv[2] == 'routed'
+prog = eng.program('ev', nb, routed=routed)
 st = torch.cuda.current_stream()
 tot = [0.0] * len(prog['fwd'])
 for rep in range(6):

@@ -34,7 +34,7 @@ buf = torch.zeros(NWG * SL, dtype=torch.int64, device=eng.dev)
 KIND = {1: 'fwd', 2: 'dgh_bn', 3: 'dgh_raw', 4: 'dgv', 8: 'wgrad', 10: 'lin_fwd', 11: 'lin_bwd', 12: 'tail_fwd', 13: 'tail_bwd', 14: 'route'}
 NAMES = ['start', 'tables', 'staged', 'unit0', 'loop', 'exit']
 for op in ops:
-    if op.what not in ('fwd_group', 'msconv_fwd', 'bwd_scale', 'lin_fwd', 'lin_bwd', 'exit_tail_fwd', 'exit_tail_bwd', 'route') or (want not in op.tag and want != op.what):
+    if op.what not in ('fwd_group', 'msconv_fwd', 'bwd_scale', 'bwd_level', 'lin_fwd', 'lin_bwd', 'exit_tail_fwd', 'exit_tail_bwd', 'route') or (want not in op.tag and want != op.what):
         continue
     for _ in range(2): op(st.cuda_stream)            # warm caches
     torch.cuda.synchronize()
