@@ -85,16 +85,25 @@ struct BnC { float m, rstd, gamma, beta; };
 
 // Sums of TWO statistics over the replicated slots in one loop: the loads of both are in flight
 // together, 8 slots per round trip (16 slots = 2 dependent round trips instead of 8).
+// (Addressing: a UNIFORM row pointer per slot plus the lane's 32-bit byte offset -- the load takes the scalar-base +
+// vector-offset form and costs no vector arithmetic; `base[s * C2 + i]` with 64-bit index arithmetic was six
+// instructions per load, and this code is the first thing every workgroup of a launch executes.)
+__device__ __forceinline__ double ld_slot(const double *base, int C2, int s, unsigned off) {
+    const char *row = (const char *)(base + (size_t)s * C2);             // uniform
+    return *(const double *)(row + off);
+}
 __device__ __forceinline__ void slot_sum2(const double *base, int C2, int i0, int i1, int nslot, double &a, double &b) {
     double t0 = 0.0, t1 = 0.0;
+    const unsigned o0 = (unsigned)i0 * 8u, o1 = (unsigned)i1 * 8u;
 #pragma unroll 8
-    for (int s = 0; s < nslot; ++s) { t0 += base[s * C2 + i0]; t1 += base[s * C2 + i1]; }
+    for (int s = 0; s < nslot; ++s) { t0 += ld_slot(base, C2, s, o0); t1 += ld_slot(base, C2, s, o1); }
     a = t0; b = t1;
 }
 __device__ __forceinline__ double slot_sum(const double *base, int C2, int idx, int nslot) {
     double t = 0.0;
+    const unsigned o = (unsigned)idx * 8u;
 #pragma unroll 8
-    for (int s = 0; s < nslot; ++s) t += base[s * C2 + idx];
+    for (int s = 0; s < nslot; ++s) t += ld_slot(base, C2, s, o);
     return t;
 }
 
@@ -132,21 +141,30 @@ __device__ __forceinline__ BnC bn_coef(const mpnn_act &b, int c) {
 // by the round trip.)
 __device__ __forceinline__ void bn_bwd_row(const mpnn_act &b, const double *red, int red_nslot, int c, bool want_beta, float *e) {
     const int C2 = 2 * b.C, ns = b.nslot, rn = red ? red_nslot : 0;
-    const double *rp = red ? red : b.sum;              // (clamped loads need a valid address)
     const float gamma = b.gamma[c], beta = b.beta[c];
-    double a0[8], a1[8], q0[8], q1[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) { const int ss = s < ns ? s : 0; a0[s] = b.sum[ss * C2 + c]; a1[s] = b.sum[ss * C2 + b.C + c]; }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) { const int ss = s < rn ? s : 0; q0[s] = rp[ss * C2 + c]; q1[s] = rp[ss * C2 + b.C + c]; }
+    const unsigned o0 = (unsigned)c * 8u, o1 = (unsigned)(b.C + c) * 8u;
     double s1 = 0.0, s2 = 0.0, r0 = 0.0, r1 = 0.0;
+    if (ns == 8 && (rn == 8 || rn == 0)) {             // (uniform; what the engine uses: nothing predicated, ~100 instructions)
+        double a0[8], a1[8], q0[8], q1[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        if (s < ns) { s1 += a0[s]; s2 += a1[s]; }
-        if (s < rn) { r0 += q0[s]; r1 += q1[s]; }
+        for (int s = 0; s < 8; ++s) { a0[s] = ld_slot(b.sum, C2, s, o0); a1[s] = ld_slot(b.sum, C2, s, o1); }
+        if (rn) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { q0[s] = ld_slot(red, C2, s, o0); q1[s] = ld_slot(red, C2, s, o1); }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { q0[s] = 0.0; q1[s] = 0.0; }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { s1 += a0[s]; s2 += a1[s]; }
+        if (rn) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { r0 += q0[s]; r1 += q1[s]; }
+        }
+    } else {
+        slot_sum2(b.sum, C2, c, b.C + c, ns, s1, s2);
+        if (rn) slot_sum2(red, C2, c, b.C + c, rn, r0, r1);
     }
-    for (int s = 8; s < ns; ++s) { s1 += b.sum[s * C2 + c]; s2 += b.sum[s * C2 + b.C + c]; }          // (more than 8 slots: rare)
-    for (int s = 8; s < rn; ++s) { r0 += rp[s * C2 + c]; r1 += rp[s * C2 + b.C + c]; }
     const double inv = 1.0 / (double)b.cnt;
     const double mean = s1 * inv;
     double var = s2 * inv - mean * mean;
