@@ -1,3 +1,7 @@
+"""Ablation of the conv bodies (skip the MFMAs / the staging / the epilogue of a unit, MPNN_CONV_DBG bits 1 / 2 / 4) on a few
+launches of the training step.  Needs a library built with the ablation branches compiled in:
+    make -C multipath-nn_amd/csrc EXTRA=-DMPNN_ABLATE      (production builds fold them away)
+"""
 import sys, os, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'multipath-nn_amd'))
