@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, SMALL ? 3 : MPNN_OCC) void fwd_group_k(const m
         case 0: p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
         case 2: p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
         case 4: p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
-        case 6: strip16_body<IDX>(tab[m], id - w0, gx, q.rh[m], q.xcd, smem); break;       // 16 -> 16 channels on a big map (conv_strip.h)
+        case 6: strip16_body<IDX>(tab[m], bx, yy, gx, q.rh[m], q.xcd, smem); break;        // 16 -> 16 k channels on a big map (conv_strip.h)
         default:
             if constexpr (SMALL) {
                 if (kind == 1)      { p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, true, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); }
@@ -105,7 +105,7 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         if (!q.small[k] && (p.a.C & 3)) return MPNN_E_SHAPE;
         static const int strip_env = [] { const char *e = getenv("MPNN_STRIP"); return e ? atoi(e) : 512; }();     // minimum batch, 0 = off
         // (evaluation batches only: at the training batch a strip per wave leaves the chip half empty -- 14.7 against 13.3 us)
-        if (strip_env && p.n >= strip_env && p.W >= 16 && (p.W % 16) == 0 && (p.H % 4) == 0 && p.a.C == 16 && p.Cout == 16 && !args[k].v &&
+        if (strip_env && p.n >= strip_env && p.W >= 16 && (p.W % 16) == 0 && (p.H % 4) == 0 && p.a.C == 16 && !args[k].v &&
             (!args[k].pool_out || !(p.H & 1))) {
             q.gk[k] = 3;  p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W);        // (64-pixel tiles: the unit of the work shares)
         } else
@@ -113,7 +113,7 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         else if (p.W == 8 && p.H == 8) { q.gk[k] = 1; p.n_tiles = conv_grid_x<1>(p.n, 8, 8); }
         else if (p.W == 4 && p.H == 4) { q.gk[k] = 2; p.n_tiles = conv_grid_x<2>(p.n, 4, 4); }
         else return MPNN_E_SHAPE;
-        q.gy[k] = q.gk[k] == 3 ? 1 : p.Cout / 16;
+        q.gy[k] = p.Cout / 16;
         q.y0[k] = rows;
         rows += q.gy[k];
     }

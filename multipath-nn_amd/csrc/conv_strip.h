@@ -1,4 +1,4 @@
-// Forward conv of a 16-channel map into 16 channels on the big maps (W % 16 == 0: the 32x32 / 16x16 scales of the
+// Forward conv of a 16-channel map into 16 k channels (a workgroup row per 16 of them) on the big maps (W % 16 == 0: the 32x32 / 16x16 scales of the
 // first blocks), no operand V: a WAVE walks a strip of 16 pixels x `rh` rows top to bottom and nothing is shared
 // between waves -- no LDS tiles, no barrier.
 //
@@ -19,12 +19,12 @@
 struct StripSeq { int ij, ys, xs; };      // image index in the wave's sequence, row segment, column strip
 
 template <bool IDX>
-__device__ __forceinline__ void strip16_body(const mpnn_conv_fwd_args &a, const int bx, const int gx, const int rh,
+__device__ __forceinline__ void strip16_body(const mpnn_conv_fwd_args &a, const int bx, const int by, const int gx, const int rh,
                                              const int xcd, char *smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
-    const int H = a.H, W = a.W;
+    const int H = a.H, W = a.W, Co = a.Cout, co0 = by * 16;      // this workgroup's 16 output channels
     int n_img = a.n;
     if (a.cnt) { const int c = *a.cnt; n_img = c < a.n ? c : a.n; }        // device-side count of the routed sub-batch
     const int xs_n = W >> 4, ys_n = H / rh, tpi = xs_n * ys_n;
@@ -49,8 +49,8 @@ __device__ __forceinline__ void strip16_body(const mpnn_conv_fwd_args &a, const 
     // weights: fragment of (tap t, k-step j) = W[t][ci = 4g + j][co = li]; forward pack [tap][ci / 4][Cout][4]
     f32x4 wr[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wr[t] = *(const f32x4 *)(a.wa_pack + t * 256 + (g * 16 + li) * 4);
-    const f32x4 bias4 = *(const f32x4 *)(a.bias + g * 4);
+    for (int t = 0; t < 9; ++t) wr[t] = *(const f32x4 *)(a.wa_pack + t * 16 * Co + (g * Co + co0 + li) * 4);
+    const f32x4 bias4 = *(const f32x4 *)(a.bias + co0 + g * 4);
 
     // strips of this wave: jw, jw + nw, ... of the launch's sequence (XCD-aware: of its own XCD's images, conv_kernel.h)
     const bool xa = xcd != 0 && (a.n & 31) == 0 && (gx & 7) == 0 && !IDX;
@@ -75,8 +75,8 @@ __device__ __forceinline__ void strip16_body(const mpnn_conv_fwd_args &a, const 
         // lane offsets of the three column shifts (edge lanes of edge strips read the middle one and are zeroed)
         const int o0 = off1 - 64 + (64 & -(int)zl), o2 = off1 + 64 - (64 & -(int)zr);
         const char *xin = (const char *)a.a.x + (((long)n * H) * W + x0) * 64;
-        float *outp = a.out + (((long)n * H) * W + x0) * 16 + (li * 16 + g * 4);
-        float *poolp = pool ? a.pool_out + (((long)n * (H >> 1)) * (W >> 1) + (x0 >> 1)) * 16 + ((li >> 1) * 16 + g * 4) : nullptr;
+        float *outp = a.out + (((long)n * H) * W + x0 + li) * Co + co0 + g * 4;
+        float *poolp = pool ? a.pool_out + (((long)n * (H >> 1)) * (W >> 1) + (x0 >> 1) + (li >> 1)) * Co + co0 + g * 4 : nullptr;
 
         // halo row y: raw loads (a row outside the image reads row 0 and is zeroed on use)
         auto load_row = [&](int y, f32x4 *r) {
@@ -115,7 +115,7 @@ __device__ __forceinline__ void strip16_body(const mpnn_conv_fwd_args &a, const 
         // output row y is complete: bias, store, statistics, pooled row every second row
         auto finish = [&](f32x4 acc, int y) {
             acc += bias4;
-            *(f32x4 *)(outp + (long)y * W * 16) = acc;
+            *(f32x4 *)(outp + (long)y * W * Co) = acc;
             if (stats) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { s1[c] += acc[c]; s2[c] += acc[c] * acc[c]; }
@@ -129,7 +129,7 @@ __device__ __forceinline__ void strip16_body(const mpnn_conv_fwd_args &a, const 
                         const float o = __builtin_bit_cast(float, dpp_i<MPNN_DPP_QUAD_XOR1>(__builtin_bit_cast(int, q)));
                         m[c] = fmaxf(q, o);
                     }
-                    *(f32x4 *)(poolp + (long)(y >> 1) * (W >> 1) * 16) = m;      // (both lanes of a pair store the same value)
+                    *(f32x4 *)(poolp + (long)(y >> 1) * (W >> 1) * Co) = m;      // (both lanes of a pair store the same value)
                 }
                 prev_out = acc;
             }
@@ -193,9 +193,9 @@ __device__ __forceinline__ void strip16_body(const mpnn_conv_fwd_args &a, const 
 #pragma unroll
             for (int w = 0; w < 4; ++w) { a1 += red[(w * 16 + tid) * 2]; a2 += red[(w * 16 + tid) * 2 + 1]; }
             const int nslot = a.out_nslot < 1 ? 1 : (a.out_nslot > MPNN_BN_SLOTS ? MPNN_BN_SLOTS : a.out_nslot);
-            double *slot = a.out_sum + (size_t)(bx % nslot) * 2 * 16;
-            atomicAdd(slot + tid, a1);
-            atomicAdd(slot + 16 + tid, a2);
+            double *slot = a.out_sum + (size_t)(bx % nslot) * 2 * Co;
+            atomicAdd(slot + co0 + tid, a1);
+            atomicAdd(slot + Co + co0 + tid, a2);
         }
     }
 }

@@ -414,20 +414,20 @@ def test_first_conv_kernel(case, want_pool):
     close(grp[1][16:], (ref * ref).sum(axis=(0, 1, 2)), 1e-4)
 
 
-@pytest.mark.parametrize('case', [(32, 32, 512), (16, 16, 515), (16, 48, 512), (8, 16, 640)])
+@pytest.mark.parametrize('case', [(32, 32, 512, 16), (16, 16, 515, 32), (16, 48, 512, 16), (8, 16, 640, 64)])
 @pytest.mark.parametrize('bn', [False, True])
 @pytest.mark.parametrize('want_pool', [False, True])
 def test_strip_conv_kernel(case, bn, want_pool):
-    """16 -> 16 channels on a big map without operand V runs in the wave-per-strip body when it is a member of a
+    """16 -> 16 k channels on a big map without operand V runs in the wave-per-strip body when it is a member of a
     group launch of an evaluation-size batch (>= 512 samples; conv_strip.h): outputs and the pooled map BIT-IDENTICAL to the general body's (mpnn_msconv_fwd),
     the statistics the same sums in another order; against the oracle."""
     import hiputil as U
     from lib import _hip
-    H, W, n = case
+    H, W, n, co = case
     rng = np.random.default_rng(H * 7 + W + n)
     x = rng.standard_normal((n, H, W, 16)).astype(np.float32)
-    wh = (rng.standard_normal((3, 3, 16, 16)) / 12).astype(np.float32)
-    b = (rng.standard_normal(16) * 0.1).astype(np.float32)
+    wh = (rng.standard_normal((3, 3, 16, co)) / 12).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
     gamma, beta = rng.uniform(0.5, 1.5, 16), rng.standard_normal(16) * 0.3
     bnd, cnt = U.bn_dict(x, gamma, beta) if bn else (None, 1)
     mode = _hip.ACT_BN_BATCH if bn else _hip.ACT_IDENTITY
