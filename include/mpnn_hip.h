@@ -123,8 +123,13 @@ int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
  * members by work.  A single member on an 8x8 / 4x4 map with >= 64 input channels (multiples of
  * 32 per operand) in TRAINING mode (a.mode == MPNN_ACT_BN_BATCH) takes the K-split body (512
  * threads, two chunks of a 32-channel unit in parallel); results are the same up to fp32 summation
- * order.  Evaluation-mode launches always use the one-chunk body, so a conv gives bit-identical
- * rows whether it runs grouped or alone, on all samples or on a routed sub-batch. */
+ * order.  Evaluation-mode launches never take it.  Members on maps with W % 16 == 0 whose input is
+ * one to three 16-channel chunks (no 1/3-channel image operand) take the wave-per-strip bodies of
+ * conv_strip.h when the record's sample capacity `n` is >= 512 (MPNN_STRIP: minimum, 0 = off): the
+ * one-chunk body gives the same bits as mpnn_msconv_fwd, the multi-chunk body the same values up
+ * to fp32 summation order.  Which body runs depends only on the shapes and on `n` -- never on the
+ * grouping, the index list or the device-side count -- so a conv gives bit-identical rows on all
+ * samples or on a routed sub-batch of the same capacity. */
 int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
                           void *stream);
 

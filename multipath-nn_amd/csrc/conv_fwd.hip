@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256, SMALL ? 3 : MPNN_OCC) void fwd_group_k(const m
         case 2: p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
         case 4: p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
         case 6: strip16_body<IDX>(tab[m], bx, yy, gx, q.rh[m], q.xcd, smem); break;        // 16 -> 16 k channels on a big map (conv_strip.h)
+        case 8: stripk_body<IDX>(tab[m], bx, yy, gx, q.rh[m], q.xcd, smem); break;         // the same with 2-3 input chunks
         default:
             if constexpr (SMALL) {
                 if (kind == 1)      { p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, true, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); }
@@ -105,9 +106,10 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         if (!q.small[k] && (p.a.C & 3)) return MPNN_E_SHAPE;
         static const int strip_env = [] { const char *e = getenv("MPNN_STRIP"); return e ? atoi(e) : 512; }();     // minimum batch, 0 = off
         // (evaluation batches only: at the training batch a strip per wave leaves the chip half empty -- 14.7 against 13.3 us)
-        if (strip_env && p.n >= strip_env && p.W >= 16 && (p.W % 16) == 0 && (p.H % 4) == 0 && p.a.C == 16 && !args[k].v &&
-            (!args[k].pool_out || !(p.H & 1))) {
-            q.gk[k] = 3;  p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W);        // (64-pixel tiles: the unit of the work shares)
+        const int kch = (p.a.C >> 4) + (args[k].v ? (p.Cv >> 4) : 0);                  // 16-channel chunks of input
+        if (strip_env && p.n >= strip_env && p.W >= 16 && (p.W % 16) == 0 && (p.H % 4) == 0 && (p.a.C % 16) == 0 && p.a.C >= 16 &&
+            (!args[k].v || (p.Cv % 16) == 0) && kch <= MPNN_STRIP_KMAX && (!args[k].pool_out || !(p.H & 1))) {
+            q.gk[k] = kch == 1 ? 3 : 4;  p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W);        // (64-pixel tiles: the unit of the work shares)
         } else
         if (p.W >= 16 && (p.W % 16) == 0 && (p.H % 4) == 0) { q.gk[k] = 0; p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); }
         else if (p.W == 8 && p.H == 8) { q.gk[k] = 1; p.n_tiles = conv_grid_x<1>(p.n, 8, 8); }
@@ -121,15 +123,15 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
     if (count == 1 && mpnn_first_conv_launch(&args[0], (hipStream_t)stream) == 0) return 0;
     // Share the resident workgroup slots between the members in proportion to their work, so that
     // every member is resident from the start.
-    const int bytes[4] = {ConvSmem<0, 4, 16>::BYTES, ConvSmem<1, 4, 16>::BYTES, ConvSmem<2, 4, 16>::BYTES, 2048};
+    const int bytes[5] = {ConvSmem<0, 4, 16>::BYTES, ConvSmem<1, 4, 16>::BYTES, ConvSmem<2, 4, 16>::BYTES, 2048, strip_lds_bytes(MPNN_STRIP_KMAX)};
     int lds = 0;
     for (int k = 0; k < count; ++k) if (bytes[q.gk[k]] > lds) lds = bytes[q.gk[k]];
     // a single deep member on a small map: 128-256 workgroups of 4 waves would leave every SIMD with one
     // wave and nothing to overlap -> K-split body (two thread groups per workgroup, 32-channel units)
     static const int ks_env = [] { const char *e = getenv("MPNN_FWD_KSPLIT"); return e ? atoi(e) : 1; }();
-    // (training launches only: the evaluation path keeps ONE summation order per conv whether it runs
-    // grouped, alone, dense or routed, so routed and dense evaluation agree bit for bit)
-    if (ks_env && !any_idx && hp[0].a.mode == MPNN_ACT_BN_BATCH && count == 1 && q.gk[0] != 0 && q.gk[0] != 3 && !q.small[0] && (hp[0].a.C % 32) == 0 && (hp[0].Cv % 32) == 0 &&
+    // (training launches only: in the evaluation path the body of a conv depends on its shapes and its sample
+    // capacity alone, so routed and dense evaluation of a batch agree bit for bit)
+    if (ks_env && !any_idx && hp[0].a.mode == MPNN_ACT_BN_BATCH && count == 1 && q.gk[0] != 0 && q.gk[0] < 3 && !q.small[0] && (hp[0].a.C % 32) == 0 && (hp[0].Cv % 32) == 0 &&
         hp[0].a.C + hp[0].Cv >= 64) {
         const int gy = q.gy[0];
         int gx = hp[0].n_tiles;
@@ -158,9 +160,9 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         long g = (slots * work[k]) / (total > 0 ? total : 1) / q.gy[k];      // workgroups per tile-row
         if (g < 1) g = 1;
         if (g > hp[k].n_tiles) g = hp[k].n_tiles;
-        if (q.gk[k] == 3 && g > (hp[k].n_tiles + 3) / 4) g = (hp[k].n_tiles + 3) / 4;       // a wave per strip of >= 4 rows
+        if (q.gk[k] >= 3 && g > (hp[k].n_tiles + 3) / 4) g = (hp[k].n_tiles + 3) / 4;       // a wave per strip of >= 4 rows
         q.gx[k] = xcd_round((int)g);
-        if (q.gk[k] == 3) {
+        if (q.gk[k] >= 3) {
             // rows per strip: the longest (least halo) that still gives every wave of the member's workgroups a strip
             const long cols = (long)hp[k].n * (hp[k].W >> 4);
             int rh = 4;

@@ -445,6 +445,41 @@ def test_strip_conv_kernel(case, bn, want_pool):
     close(grp[0], ref, 2e-5)
 
 
+@pytest.mark.parametrize('case', [(16, 16, 512, 16, 16, 16), (16, 16, 512, 32, 0, 32), (16, 32, 513, 16, 16, 32), (8, 16, 640, 32, 16, 16)])
+@pytest.mark.parametrize('bn', [False, True])
+def test_strip_conv_kernel_two_or_three_chunks(case, bn):
+    """32-channel inputs and / or the pooled finer map V (2-3 sixteen-channel chunks) on a big map at an evaluation-size
+    batch: the multi-chunk strip body (weights in LDS; conv_strip.h).  Its summation order differs from the general
+    body's (dy, chunk, ... against chunk, dy, ...): equal to fp32 rounding, and against the oracle; the pooled map is
+    the exact max-pool of its own output."""
+    import hiputil as U
+    from lib import _hip
+    H, W, n, ca, cv, co = case
+    rng = np.random.default_rng(H * 7 + W + n + ca + cv)
+    x = rng.standard_normal((n, H, W, ca)).astype(np.float32)
+    v = rng.standard_normal((n, 2 * H, 2 * W, cv)).astype(np.float32) if cv else None
+    wh = (rng.standard_normal((3, 3, ca, co)) / np.sqrt(9 * ca)).astype(np.float32)
+    wv = (rng.standard_normal((3, 3, cv, co)) / np.sqrt(9 * cv)).astype(np.float32) if cv else None
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, ca), rng.standard_normal(ca) * 0.3
+    bnd, cnt = U.bn_dict(x, gamma, beta) if bn else (None, 1)
+    mode = _hip.ACT_BN_BATCH if bn else _hip.ACT_IDENTITY
+    one = U.conv_fwd(x, wh, b, v, wv, bnd, mode, 0, cnt, want_pool=True)
+    grp = U.conv_fwd(x, wh, b, v, wv, bnd, mode, 0, cnt, want_pool=True, group=True)
+    scale = 1 + np.abs(one[0]).max()
+    assert np.abs(grp[0] - one[0]).max() <= 2e-5 * scale
+    assert np.array_equal(grp[2], U.pool2_np(grp[0]))
+    close(grp[1], one[1], 1e-4)
+    xs = x.astype(np.float64)
+    if bn:
+        y, _, _ = O.bn_train(xs, gamma, beta)
+        xs = np.maximum(y, 0)
+    ref = O.conv_same(xs, wh.astype(np.float64)) + b
+    if cv:
+        ref = ref + O.conv_same(U.pool2_np(v).astype(np.float64), wv.astype(np.float64))
+    close(grp[0], ref, 2e-5)
+
+
 def _hip_mode():
     from lib import _hip
     return _hip.ACT_BN_BATCH
