@@ -342,6 +342,10 @@ __global__ __launch_bounds__(256) void lin_bwd_k(const mpnn_lin_bwd_args *__rest
                     accW[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[pp][s], bdy[pp][0][s], accW[0], 0, 0, 0);
                     accW[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[pp][s], bdy[pp][1][s], accW[1], 0, 0, 0);
                 }
+            // (pin the dW accumulators here: nothing reads them until the loop ends, so the compiler sank their MFMAs
+            // below the drain, to the loop latch -- where the next iteration's register copies read them behind five
+            // scalar instructions: the hazard mfma_drain exists for, tools/scan_mfma_hazard.py)
+            asm volatile("" : "+a"(accW[0]), "+a"(accW[1]));
             mfma_drain();
 #pragma unroll
             for (int pp = 0; pp < LB_GP; ++pp)
