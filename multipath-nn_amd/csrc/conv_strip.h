@@ -16,6 +16,8 @@
 #pragma once
 #include "conv_kernel.h"
 
+struct StripSeq { int ij, ys, xs; };      // image index in the wave's sequence, row segment, column strip
+
 template <bool IDX>
 __device__ __forceinline__ void strip16_body(const mpnn_conv_fwd_args &a, const int bx, const int by, const int gx, const int rh,
                                              const int xcd, char *smem) {
