@@ -414,7 +414,7 @@ def test_first_conv_kernel(case, want_pool):
     close(grp[1][16:], (ref * ref).sum(axis=(0, 1, 2)), 1e-4)
 
 
-@pytest.mark.parametrize('case', [(32, 32, 512, 16), (16, 16, 515, 32), (16, 48, 512, 16), (8, 16, 640, 64)])
+@pytest.mark.parametrize('case', [(32, 32, 512, 16), (16, 16, 515, 32), (16, 48, 512, 16), (8, 16, 640, 64), (12, 16, 512, 16), (20, 32, 513, 16)])
 @pytest.mark.parametrize('bn', [False, True])
 @pytest.mark.parametrize('want_pool', [False, True])
 def test_strip_conv_kernel(case, bn, want_pool):
@@ -445,7 +445,7 @@ def test_strip_conv_kernel(case, bn, want_pool):
     close(grp[0], ref, 2e-5)
 
 
-@pytest.mark.parametrize('case', [(16, 16, 512, 16, 16, 16), (16, 16, 512, 32, 0, 32), (16, 32, 513, 16, 16, 32), (8, 16, 640, 32, 16, 16)])
+@pytest.mark.parametrize('case', [(16, 16, 512, 16, 16, 16), (16, 16, 512, 32, 0, 32), (16, 32, 513, 16, 16, 32), (8, 16, 640, 32, 16, 16), (12, 16, 512, 32, 0, 16)])
 @pytest.mark.parametrize('bn', [False, True])
 def test_strip_conv_kernel_two_or_three_chunks(case, bn):
     """32-channel inputs and / or the pooled finer map V (2-3 sixteen-channel chunks) on a big map at an evaluation-size
