@@ -127,7 +127,8 @@ int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
  * one to three 16-channel chunks (no 1/3-channel image operand) take the wave-per-strip bodies of
  * conv_strip.h when the record's sample capacity `n` is >= 512 (MPNN_STRIP: minimum, 0 = off): the
  * one-chunk body gives the same bits as mpnn_msconv_fwd, the multi-chunk body the same values up
- * to fp32 summation order.  Which body runs depends only on the shapes and on `n` -- never on the
+ * to fp32 summation order.  Groups of 8x8 / 4x4 members with Cout % 32 == 0 in evaluation mode and
+ * `n` >= 1024 (MPNN_FWD_WIDE) use 32-channel output tiles: the same bits.  Which body runs depends only on the shapes and on `n` -- never on the
  * grouping, the index list or the device-side count -- so a conv gives bit-identical rows on all
  * samples or on a routed sub-batch of the same capacity. */
 int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,

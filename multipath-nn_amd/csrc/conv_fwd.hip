@@ -45,8 +45,11 @@ __host__ __device__ static inline int fill_fwd(const mpnn_conv_fwd_args *a, Conv
 // SMALL = some member has a 1- or 3-channel operand A (block 0).  Groups without one run an
 // instantiation that omits those bodies: 128 instead of 160 VGPRs, i.e. 4 instead of 3 waves per SIMD.
 // IDX = the members carry index lists (routed evaluation): the same bodies with the image indirection.
-template <bool SMALL, bool IDX>
-__global__ __launch_bounds__(256, SMALL ? 3 : MPNN_OCC) void fwd_group_k(const mpnn_conv_fwd_args *__restrict__ tab, const FwdGroupP q) {
+// WIDE = every member is an 8x8 / 4x4 conv with Cout % 32 == 0 at an evaluation batch: 32 output channels per
+// workgroup (two M-tiles per wave, two wave columns) -- the input tile is staged once per 32 instead of per 16
+// output channels; same contraction order per output element, i.e. the same bits as the 16-channel tile.
+template <bool SMALL, bool IDX, bool WIDE = false>
+__global__ __launch_bounds__(256, WIDE ? 2 : (SMALL ? 3 : MPNN_OCC)) void fwd_group_k(const mpnn_conv_fwd_args *__restrict__ tab, const FwdGroupP q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // sized by the host for the members present
     // 1-D grid with exactly the workgroups that have work (a 2-D grid padded to the widest member
     // launches workgroups that exit at once, and they were seen to delay the residency of real ones)
@@ -59,6 +62,11 @@ __global__ __launch_bounds__(256, SMALL ? 3 : MPNN_OCC) void fwd_group_k(const m
     ConvP p = {};
     fill_fwd(tab + m, p);
     p.xcd = q.xcd;
+    if constexpr (WIDE) {
+        if (kind == 2) { p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 2, 1, 2, 2, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); }
+        else           { p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 2, 1, 2, 2, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); }
+        return;
+    }
     switch (kind) {
         case 0: p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
         case 2: p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, false, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); break;
@@ -145,7 +153,19 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
     }
     bool any_small = false;
     for (int k = 0; k < count; ++k) any_small = any_small || q.small[k];
+    // 32-channel output tiles: every member an 8x8 / 4x4 conv with Cout % 32 == 0, evaluation mode, capacity >= MPNN_FWD_WIDE
+    static const int wide_env = [] { const char *e = getenv("MPNN_FWD_WIDE"); return e ? atoi(e) : 1024; }();     // 0 = off
+    bool wide = wide_env > 0;
+    for (int k = 0; k < count; ++k)
+        wide = wide && (q.gk[k] == 1 || q.gk[k] == 2) && !q.small[k] && (hp[k].Cout % 32) == 0 && hp[k].n >= wide_env &&
+               hp[k].a.mode != MPNN_ACT_BN_BATCH;
+    if (wide) {
+        const int wb[3] = {0, ConvSmem<1, 2, 32>::BYTES, ConvSmem<2, 2, 32>::BYTES};
+        lds = 0;
+        for (int k = 0; k < count; ++k) { q.gy[k] = hp[k].Cout / 32; if (wb[q.gk[k]] > lds) lds = wb[q.gk[k]]; }
+    }
     void (*kern)(const mpnn_conv_fwd_args *, const FwdGroupP) =
+        wide ? (any_idx ? fwd_group_k<false, true, true> : fwd_group_k<false, false, true>) :
         any_idx ? (any_small ? fwd_group_k<true, true> : fwd_group_k<false, true>)
                 : (any_small ? fwd_group_k<true, false> : fwd_group_k<false, false>);
     const long slots = resident_slots((const void *)kern, lds);

@@ -480,6 +480,38 @@ def test_strip_conv_kernel_two_or_three_chunks(case, bn):
     close(grp[0], ref, 2e-5)
 
 
+@pytest.mark.parametrize('shape', [(8, 32, 32, 64), (4, 64, 64, 64), (4, 64, 0, 128), (8, 32, 0, 32)])
+def test_wide_group_equals_single_launch(shape):
+    """Evaluation batches (capacity >= 1024, moving-average BatchNorm): a group whose members are 8x8 / 4x4 convs with
+    Cout % 32 == 0 runs 32-channel output tiles (fwd_group_k<.., WIDE>).  Same contraction order per output element:
+    bit-identical to mpnn_msconv_fwd, pooled map included; against the oracle on the first samples."""
+    import hiputil as U
+    from lib import _hip
+    H, ca, cv, co = shape
+    rng = np.random.default_rng(sum(shape) + 1)
+    n = 1027
+    x = rng.standard_normal((n, H, H, ca)).astype(np.float32)
+    wh = (rng.standard_normal((3, 3, ca, co)) / np.sqrt(9 * ca)).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    v = rng.standard_normal((n, 2 * H, 2 * H, cv)).astype(np.float32) if cv else None
+    wv = (rng.standard_normal((3, 3, cv, co)) / np.sqrt(9 * cv)).astype(np.float32) if cv else None
+    gamma, beta = rng.uniform(0.5, 1.5, ca), rng.standard_normal(ca) * 0.3
+    m_avg, v_avg = rng.standard_normal(ca) * 0.2, rng.uniform(0.5, 1.5, ca)
+    bn, cnt = U.bn_dict(x, gamma, beta, m_avg, v_avg)
+    want_pool = H >= 8
+    one = U.conv_fwd(x, wh, b, v, wv, bn, _hip.ACT_BN_MOVING, 0, cnt, want_pool=want_pool)
+    grp = U.conv_fwd(x, wh, b, v, wv, bn, _hip.ACT_BN_MOVING, 0, cnt, want_pool=want_pool, group=True)
+    assert np.array_equal(grp[0], one[0])
+    if want_pool:
+        assert np.array_equal(grp[2], one[2])
+    k = 16
+    y = gamma * (x[:k].astype(np.float64) - m_avg) / np.sqrt(v_avg + 1e-6) + beta
+    ref = O.conv_same(np.maximum(y, 0), wh.astype(np.float64)) + b
+    if cv:
+        ref = ref + O.conv_same(U.pool2_np(v[:k]).astype(np.float64), wv.astype(np.float64))
+    close(grp[0][:k], ref, 2e-5)
+
+
 def _hip_mode():
     from lib import _hip
     return _hip.ACT_BN_BATCH
