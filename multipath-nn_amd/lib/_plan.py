@@ -88,7 +88,7 @@ class Engine:
         self.multi_stream = bool(int(os.environ.get('MPNN_STREAMS', '0')))
         self.group_fwd = bool(int(os.environ.get('MPNN_FWD_GROUP', '1')))   # wavefront-grouped forward launches
         self.bwd_levels = bool(int(os.environ.get('MPNN_BWD_LEVELS', '1')))  # one backward launch per dependency level
-        self.routed_min_batch = int(os.environ.get('MPNN_ROUTED_MIN_BATCH', '1024'))
+        self.routed_min_batch = int(os.environ.get('MPNN_ROUTED_MIN_BATCH', '2048'))
         self.fold_clear = bool(int(os.environ.get('MPNN_FOLD_CLEAR', '1')))  # no clearing launch in a training step
         self._acc_clean = False          # the step's accumulators (slot sums, TALR statistics, loss) are cleared
         self._streams = []

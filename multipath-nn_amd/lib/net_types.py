@@ -147,7 +147,7 @@ class Net(metaclass=ABCMeta):
         """Forward pass + routing in evaluation mode ('ev': BatchNorm moving averages, hard routing);
         per-layer results are then readable as ``ℓ.p_ev``, ``ℓ.δ_cor`` ... device tensors.
 
-        routed='auto' picks the routed evaluation from 1 024 samples per launch on and the dense one below
+        routed='auto' picks the routed evaluation from 2 048 samples per launch on and the dense one below
         (Engine.routed_min_batch); routed=True runs the ROUTED evaluation: every block only processes the samples its ancestors'
         routers sent to it (sample lists compacted on the device, no host sync).  ``p_ev`` and every
         p_ev-weighted statistic (acc, moc, p_cor, p_inc, *_by_cls: all that the reference's figure
