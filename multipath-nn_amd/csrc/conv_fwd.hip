@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256, WIDE ? 2 : (SMALL ? 3 : MPNN_OCC)) void fwd_gr
         case 8: stripk_body<IDX>(tab[m], bx, yy, gx, q.rh[m], q.xcd, smem); break;         // the same with 2-3 input chunks
         default:
             if constexpr (SMALL) {
-                if (kind == 1)      { p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, true, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); }
+                if (kind == 9)      stripk_body<IDX, true>(tab[m], bx, yy, gx, q.rh[m], q.xcd, smem);        // image + V on a big map (conv_strip.h)
+                else if (kind == 1) { p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W); conv_body<0, 1, 1, 4, 1, true, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); }
                 else if (kind == 3) { p.n_tiles = conv_grid_x<1>(p.n, p.H, p.W); conv_body<1, 1, 1, 4, 1, true, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); }
                 else                { p.n_tiles = conv_grid_x<2>(p.n, p.H, p.W); conv_body<2, 1, 1, 4, 1, true, EPI_FWD, 1, false, IDX>(p, bx, yy, gx, smem); }
             }
@@ -115,6 +116,10 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         static const int strip_env = [] { const char *e = getenv("MPNN_STRIP"); return e ? atoi(e) : 512; }();     // minimum batch, 0 = off
         // (evaluation batches only: at the training batch a strip per wave leaves the chip half empty -- 14.7 against 13.3 us)
         const int kch = (p.a.C >> 4) + (args[k].v ? (p.Cv >> 4) : 0);                  // 16-channel chunks of input
+        if (strip_env && p.n >= strip_env && q.small[k] && args[k].v && (p.Cv % 16) == 0 && 1 + (p.Cv >> 4) <= MPNN_STRIP_KMAX &&
+            p.a.mode == MPNN_ACT_IDENTITY && p.W >= 16 && (p.W % 16) == 0 && (p.H % 4) == 0 && (!args[k].pool_out || !(p.H & 1))) {
+            q.gk[k] = 4;  p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W);                    // image + V: the strip body's SMA form
+        } else
         if (strip_env && p.n >= strip_env && p.W >= 16 && (p.W % 16) == 0 && (p.H % 4) == 0 && (p.a.C % 16) == 0 && p.a.C >= 16 &&
             (!args[k].v || (p.Cv % 16) == 0) && kch <= MPNN_STRIP_KMAX && (!args[k].pool_out || !(p.H & 1))) {
             q.gk[k] = kch == 1 ? 3 : 4;  p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W);        // (64-pixel tiles: the unit of the work shares)

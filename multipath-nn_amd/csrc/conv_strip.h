@@ -212,14 +212,17 @@ __device__ __forceinline__ void strip16_body(const mpnn_conv_fwd_args &a, const 
 #define MPNN_STRIP_KMAX 3
 static inline int strip_lds_bytes(int K) { return 2048 + 1024 + K * 9 * 64 * 16; }      // red + coefficients + weights
 
-template <bool IDX>
+// SMA: operand A is the 1..3-channel pyramid image of block 0 (ToPyramid's strided pick, no BatchNorm): chunk 0 is ONE
+// k-step per tap (lane (li, g) supplies channel g), the pooled finer map V follows as usual.
+template <bool IDX, bool SMA = false>
 __device__ __forceinline__ void stripk_body(const mpnn_conv_fwd_args &a, const int bx, const int by, const int gx, const int rh,
                                             const int xcd, char *smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
     const int H = a.H, W = a.W, Co = a.Cout, co0 = by * 16;
-    const int Ca = a.a.C, Cv = a.v ? a.Cv : 0, KA = Ca >> 4, KV = Cv >> 4, K = KA + KV;
+    const int Ca = a.a.C, Cv = a.v ? a.Cv : 0, KA = SMA ? 1 : Ca >> 4, KV = Cv >> 4, K = KA + KV;
+    const int sh = SMA ? a.a.shift : 0;
     int n_img = a.n;
     if (a.cnt) { const int c = *a.cnt; n_img = c < a.n ? c : a.n; }
     const int xs_n = W >> 4, ys_n = H / rh, tpi = xs_n * ys_n;
@@ -228,7 +231,7 @@ __device__ __forceinline__ void stripk_body(const mpnn_conv_fwd_args &a, const i
     float *cS = (float *)(smem + 2048);                     // [3][Ca]: mean, gamma * rstd, beta of operand A's channels
     f32x4 *wl = (f32x4 *)(smem + 2048 + 1024);              // [K][9][64]
     const int mode = a.a.mode;
-    if (mode != MPNN_ACT_IDENTITY && tid < Ca) {
+    if (!SMA && mode != MPNN_ACT_IDENTITY && tid < Ca) {
         const BnC k = bn_coef(a.a, tid);
         cS[tid] = k.m; cS[Ca + tid] = k.gamma * k.rstd; cS[2 * Ca + tid] = k.beta;
     }
@@ -238,6 +241,11 @@ __device__ __forceinline__ void stripk_body(const mpnn_conv_fwd_args &a, const i
         const bool isv = kq >= KA;
         const float *pk = isv ? a.wv_pack : a.wa_pack;
         const int nch = isv ? KV : KA, kk = isv ? kq - KA : kq;
+        if (SMA && !isv) {                                  // the image: W[t][ci = fg][co] in component 0
+            const float w = fg < Ca ? pk[(size_t)t * 16 * Co + (co0 + fl) * 4 + fg] : 0.f;
+            wl[f] = f32x4{w, 0.f, 0.f, 0.f};
+            continue;
+        }
         wl[f] = *(const f32x4 *)(pk + (size_t)t * nch * 16 * Co + ((kk * 4 + fg) * Co + co0 + fl) * 4);
     }
     __syncthreads();
@@ -266,6 +274,14 @@ __device__ __forceinline__ void stripk_body(const mpnn_conv_fwd_args &a, const i
         // unit (halo row y, chunk kq): raw loads; a row outside the image reads row 0 and is zeroed on use
         auto load_unit = [&](int y, int kq, f32x4 *r) {
             const bool isv = kq >= KA;
+            if (SMA && !isv) {                              // (uniform) one channel per lane, strided pick of the pyramid
+                const int yy = (unsigned)y < (unsigned)H ? y : 0, gc = g < Ca ? g : Ca - 1;
+                const float *rp = a.a.x + ((((long)n * (H << sh) + ((long)yy << sh)) * (W << sh)) + ((long)x0 << sh)) * Ca + gc;
+                r[0] = f32x4{rp[(long)(pl << sh) * Ca], 0.f, 0.f, 0.f};
+                r[1] = f32x4{rp[(long)(li << sh) * Ca], 0.f, 0.f, 0.f};
+                r[2] = f32x4{rp[(long)(pr << sh) * Ca], 0.f, 0.f, 0.f};
+                return;
+            }
             const float *src = isv ? a.v : a.a.x;
             const int C = isv ? Cv : Ca, ch = (isv ? kq - KA : kq) * 16 + g * 4;
             const float *rp = src + (img_px + (long)((unsigned)y < (unsigned)H ? y : 0) * W) * C + ch;
@@ -275,7 +291,7 @@ __device__ __forceinline__ void stripk_body(const mpnn_conv_fwd_args &a, const i
         };
         auto prep_unit = [&](int y, int kq, f32x4 *r) {
             const bool rz = (unsigned)y >= (unsigned)H;
-            const bool bn = kq < KA && mode != MPNN_ACT_IDENTITY;              // (uniform)
+            const bool bn = !SMA && kq < KA && mode != MPNN_ACT_IDENTITY;      // (uniform)
             f32x4 cm = {0.f, 0.f, 0.f, 0.f}, cs = cm, cb = cm;
             if (bn) {
                 const int c = kq * 16 + g * 4;
@@ -297,12 +313,13 @@ __device__ __forceinline__ void stripk_body(const mpnn_conv_fwd_args &a, const i
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const f32x4 w0 = wk[dx * 64], w1 = wk[(3 + dx) * 64], w2 = wk[(6 + dx) * 64];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                auto kstep = [&](int c) {
                     if (on_up) up = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[c], r[dx][c], up, 0, 0, 0);
                     if (on_mid) mid = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[c], r[dx][c], mid, 0, 0, 0);
                     if (on_dn) dn = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c], r[dx][c], dn, 0, 0, 0);
-                }
+                };
+                kstep(0);
+                if (!(SMA && kq == 0)) { kstep(1); kstep(2); kstep(3); }       // (uniform: the image chunk is one k-step)
             }
         };
         f32x4 prev_out = {0.f, 0.f, 0.f, 0.f};

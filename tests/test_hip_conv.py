@@ -480,6 +480,31 @@ def test_strip_conv_kernel_two_or_three_chunks(case, bn):
     close(grp[0], ref, 2e-5)
 
 
+@pytest.mark.parametrize('case', [(16, 16, 512, 3, 16, 16, 1), (16, 32, 513, 1, 16, 32, 1), (16, 16, 512, 3, 32, 16, 2)])
+def test_strip_conv_kernel_image_plus_v(case):
+    """Block 0's coarser scales on a big map: the 1..3-channel pyramid image (strided pick, shift) plus the pooled finer
+    map V, at an evaluation-size batch -- the image form of the multi-chunk strip body (conv_strip.h, SMA): against
+    the general body to fp32 summation order and against the oracle; the pooled map is the max-pool of its own output."""
+    import hiputil as U
+    from lib import _hip
+    H, W, n, ca, cv, co, shift = case
+    rng = np.random.default_rng(H * 7 + W + n + ca + cv + shift)
+    x = rng.standard_normal((n, H << shift, W << shift, ca)).astype(np.float32)
+    v = rng.standard_normal((n, 2 * H, 2 * W, cv)).astype(np.float32)
+    wh = (rng.standard_normal((3, 3, ca, co)) / np.sqrt(9 * ca)).astype(np.float32)
+    wv = (rng.standard_normal((3, 3, cv, co)) / np.sqrt(9 * cv)).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    one = U.conv_fwd(x, wh, b, v, wv, None, _hip.ACT_IDENTITY, shift, 1, want_pool=True)
+    grp = U.conv_fwd(x, wh, b, v, wv, None, _hip.ACT_IDENTITY, shift, 1, want_pool=True, group=True)
+    scale = 1 + np.abs(one[0]).max()
+    assert np.abs(grp[0] - one[0]).max() <= 2e-5 * scale
+    assert np.array_equal(grp[2], U.pool2_np(grp[0]))
+    close(grp[1], one[1], 1e-4)
+    xs = x[:, ::1 << shift, ::1 << shift, :].astype(np.float64)
+    ref = O.conv_same(xs, wh.astype(np.float64)) + b + O.conv_same(U.pool2_np(v).astype(np.float64), wv.astype(np.float64))
+    close(grp[0], ref, 2e-5)
+
+
 @pytest.mark.parametrize('shape', [(8, 32, 32, 64), (4, 64, 64, 64), (4, 64, 0, 128), (8, 32, 0, 32)])
 def test_wide_group_equals_single_launch(shape):
     """Evaluation batches (capacity >= 1024, moving-average BatchNorm): a group whose members are 8x8 / 4x4 convs with
