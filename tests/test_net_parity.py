@@ -284,6 +284,13 @@ def test_training_batch_256():
     run_case(A.ac_chain(k_cpt=1.6e-8), 256, lambda net, t: {net.τ: 0.8}, steps=1)
 
 
+def test_training_batch_512_strip_bodies():
+    """512 samples per step: the forward convs of the big maps take the wave-per-strip bodies (conv_strip.h, capacity
+    >= 512) in TRAINING mode too -- batch-statistics BatchNorm on load, statistics of the outputs from the strips."""
+    import arch_and_hypers as A
+    run_case(A.ac_chain(k_cpt=1.6e-8), 512, lambda net, t: {net.τ: 0.8}, steps=1)
+
+
 def test_forward_only_fetch_in_tr_mode():
     """A fetch with mode 'tr' and no train op (net_types.py:50-52; the placeholders accept it): batch-statistics
     BatchNorm, soft routing p_tr -- and, as in the reference (layer_types.py:231-236), the consumed BatchNorms move
