@@ -331,9 +331,18 @@ __global__ __launch_bounds__(RT_THREADS) void route_k(const mpnn_route_args a) {
     if (a.loss) {
         const double e = wave_sum_d(live ? (double)l_err : 0.0), c = wave_sum_d(live ? (double)l_cpt : 0.0);
         const double x = wave_sum_d(live ? (double)l_aux : 0.0), cnt = wave_sum_d((live && wave == 0) ? 1.0 : 0.0);
-        if (lane_t == 0) {
-            atomicAdd(a.loss, e); atomicAdd(a.loss + 1, c); atomicAdd(a.loss + 2, x);
-            if (wave == 0) atomicAdd(a.loss + 3, cnt);
+        // the eight waves' sums meet in LDS (fixed order) and leave as ONE atomic per sum and workgroup: same-address
+        // atomics serialise across the chip -- with one per wave the launch took 32 us at 4 096 samples (64 workgroups)
+        // (in the head of the dynamic LDS area, once every wave is done with the tables: the launch may use all 160 KB)
+        double *lsum = (double *)lds;                     // [RT_WAVES][4]
+        __syncthreads();
+        if (lane_t == 0) { lsum[wave * 4] = e; lsum[wave * 4 + 1] = c; lsum[wave * 4 + 2] = x; lsum[wave * 4 + 3] = wave == 0 ? cnt : 0.0; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < RT_WAVES; ++w) t += lsum[w * 4 + threadIdx.x];
+            atomicAdd(a.loss + threadIdx.x, t);
         }
     }
     trace_stamp(5);
