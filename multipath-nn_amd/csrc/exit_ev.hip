@@ -126,74 +126,89 @@ __global__ __launch_bounds__(EV_WAVES * 64) void exit_ev_k(const mpnn_exit_ev_ar
         else hs[row * TR + col] = col < M1 ? v : 0.f;          // (bias and k_cpt column: in the tail, from LDS)
     }
     __syncthreads();
-    if (tid >= 64) return;                   // wave 0: one sample per lane (lanes 0..15)
-    const bool mine = tid < 16 && img_s[tid < 16 ? tid : 0] >= 0;
-    const int my = mine ? img_s[tid] : 0;
-    if (has_head && mine) {
-        const int nc = a.n_cls;
-        float z[TC], p[TC];
+    if (tid >= 256) return;                  // waves 0-3 stay (a barrier counts the waves that are still alive)
+    // ---- router tail on 256 threads: thread (sample s, column c) computes ONE output of each of the three maps ----
+    // (one sample per lane did all 16 x 16 + 16 x S multiply-adds of a sample in sequence: ~2.5 us of a lone wave)
+    __shared__ float a1s[16 * TR], a2s[16 * TR], rs[16 * TS];
+    __shared__ int arg_s[16];
+    if (has_router) {
+        const int sm = tid >> 4, c = tid & 15;
+        const int my_s = img_s[sm];
+        const float kc = (a.extra_col && my_s >= 0) ? a.alpha_cpt * a.k_cpt[my_s] : 0.f;
+        const float h1 = hs[sm * TR + c] + vec[7 * TR + c] + kc * vec[8 * TR + c];
+        a1s[tid] = fmaxf(vec[c] * (h1 - vec[TR + c]) + vec[2 * TR + c], 0.f);
+        __syncthreads();
+        float h = vec[6 * TR + c];
 #pragma unroll
-        for (int k = 0; k < TC; ++k) z[k] = zs[tid * TC + k];
-        float mx = z[0];
+        for (int cc = 0; cc < TR; ++cc) h += a1s[sm * TR + cc] * w2s[cc * TR + c];
+        a2s[tid] = fmaxf(vec[3 * TR + c] * (h - vec[4 * TR + c]) + vec[5 * TR + c], 0.f);
+        __syncthreads();
+        if (c < TS) {
+            float r = vec[9 * TR + c];
 #pragma unroll
-        for (int k = 1; k < TC; ++k) if (k < nc) mx = fmaxf(mx, z[k]);
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < TC; ++k) { p[k] = k < nc ? expf(z[k] - mx) : 0.f; sum += p[k]; }
-        const float inv = 1.f / sum;
-        float ce = 0.f, pmax = 0.f, ymax = 0.f; int ap = 0, ay = 0;
-#pragma unroll
-        for (int k = 0; k < TC; ++k) {
-            if (k < nc) {
-                const float pk = p[k] * inv, yk = a.y[(size_t)my * nc + k];
-                ce -= yk * logf(a.eps_ce / (float)nc + (1.f - a.eps_ce) * pk);
-                if (k == 0 || pk > pmax) { pmax = pk; ap = k; }
-                if (k == 0 || yk > ymax) { ymax = yk; ay = k; }
-            }
+            for (int cc = 0; cc < TR; ++cc) r += a2s[sm * TR + cc] * w3s[cc * TS + c];
+            rs[sm * TS + c] = r;
+            if (c < S && my_s >= 0) a.r[(size_t)my_s * a.r_stride + c] = r;
         }
-        a.c_err[my] = ce;
-        a.d_cor[my] = ap == ay ? 1.f : 0.f;
+        __syncthreads();
+        if (c == 0) {
+            int arg = 0; float rmax = rs[sm * TS];
+#pragma unroll
+            for (int i = 1; i < TS; ++i) if (i < S && rs[sm * TS + i] > rmax) { rmax = rs[sm * TS + i]; arg = i; }   // first index on ties (tf.argmax)
+            arg_s[sm] = arg;
+        }
+        __syncthreads();
     }
-    if (!has_router) return;
-    int arg = 0;
-    if (mine) {
-        const float kc = a.extra_col ? a.alpha_cpt * a.k_cpt[my] : 0.f;
-        float a1[TR];
+    // ---- wave 0: the head (one sample per lane); wave 1, at the same time: the children's lists ----
+    if (wid == 0) {
+        const bool mine = tid < 16 && img_s[tid < 16 ? tid : 0] >= 0;
+        const int my = mine ? img_s[tid] : 0;
+        if (has_head && mine) {
+            const int nc = a.n_cls;
+            float z[TC], p[TC];
 #pragma unroll
-        for (int c = 0; c < TR; ++c) {
-            const float h1 = hs[tid * TR + c] + vec[7 * TR + c] + kc * vec[8 * TR + c];
-            a1[c] = fmaxf(vec[c] * (h1 - vec[TR + c]) + vec[2 * TR + c], 0.f);
-        }
-        float a2[TR];
+            for (int k = 0; k < TC; ++k) z[k] = zs[tid * TC + k];
+            float mx = z[0];
 #pragma unroll
-        for (int j = 0; j < TR; ++j) {
-            float h = vec[6 * TR + j];
+            for (int k = 1; k < TC; ++k) if (k < nc) mx = fmaxf(mx, z[k]);
+            float sum = 0.f;
 #pragma unroll
-            for (int c = 0; c < TR; ++c) h += a1[c] * w2s[c * TR + j];
-            a2[j] = fmaxf(vec[3 * TR + j] * (h - vec[4 * TR + j]) + vec[5 * TR + j], 0.f);
-        }
-        float rmax = 0.f;
+            for (int k = 0; k < TC; ++k) { p[k] = k < nc ? expf(z[k] - mx) : 0.f; sum += p[k]; }
+            const float inv = 1.f / sum;
+            float ce = 0.f, pmax = 0.f, ymax = 0.f; int ap = 0, ay = 0;
 #pragma unroll
-        for (int i = 0; i < TS; ++i) {
-            float r = vec[9 * TR + i];
-#pragma unroll
-            for (int c = 0; c < TR; ++c) r += a2[c] * w3s[c * TS + i];
-            if (i < S) {
-                a.r[(size_t)my * a.r_stride + i] = r;
-                if (i == 0 || r > rmax) { rmax = r; arg = i; }       // first index on ties (tf.argmax)
+            for (int k = 0; k < TC; ++k) {
+                if (k < nc) {
+                    const float pk = p[k] * inv, yk = a.y[(size_t)my * nc + k];
+                    ce -= yk * logf(a.eps_ce / (float)nc + (1.f - a.eps_ce) * pk);
+                    if (k == 0 || pk > pmax) { pmax = pk; ap = k; }
+                    if (k == 0 || yk > ymax) { ymax = yk; ay = k; }
+                }
             }
+            a.c_err[my] = ce;
+            a.d_cor[my] = ap == ay ? 1.f : 0.f;
         }
+        return;
     }
-    // ---- compaction into the children's lists: ballot + popcount prefix, one atomic per (wave, sink) ----
+    if (wid != 1 || !has_router) return;
+    // ---- compaction into the children's lists: ballot + popcount prefix, one atomic per (wave, sink); the atomics
+    // of all sinks are issued before the first result is used (they are independent round trips) ----
+    const bool mine = lane < 16 && img_s[lane < 16 ? lane : 0] >= 0;
+    const int my = mine ? img_s[lane] : 0;
+    const int arg = mine ? arg_s[lane] : 0;
+    unsigned long long m[TS];
+    int base[TS];
 #pragma unroll
     for (int i = 0; i < TS; ++i) {
-        if (i >= S || !a.child_idx[i]) continue;                    // uniform
-        const unsigned long long m = __ballot(mine && arg == i);
-        if (!m) continue;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(a.child_cnt[i], (int)__popcll(m));
-        base = __shfl(base, 0);
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        m[i] = (i < S && a.child_idx[i]) ? __ballot(mine && arg == i) : 0ull;          // (uniform condition)
+        base[i] = 0;
+        if (m[i] && lane == 0) base[i] = atomicAdd(a.child_cnt[i], (int)__popcll(m[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < TS; ++i) {
+        if (!m[i]) continue;
+        const int b0 = __shfl(base[i], 0);
+        const int pos = b0 + __popcll(m[i] & ((1ull << lane) - 1ull));
         if (mine && arg == i && pos < a.n) a.child_idx[i][pos] = my;       // (a list holds at most n samples: counts not cleared by the caller must not write past it)
     }
 }
