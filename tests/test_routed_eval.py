@@ -186,6 +186,24 @@ def test_exit_fractions_one_eighth_each(kind):
     assert np.allclose(hist, 1 / 8), hist
 
 
+def test_tree_net_routed_equals_dense_at_600():
+    """A TREE (ac_tree: multi-child blocks, 3-way switches) at an evaluation-size batch: the strip bodies and the
+    32-channel tiles run inside the tree's groups too; routed == dense bit for bit, sample lists == nonzero(p_ev)."""
+    import arch_and_hypers as A
+    net = A.ac_tree(k_cpt=1e-9)((32, 32, 3), (10,))
+    eng = net.engine()
+    eng.init_params(13)
+    rng = np.random.default_rng(14)
+    for p in net._all_params:
+        if not p.trainable:
+            p.assign(rng.random(p.shape) * 0.5 + (0.75 if p.name == 'v_avg' else -0.25))
+    randomise_routers(net, seed=3, scale=1.0)
+    x0, y = batch(600, seed=12)
+    dense = check_routed_equals_dense(net, x0, y)
+    hist = np.stack([dense['p_ev'][nd.idx] for nd in eng.leaves]).mean(1)
+    assert (hist > 0).sum() >= 4, hist
+
+
 def test_random_routers_ragged_1000():
     """1000 samples: 62.5 sixteen-sample tiles, 250 four-image tiles; sub-batches of every size."""
     net = make(seed=11)
