@@ -161,12 +161,31 @@ def measure_dp_structure(net, eng, feed, single_ms):
         whole = eng._graphs[key][1] == 'whole'
         return {'ms_per_step': ms, 'ms_per_step_single_graph': single_ms, 'ratio': ms / single_ms,
                 'buckets': list(eng.dp_buckets), 'collectives_per_step': len(eng.dp_buckets), 'rccl_ranks': dist.get_world_size(),
+                'reserved_cus': eng.dp_reserve_cus, 'per_bucket_update': bool(eng._bucket_opt_on()),
                 'form': 'ONE hipGraph per step: bucket sections + RCCL all-reduces (captured on the process group\'s stream) + optimizer'
                         if whole else 'one hipGraph per bucket section, all-reduces issued from the host, optimizer graph',
                 'what': 'forced 1-rank RCCL group, 200 steps, beside the single-process one-graph step'}
     finally:
         _dp.detach(net)
         dist.destroy_process_group()
+
+
+def measure_corunner(single_ms, n, k=16, T=40.0):
+    """Robustness of the data-parallel step to a kernel that runs BESIDE it (tools/dp_corunner_probe.py), on one GPU:
+    each bucket's collective replaced by k workgroups x 512 threads that hold their slots for T us, inside the one-graph
+    step.  `one_bucket`: the shipped form (the stand-in sits between the end of the backward pass and the optimizer, so
+    T is exposed by construction; `minus_T` is what the parallel branch itself costs).  `three_buckets_hidden`: the
+    bucketed form with the stand-ins at the two buckets that overlap the backward pass (the last one with T = 0):
+    contention + the graph's cross-branch edges."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import dp_corunner_probe as probe
+    out = {'k_workgroups': k, 'threads': 512, 'T_us': T, 'ms_per_step_single_graph': single_ms}
+    for name, buckets, t_last in (('one_bucket', 1, None), ('three_buckets_hidden', 3, 0.0)):
+        us = probe.measure(0, k, T, t_last, 200, n=n, buckets=buckets)
+        out[name] = {'ms_per_step': us * 1e-3, 'ratio': us * 1e-3 / single_ms}
+    out['one_bucket']['ms_per_step_minus_T'] = out['one_bucket']['ms_per_step'] - T * 1e-3
+    out['one_bucket']['ratio_minus_T'] = out['one_bucket']['ms_per_step_minus_T'] / single_ms
+    return out
 
 
 def time_configs(dev, n, reps=200):
@@ -316,6 +335,10 @@ def main():
             dp_structure = measure_dp_structure(net, eng, feed, steady['ms_median'])
         except Exception as e:
             dp_structure = {'error': repr(e)}
+        try:
+            dp_structure['corunner'] = measure_corunner(steady['ms_median'], n)
+        except Exception as e:
+            dp_structure['corunner'] = {'error': repr(e)}
     if rank == 0 and world == 1 and not args.no_configs:
         cfg_table = time_configs(dev, n)
 
@@ -377,8 +400,19 @@ def main():
         conv = [o for o in ops if o[2] > 0]
         dom_name = max((k for k in fam if fam[k][1] > 0), key=lambda k: fam[k][2])
         # the family's mean launch duration: one event pair around its run of consecutive launches
-        cnt, fl, t_ms = eng.time_family_blocks('tr', n, reps=20)[dom_name]
+        blocks_t = eng.time_family_blocks('tr', n, reps=20)
+        cnt, fl, t_ms = blocks_t[dom_name]
         ach = fl / (t_ms * 1e-3) / 1e12
+        # the OTHER conv family beside it, so that the lowest one is always on the line
+        other = 'fwd_group' if dom_name != 'fwd_group' else 'bwd_scale'
+        roof_other = None
+        if other in blocks_t and blocks_t[other][1] > 0:
+            c2, f2, t2 = blocks_t[other]
+            a2 = f2 / (t2 * 1e-3) / 1e12
+            roof_other = {'bound': 'mfma', 'achieved': a2, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s', 'frac': a2 / PEAK_F32_MFMA,
+                          'kernel': 'fwd_first_k + fwd_group_k + fwd_ks_k (the forward conv launches)' if other == 'fwd_group'
+                                    else 'bwd_scale_k + bwd_level_k (the backward conv launches)',
+                          'launches_per_step': c2, 'kernel_ms': t2 / c2, 'kernel_flops': f2 / c2}
         symbol = {'fwd_group': 'fwd_group_k', 'bwd_scale': 'bwd_scale_k<GK,OT,NCH,HASV> + bwd_level_k<GKMASK,OTMASK> (all instantiations: the backward conv launches)',
                   'msconv_fwd': 'conv_k<...,EPI_FWD>'}.get(dom_name, dom_name)
         total_ms = sum(o[3] for o in ops)
@@ -396,27 +430,32 @@ def main():
                     traffic = pm['traffic_bytes_per_launch']
         except Exception:
             pass
-        # launch floor: the same number of launches as a training step, each the smallest kernel of the
-        # library (a 1-item slab reduction), captured and replayed as one hipGraph
-        n_launch = len(ops) + 2                                   # + step_begin + optimizer
+        # launch floor: the same number of launches as a training step, captured and replayed as one hipGraph --
+        # (a) of a truly EMPTY kernel (one wave that returns: what a grid boundary costs, comparable across rounds and with
+        # the guide's figure), (b) of the smallest kernel of the library that does work (a 1-item slab reduction: two
+        # dependent memory round trips; this is what rounds 1-3 reported as `launch_floor`)
+        n_launch = len(ops) + 1                                   # + the optimizer
+        st = torch.cuda.current_stream()
         tab = torch.tensor([0, 0, 4, 1, 4, 0], dtype=torch.int32, device=dev)
         buf = torch.zeros(64, device=dev)
-        st = torch.cuda.current_stream()
-        tiny = lambda: eng.lib.mpnn_slab_reduce(buf.data_ptr(), buf[32:].data_ptr(), tab.data_ptr(), 1, st.cuda_stream)
-        tiny(); torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            st = torch.cuda.current_stream()
-            for _ in range(n_launch):
-                tiny()
-        for _ in range(5):
-            g.replay()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(50):
-            g.replay()
-        torch.cuda.synchronize()
-        floor_us = (time.perf_counter() - t1) / 50 * 1e6
+
+        def floor_of(fn):
+            fn(torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                s_ = torch.cuda.current_stream().cuda_stream
+                for _ in range(n_launch):
+                    fn(s_)
+            for _ in range(5):
+                g.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                g.replay()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / 50 * 1e6
+        floor_us = floor_of(lambda s_: eng.lib.mpnn_debug_noop(s_))
+        small_us = floor_of(lambda s_: eng.lib.mpnn_slab_reduce(buf.data_ptr(), buf[32:].data_ptr(), tab.data_ptr(), 1, s_))
 
         out = {
             'metric': 'images/sec training CIFAR-10 actor-net', 'value': value, 'unit': 'images/s',
@@ -437,8 +476,12 @@ def main():
                              'all_launches_sum_ms': total_ms, 'n_launches': len(ops)},
             'routed_flops_per_s': value * 2 * moc, 'moc': moc, 'eval': ev, 'steady_state': steady,
             'dp_structure': dp_structure, 'extra': {'configs': cfg_table},
+            'roofline_forward' if other == 'fwd_group' else 'roofline_backward': roof_other,
             'launch_floor': {'kernels_per_step': n_launch, 'us_per_step': floor_us, 'us_per_kernel': floor_us / n_launch,
-                             'what': 'hipGraph of that many 1-workgroup kernels'},
+                             'what': 'hipGraph of that many EMPTY kernels (one wave, returns at once)'},
+            'small_kernel_floor': {'kernels_per_step': n_launch, 'us_per_step': small_us, 'us_per_kernel': small_us / n_launch,
+                                   'what': 'hipGraph of that many 1-workgroup kernels with two dependent memory round trips '
+                                           '(a 1-item mpnn_slab_reduce): rounds 1-3 reported this as launch_floor'},
         }
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n)

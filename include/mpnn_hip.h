@@ -522,6 +522,32 @@ int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad, int has_v
  * kind, slot 7 = units; slots 8-10: first unit's MFMAs done, next unit staged, epilogue done).  tools/trace_phases.py prints the timeline.  Synchronises the device. */
 int mpnn_debug_set_trace(unsigned long long *buf);
 
+/* Host function (no device work, no stream): the augmentation draws of scripts/lib/data.py:24-34 -- per sample
+ * randint(0, n_src); rand() < 0.5 if sym[j] (sym == NULL: every class is symmetric); randint(-r_shift, r_shift + 1, 2)
+ * -- replayed over consecutive 32-bit outputs of numpy's legacy MT19937 stream with numpy's own bounded-integer and
+ * random_sample algorithms.  draw: [n][4] = (j, flip, du, dv), the record mpnn_augment_batch reads.  RESUMABLE so that
+ * the stream is never over-drawn: `state` (4 longs; [0..2] zero to start a batch, [3] = 1 if the caller vouches that
+ * every sym[] entry is set, which tightens the lower bound) carries the position inside the batch; a
+ * call consumes ALL n_raw words it is given and returns the minimum number of words the remaining draws need (0: the
+ * batch is complete); the caller hands over exactly that many next time (first call: n_raw = 0).  MPNN_E_ARG for bad
+ * arguments or more words than the minimum. */
+long mpnn_draw_augmentation(const unsigned int *raw, long n_raw, int n, long n_src, const unsigned char *sym,
+                            int r_shift, int *draw, long *state);
+
+/* Data parallelism (new here: the reference is single-process, scripts/train-nets:159-164).  Compute units every
+ * persistent grid launched AFTER this call leaves free (0: none, the default): RCCL's all-reduce kernels run beside
+ * the backward launches of the bucket sections (lib/_plan.py), and a grid fitted to every resident workgroup slot
+ * then holds workgroups that only start when others exit.  Affects the grids the launchers choose and the slot counts
+ * mpnn_msconv_bwd_scale_slots / mpnn_msconv_bwd_level_slots report.  Host-side state, not stream-ordered.  Returns the
+ * previous value; a negative argument only queries. */
+int mpnn_set_reserved_cus(int cus);
+
+/* Measurement aids (no reference counterpart).  mpnn_debug_spin: `wgs` workgroups of `threads` threads that do nothing
+ * but hold their slots for `us` microseconds (100 MHz device clock) -- a stand-in for a co-running collective kernel
+ * in tools/dp_corunner_probe.py.  mpnn_debug_noop: one wave that returns at once -- the launch floor in bench.py. */
+int mpnn_debug_spin(int wgs, int threads, float us, void *stream);
+int mpnn_debug_noop(void *stream);
+
 const char *mpnn_version(void);
 
 #ifdef __cplusplus

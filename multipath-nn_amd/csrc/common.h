@@ -19,33 +19,44 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // device at once (occupancy x compute units), cached per kernel instantiation.  The persistent grids
 // are sized to this: workgroups beyond it only start when earlier ones exit, which serialises the
 // bodies of a fused launch (measured: the weight-gradient workgroups of bwd_scale started 8-13 us late).
+// Compute units the persistent grids leave free (mpnn_set_reserved_cus, misc.hip): under data parallelism RCCL's
+// workgroups run beside the backward launches, and a grid fitted to EVERY resident slot then has workgroups that only
+// start once others exit -- which doubles a launch whose workgroups all finish together.
+extern int mpnn_reserved_cus_g;
+
 static int resident_slots(const void *kernel, int dyn_lds, int threads = 256, int max_per_cu = 0) {
-    struct Entry { const void *fn; int lds, slots, cap; };            // (a kernel is always queried with the same block size)
+    struct Entry { const void *fn; int lds, per_cu, cus, cap; };      // (a kernel is always queried with the same block size)
     static Entry cache[64];
     static int n_cached = 0;
-    for (int i = 0; i < n_cached; ++i)
-        if (cache[i].fn == kernel && cache[i].lds == dyn_lds && cache[i].cap == max_per_cu) return cache[i].slots;
-    int per_cu = 0, dev = 0, cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, (size_t)dyn_lds) != hipSuccess || per_cu < 1)
-        per_cu = 2;
-    // The occupancy query was seen to allow two 82 KB workgroups on a 160 KB CU (bwd_scale_k<2,4,2>:
-    // half of the grid then started 11-23 us late): bound it by the LDS arithmetic as well.
-    hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, kernel) == hipSuccess) {
-        const size_t lds = fa.sharedSizeBytes + (size_t)dyn_lds;
-        if (lds > 0) {
-            const int by_lds = (int)((160u * 1024u) / ((lds + 1279) / 1280 * 1280));     // 1280-byte allocation granules
-            if (by_lds >= 1 && by_lds < per_cu) per_cu = by_lds;
+    int per_cu = 0, cus = 256;
+    bool hit = false;
+    for (int i = 0; i < n_cached && !hit; ++i)
+        if (cache[i].fn == kernel && cache[i].lds == dyn_lds && cache[i].cap == max_per_cu) {
+            per_cu = cache[i].per_cu; cus = cache[i].cus; hit = true;
         }
+    if (!hit) {
+        int dev = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, (size_t)dyn_lds) != hipSuccess || per_cu < 1)
+            per_cu = 2;
+        // The occupancy query was seen to allow two 82 KB workgroups on a 160 KB CU (bwd_scale_k<2,4,2>:
+        // half of the grid then started 11-23 us late): bound it by the LDS arithmetic as well.
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, kernel) == hipSuccess) {
+            const size_t lds = fa.sharedSizeBytes + (size_t)dyn_lds;
+            if (lds > 0) {
+                const int by_lds = (int)((160u * 1024u) / ((lds + 1279) / 1280 * 1280));     // 1280-byte allocation granules
+                if (by_lds >= 1 && by_lds < per_cu) per_cu = by_lds;
+            }
+        }
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;      // (the caller wants fewer, larger shares)
+        if (n_cached < 64) cache[n_cached++] = Entry{kernel, dyn_lds, per_cu, cus, max_per_cu};
     }
-    if (hipGetDevice(&dev) == hipSuccess) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
-    if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;      // (the caller wants fewer, larger shares)
-    const int slots = per_cu * cus;
-    if (n_cached < 64) cache[n_cached++] = Entry{kernel, dyn_lds, slots, max_per_cu};
-    return slots;
+    const int free_cus = cus - mpnn_reserved_cus_g;
+    return per_cu * (free_cus < 8 ? 8 : free_cus);
 }
 
 // ---------------------------------------------------------------------------

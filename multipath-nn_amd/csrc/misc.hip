@@ -428,6 +428,34 @@ extern "C" int mpnn_augment_batch(const float *x_src, const float *y_src, const 
     return 0;
 }
 
+int mpnn_reserved_cus_g = 0;
+
+extern "C" int mpnn_set_reserved_cus(int cus) {
+    const int prev = mpnn_reserved_cus_g;
+    if (cus >= 0) mpnn_reserved_cus_g = cus;
+    return prev;
+}
+
+__global__ void spin_k(long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void noop_k() {}
+
+extern "C" int mpnn_debug_spin(int wgs, int threads, float us, void *stream) {
+    if (wgs <= 0) return 0;
+    if (threads < 64 || threads > 1024 || us < 0.f) return MPNN_E_ARG;
+    hipLaunchKernelGGL(spin_k, dim3(wgs), dim3(threads), 0, (hipStream_t)stream, (long)(us * 100.f));
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mpnn_debug_noop(void *stream) {
+    hipLaunchKernelGGL(noop_k, dim3(1), dim3(64), 0, (hipStream_t)stream);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
 int mpnn_trace_install_fwd(void *buf);
 int mpnn_trace_install_dgrad(void *buf);
 int mpnn_trace_install_wgrad(void *buf);

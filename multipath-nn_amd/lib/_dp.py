@@ -15,6 +15,9 @@ import torch
 import torch.distributed as dist
 
 
+_selftest = None          # outcome of captured_collectives_work() for the current process group
+
+
 def init(backend=None, force=False):
     """Initialise torch.distributed from the torchrun environment (RANK, WORLD_SIZE,
     LOCAL_RANK, MASTER_ADDR/PORT).  backend defaults to nccl (= RCCL on ROCm) when a
@@ -32,6 +35,14 @@ def init(backend=None, force=False):
         backend = os.environ.get('MPNN_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(local_device())
+        # A cap on RCCL's channels (= workgroups of its kernels) for the bucketed form, where the backward launches
+        # that run beside a bucket's all-reduce leave MPNN_DP_RESERVE_CUS compute units free (lib/_plan.py,
+        # mpnn_set_reserved_cus) and the collective must fit into them.  The default form (one all-reduce of 2.7 MB
+        # after the backward pass, nothing running beside it) leaves RCCL its own choice.
+        if int(os.environ.get('MPNN_DP_RESERVE_CUS', '0')) > 0:
+            os.environ.setdefault('NCCL_MAX_NCHANNELS', os.environ['MPNN_DP_RESERVE_CUS'])
+    global _selftest
+    _selftest = None
     dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size()
 
@@ -84,6 +95,48 @@ def sync_state(net):
     return net
 
 
+def agree(ok):
+    """Logical AND of a local flag over the ranks (every rank must take the same form of the step: a rank whose
+    graph capture failed issues its collectives from the host, the others inside their graphs)."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                     device=('cuda:%d' % local_device()) if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def captured_collectives_work():
+    """Self-test, run once per process group with MORE than one rank before any training step is captured: an
+    all-reduce recorded into a hipGraph and replayed twice must give the sum over the ranks, on every rank.  The
+    one-graph form of the data-parallel step (lib/_plan.py) is only used when this passed everywhere; otherwise all
+    ranks use one graph per bucket section with the collectives issued from the host."""
+    ok = True
+    try:
+        dev = 'cuda:%d' % local_device()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        buf = torch.zeros(1024, device=dev)
+        src = torch.full((1024,), float(rank + 1), device=dev)
+        side = torch.cuda.Stream(device=dev)
+        dist.all_reduce(buf.clone(), op=dist.ReduceOp.SUM)        # (communicator set-up outside the capture)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            buf.copy_(src)
+            h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+            with torch.cuda.stream(side):                         # (the shape of the real step: a consumer on a third stream)
+                h.wait()
+                buf.mul_(2.0)
+            torch.cuda.current_stream().wait_stream(side)
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        ok = bool(torch.all(buf == float(world * (world + 1))).item())
+    except Exception as e:                                          # noqa: BLE001 -- any failure means "do not capture"
+        import warnings
+        warnings.warn('captured RCCL collectives failed the self-test (%r): the data-parallel step uses section graphs' % (e,))
+        ok = False
+    return agree(ok)
+
+
 def attach(net, force=False):
     """Make ``net.train.run`` data-parallel over the initialised process group."""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
@@ -95,6 +148,14 @@ def attach(net, force=False):
     eng.world = dist.get_world_size()
     eng.allreduce = allreduce_async
     eng.allreduce_capturable = dist.get_backend() == 'nccl' and eng.P.is_cuda     # RCCL collectives capture into hipGraphs
+    eng.dp_agree = agree
+    if eng.allreduce_capturable and eng.dp_one_graph and eng.world > 1 and eng.use_graph:
+        # the one-graph step has only ever run with a forced ONE-rank group on the pool's one-GPU boxes: with more
+        # ranks it is taken only if a captured all-reduce verifiably works on this stack, and every rank agrees
+        global _selftest
+        if _selftest is None:
+            _selftest = captured_collectives_work()
+        eng.allreduce_capturable = _selftest
     eng._graphs.clear()                        # graphs captured so far folded the optimizer into the step
     for buf in (eng.P, eng.S, eng.A):          # identical replicas to start from
         if buf.is_cuda and dist.get_backend() == 'gloo':
@@ -108,6 +169,6 @@ def attach(net, force=False):
 def detach(net):
     """Back to single-process training (bench: after the 1-rank structure measurement)."""
     eng = net.engine()
-    eng.world, eng.allreduce, eng.allreduce_capturable = 1, None, False
+    eng.world, eng.allreduce, eng.allreduce_capturable, eng.dp_agree = 1, None, False, None
     eng._graphs.clear()
     return net

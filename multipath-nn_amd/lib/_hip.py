@@ -178,8 +178,13 @@ _SIGS = {
     'mpnn_conv_nhwc_fwd': [C.POINTER(ConvNhwcFwdArgs), P],
     'mpnn_conv_nhwc_dgrad': [C.POINTER(ConvNhwcDgradArgs), P],
     'mpnn_conv_nhwc_wgrad': [C.POINTER(ConvNhwcWgradArgs), P],
+    'mpnn_set_reserved_cus': [C.c_int],
+    'mpnn_debug_spin': [C.c_int, C.c_int, C.c_float, P],
+    'mpnn_debug_noop': [P],
+    'mpnn_draw_augmentation': [P, C.c_long, C.c_int, C.c_long, P, C.c_int, P, P],
 }
 
+_LONG = {'mpnn_draw_augmentation'}
 EXPORTS = sorted(_SIGS) + ['mpnn_version']
 
 _lib = None
@@ -203,7 +208,7 @@ def load():
         for name, sig in _SIGS.items():
             fn = getattr(lib, name)
             fn.argtypes = sig
-            fn.restype = C.c_int
+            fn.restype = C.c_long if name in _LONG else C.c_int
         lib.mpnn_version.restype = C.c_char_p
         _lib = lib
     return _lib

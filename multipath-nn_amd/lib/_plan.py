@@ -97,7 +97,20 @@ class Engine:
         self.world = 1
         self.allreduce = None            # callable(G) installed by lib/_dp.py
         self.allreduce_capturable = False  # the collective may be captured into a hipGraph (RCCL on device tensors)
+        self.dp_agree = None             # callable(bool) -> bool: logical AND over the ranks (lib/_dp.py)
         self.dp_one_graph = bool(int(os.environ.get('MPNN_DP_ONE_GRAPH', '1')))
+        # data parallel with SEVERAL gradient buckets (MPNN_DP_BUCKETS > 1; the default is one, see _alloc_params):
+        # compute units the backward launches that run beside a bucket's all-reduce leave to the collective's
+        # workgroups (mpnn_set_reserved_cus), and whether each bucket is applied (TALR + momentum) on a side stream as
+        # soon as its all-reduce has finished.  Both measured on one GPU with a stand-in for the collective
+        # (tools/dp_corunner_probe.py, profiles/r04_dp_corunner.txt) and OFF by default: a co-running kernel does not
+        # slow the launches it runs beside (the launches behind the bucket points are the deep small-map ones, which
+        # do not fill the chip), the reservation costs 12 us per step, and every additional parallel branch of the step
+        # graph stalls the main branch by ~30 us.
+        self.dp_reserve_cus = int(os.environ.get('MPNN_DP_RESERVE_CUS', '0'))
+        self.dp_bucket_opt = bool(int(os.environ.get('MPNN_DP_BUCKET_OPT', '0')))
+        self._opt_stream = None
+        self.prologue = None             # callable(stream): first launch of every training step (the input pipeline)
         self._keep = []
         self._progs = {}
         self._graphs = {}
@@ -251,7 +264,13 @@ class Engine:
             return (2, 0)
         self.trainable = sorted((p for p in self.net._all_params if p.trainable), key=ready_class)
         self.state_params = [p for p in self.net._all_params if not p.trainable]
-        off, cls_end, blk_end = 0, {0: 0, 1: 0, 2: 0}, {}
+        # The per-node TALR statistics (sum p_tr, sum p_tr^2; net_types.py:25-27) sit at the HEAD of G: they are final
+        # right after mpnn_route -- before any gradient -- and every segment's learning-rate scale needs them, so under
+        # data parallelism they ride in the FIRST bucket and each bucket can be applied as soon as it is reduced.
+        # P and A keep the same (unused) prefix: one offset addresses a parameter in all three buffers.
+        n_stat = 2 * len(self.nodes)
+        off = self.stat_pad = (n_stat + 3) // 4 * 4
+        cls_end, blk_end = {0: off, 1: off, 2: off}, {}
         for p in self.trainable:
             # every tensor starts on a 16-byte boundary: the kernels that stream gradients (slab reduction:
             # float4 loads and stores) take a 4x slower scalar path for a misaligned destination, and one
@@ -266,7 +285,7 @@ class Engine:
                 blk_end[c[1]] = off
         off = (off + 3) // 4 * 4
         self.n_params = off
-        # gradient buckets [lo, hi) in floats of G (the TALR node statistics ride in the last one):
+        # gradient buckets [lo, hi) in floats of G (the TALR node statistics ride at the head of the first one):
         # exits | conv of the blocks the backward finishes first (>= 40 % of the conv floats) | the rest
         conv_lo, conv_hi = cls_end[0], cls_end[1]
         cut, self.dp_cut_block = conv_hi, None
@@ -274,15 +293,26 @@ class Engine:
             if blk_end[k] - conv_lo >= 0.4 * (conv_hi - conv_lo) and blk_end[k] < conv_hi:
                 cut, self.dp_cut_block = blk_end[k], k          # k: index in reversed(self.blocks)
                 break
-        end = off + 2 * len(self.nodes)
+        end = off
         self.dp_buckets = {}                                   # name -> (lo, hi); markers of the same names in the program
-        n_buckets = int(os.environ.get('MPNN_DP_BUCKETS', '3'))
+        # ONE bucket by default: the whole of G is all-reduced after the launch that ends the backward pass.  The
+        # bucketed form (3: exits | deep blocks | rest, each all-reduce issued where its bucket becomes final, beside the
+        # rest of the backward pass) hides two of three collectives, but inside the step's hipGraph every parallel
+        # branch that starts in the MIDDLE of the main branch stalls the main branch by ~30 us on this runtime
+        # (profiles/r04_dp_corunner.txt: 498 -> 573 us with two 40-us stand-in kernels that overlap perfectly in the
+        # kernel trace; no runtime knob changes it, profiles/r04_dp_env_sweep.txt), which is more than a 0.7-0.9 MB
+        # all-reduce over xGMI takes.  A branch at the END of the graph (the one-bucket form) costs ~2 us.
+        n_buckets = int(os.environ.get('MPNN_DP_BUCKETS', '1'))
+        if os.environ.get('MPNN_DP_OVERLAP', '1') == '0':      # no overlap at all: the comparison point of the bucketed form
+            n_buckets = 1
         if n_buckets <= 1:                                     # ONE all-reduce of the whole of G after the backward pass
             conv_lo, self.dp_cut_block = 0, None
         elif n_buckets == 2:                                   # exits | everything else
             self.dp_cut_block = None
-        if conv_lo > 0:
-            self.dp_buckets['exit'] = (0, conv_lo)
+        if conv_lo > self.stat_pad:
+            self.dp_buckets['exit'] = (0, conv_lo)             # (with the node statistics at its head)
+        else:
+            conv_lo = 0
         if self.dp_cut_block is not None:
             self.dp_buckets['mid'] = (conv_lo, cut)
             self.dp_buckets['end'] = (cut, end)
@@ -292,13 +322,12 @@ class Engine:
         for p in self.state_params:
             p.offset = soff
             soff += p.size
-        n_stat = 2 * len(self.nodes)
         dev = self.dev
         self.P = torch.zeros(off, device=dev)
         self.A = torch.zeros(off, device=dev)
-        self.G = torch.zeros(off + n_stat, device=dev)
+        self.G = torch.zeros(off, device=dev)
         self.S = torch.zeros(max(soff, 1), device=dev)
-        self.node_stat = self.G[off:]
+        self.node_stat = self.G[:n_stat]
         for p in self.trainable:
             p.data = self.P[p.offset:p.offset + p.size]
             p.grad = self.G[p.offset:p.offset + p.size]
@@ -338,6 +367,13 @@ class Engine:
                 eq_off += p.size
         self.w_eq = torch.from_numpy(np.concatenate(eqs)).to(dev) if eqs else None
         self.n_seg = len(seg) // _hip.SEG_INTS
+        # optimizer work items of each gradient bucket (the items are in layout order): [first, count)
+        seg_off = seg[0::_hip.SEG_INTS]
+        self.seg_range = {}
+        for name, (lo, hi) in self.dp_buckets.items():
+            ks = [k for k, o in enumerate(seg_off) if lo <= o < hi]
+            self.seg_range[name] = (ks[0], len(ks)) if ks else (0, 0)
+            assert not ks or ks == list(range(ks[0], ks[0] + len(ks)))
         for p in self.trainable:
             p._on_assign = self.invalidate_packs
         self._packs_fresh = False
@@ -365,7 +401,7 @@ class Engine:
         self.dsum_last = torch.zeros(nd, dtype=torch.float64, device=dev)
         n_g = self.G.numel()
         self.G = self._zarena[zb:zb + n_g * 4].view(torch.float32)
-        self.node_stat = self.G[n_g - self.node_stat.numel():]
+        self.node_stat = self.G[:n_stat]
         for p in self.trainable:
             p.grad = self.G[p.offset:p.offset + p.size]
         self.n_bn = len(tab) // 8
@@ -664,6 +700,12 @@ class Engine:
     def program(self, mode, n, routed=False):
         """Launch lists of one (mode, batch size).  routed ('ev' only): the routed evaluation -- every
         block runs on the sample list its parent's router produced on the device (see _program_ev)."""
+        try:
+            return self._program(mode, n, routed)
+        finally:
+            self.lib.mpnn_set_reserved_cus(0)      # (a data-parallel training program is built with a reservation in place)
+
+    def _program(self, mode, n, routed):
         # routed='auto': routed above ROUTED_MIN_BATCH samples, dense below (the routed schedule is block-serial --
         # 28 launches against 13 -- and only pays once the launches are throughput-bound; profiles/r03_eval_sweep.txt)
         if routed == 'auto':
@@ -674,7 +716,8 @@ class Engine:
             # hipStreamEndCapture), and the DAG schedule has no bucket boundaries to overlap the collectives with
             raise NotImplementedError('data-parallel training runs on the single-stream schedule (MPNN_STREAMS=0)')
         dp = mode == 'tr' and self.allreduce is not None
-        key = (mode, n, self.multi_stream, self.group_fwd, routed, dp, self.bwd_levels, self.fold_clear)
+        reserve = self.dp_reserve_cus if (dp and len(self.dp_buckets) > 1) else 0
+        key = (mode, n, self.multi_stream, self.group_fwd, routed, dp, self.bwd_levels, self.fold_clear, reserve)
         if key in self._progs:
             return self._progs[key]
         self._ensure_capacity(n, mode == 'tr')
@@ -690,12 +733,15 @@ class Engine:
         ϕ = net.hypers
         fwd, bwd = [], []
 
+        cur_reserve = [0]                     # compute units the launches being built leave free (see below: trunk backward)
+
         def call(fn, what, *args, flops=0.0, tag='', stream=0, waits=(), records=None):
             def launch(st):
                 _hip.check(fn(*args, st), what)
             launch.what, launch.flops, launch.tag = what, float(flops), tag
             launch.stream, launch.waits, launch.records = stream, tuple(waits), records
             launch.args = args
+            launch.reserve = cur_reserve[0]
             return launch
 
         def marker(kind, tag=''):             # 'fork' / 'join' of the side streams; 'bucket': a gradient range is final
@@ -887,6 +933,10 @@ class Engine:
             bwd.append(call(lib.mpnn_lin_bwd_rs if n <= 512 else lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
         if dp and 'exit' in self.dp_buckets:
             bwd.append(marker('bucket', 'exit'))       # head + router gradients are final: their all-reduce starts here
+        # From here to the end of the backward pass a bucket's all-reduce runs beside the launches: their persistent
+        # grids (and the workgroup budgets computed below) leave `reserve` compute units to the collective's kernels.
+        cur_reserve[0] = reserve
+        lib.mpnn_set_reserved_cus(reserve)           # (program() resets it)
         bwd.append(marker('fork'))
         dz_written = set()
         slab_members = []                                   # (is_cut_block, table rows, [(args, field, offset)])
@@ -1332,8 +1382,12 @@ class Engine:
         streams (under graph capture they become parallel branches of the hipGraph)."""
         main = torch.cuda.current_stream()
         if not self.multi_stream:
-            for op in ops:
-                op(main.cuda_stream)
+            try:
+                for op in ops:
+                    self._set_reserve(getattr(op, 'reserve', 0))
+                    op(main.cuda_stream)
+            finally:
+                self._set_reserve(0)
             return
         # One set of side streams per section: re-forking streams that were already joined inside
         # the same hipGraph capture crashes hipStreamEndCapture (ROCm 7.2).
@@ -1376,6 +1430,13 @@ class Engine:
                 e.record(st)
                 events[op.records] = (op.stream, e)
         assert not forked, 'program section ended with side streams still forked'
+
+    def _set_reserve(self, cus):
+        """Compute units the grids of the launches that follow leave free (host-side state of the library)."""
+        if cus != getattr(self, '_reserved', 0):
+            self.lib.mpnn_set_reserved_cus(cus)
+            self._reserved = cus
+
     def _zero(self, train):
         if train:
             self._zarena.zero_()           # (G lives in the same arena)
@@ -1386,10 +1447,14 @@ class Engine:
         _hip.check(self.lib.mpnn_pack_weights(self.P.data_ptr(), self.packs.data_ptr(), self.pack_desc.data_ptr(),
                                               self.n_pack, torch.cuda.current_stream().cuda_stream), 'pack_weights')
 
-    def _opt(self, n):
+    def _opt(self, n, bucket=None):
+        """TALR + L2 + momentum update (net_types.py:24-37) of every parameter, or of one gradient bucket's."""
         talr = 1 if (self.net._net_kind != 'sr' and getattr(self.net.hypers, 'talr', False)) else 0
+        first, count = (0, self.n_seg) if bucket is None else self.seg_range[bucket]
+        if count == 0:
+            return
         _hip.check(self.lib.mpnn_talr_momentum_step(
-            self.P.data_ptr(), self.A.data_ptr(), self.G.data_ptr(), self.seg.data_ptr(), self.n_seg,
+            self.P.data_ptr(), self.A.data_ptr(), self.G.data_ptr(), self.seg[first * _hip.SEG_INTS:].data_ptr(), count,
             self.node_stat.data_ptr(), self.hyp.data_ptr(), talr, 1.0 / (n * self.world), 1.0 / self.world,
             self.w_eq.data_ptr() if self.w_eq is not None else None, self.packs.data_ptr(),
             torch.cuda.current_stream().cuda_stream), 'talr_momentum_step')
@@ -1450,11 +1515,14 @@ class Engine:
         elif not (prog.get('fold') and self._acc_clean):
             self._begin(True)
 
-    def _phase_a(self, prog, train):
+    def _phase_a(self, prog, train, n=None):
         """Everything of a step except the optimizer (eager launches).  Data parallel: the all-reduce
         of each gradient bucket is issued as soon as its section is queued -- lib/_dp.py returns an
         asynchronous handle, so the collective runs on RCCL's stream beside the rest of the backward
         pass; all handles are waited for (a stream-level dependency) before the optimizer."""
+        n = prog['n'] if n is None else n
+        if train and self.prologue is not None:
+            self.prologue(torch.cuda.current_stream().cuda_stream)
         self._clear_if_needed(prog, train)
         if train:
             self._acc_clean = False                # (until the whole backward pass has been queued)
@@ -1468,9 +1536,38 @@ class Engine:
         for k, (ops, bucket) in enumerate(self._sections(prog, train)):
             self._launch(ops, k)
             if bucket is not None:
-                handles.append(self._reduce_bucket(bucket))
-        self._wait(handles)
+                handles.append((bucket, self._reduce_bucket(bucket)))
+                if self._bucket_opt_on():
+                    self._opt_bucket(n, *handles.pop())
+        self._wait([h for _, h in handles])
         self._acc_clean = bool(prog.get('fold'))
+
+    def _bucket_opt_on(self):
+        return self.dp_bucket_opt and len(self.dp_buckets) > 1
+
+    def _opt_bucket(self, n, bucket, handle):
+        """Apply one gradient bucket as soon as its all-reduce has finished.  The last bucket: on the compute stream,
+        which then also waits for the side stream.  Earlier buckets: on a side stream behind the collective (the
+        parameters they update -- exits; the deep blocks' conv weights and their packs -- are not read by the rest of the
+        backward pass, and the node statistics every TALR scale needs came with the FIRST bucket), so the compute
+        stream goes on with the backward pass and only the `end` bucket's update stays exposed."""
+        main = torch.cuda.current_stream()
+        last = bucket == list(self.dp_buckets)[-1]
+        if last:
+            self._wait([handle])
+            self._opt(n, bucket)
+            if self._opt_stream is not None:
+                main.wait_stream(self._opt_stream)
+            return
+        if self._opt_stream is None:
+            self._opt_stream = torch.cuda.Stream(device=self.dev)
+        side = self._opt_stream
+        with torch.cuda.stream(side):
+            if hasattr(handle, 'wait'):
+                handle.wait()                      # (a stream dependency on the collective, on the side stream)
+            else:
+                side.wait_stream(main)             # (a blocking collective: it was ordered on the compute stream)
+            self._opt(n, bucket)
 
     def run(self, feed, train, routed=False):
         if len(self._event_keep) > 4096:
@@ -1493,17 +1590,33 @@ class Engine:
             self._bind_views(n)
             return
         prog = self.program(mode, n, routed)
-        do_bwd = train
         if not self.use_graph:
-            self._phase_a(prog, do_bwd)
-            if do_bwd:
-                self._opt(n)
+            self._step_eager(prog, train, n)
         else:
-            self._run_graphed(prog, do_bwd, n)
+            self._run_graphed(prog, train, n)
         self.last_n, self.last_mode = n, mode
         if train:
             self._last_fold = bool(prog.get('fold'))
         self._bind_views(n)
+
+    def _step_eager(self, prog, train, n):
+        """One step as eager launches (also what a whole-step hipGraph captures): everything up to the optimizer, then
+        the optimizer -- unless the data-parallel step already applied every bucket behind its all-reduce."""
+        self._phase_a(prog, train, n)
+        if train and not (self.allreduce is not None and self._bucket_opt_on()):
+            self._opt(n)
+
+    def set_prologue(self, fn):
+        """fn(stream) becomes the first launch of every training step -- lib/data.py installs the on-device batch
+        assembly (mpnn_augment_batch) here, so that it is replayed with the step's hipGraph."""
+        self.prologue = fn
+        self._graphs = {k: v for k, v in self._graphs.items() if k[0] != 'tr'}
+
+    def mark_dirty(self):
+        """Tell the engine that something outside run() launched program ops or wrote the step's accumulators (slot
+        sums, TALR statistics, loss sums): the next training step starts with a clearing launch instead of relying on
+        the previous step having left them cleared."""
+        self._acc_clean = False
 
     def _forward_tr(self, n):
         prog = self.program('tr', n)
@@ -1519,15 +1632,14 @@ class Engine:
         self._acc_clean = fold
 
     def _run_graphed(self, prog, train, n):
-        """First call runs eagerly (loads code objects); the second captures
-        hipGraphs (phase A = forward+backward, phase B = optimizer, split so a
-        data-parallel all-reduce can sit between them); later calls replay."""
-        key = (prog['mode'], n, train, prog.get('routed', False))
+        """First call runs eagerly (loads code objects); the second captures the step as ONE hipGraph (one process, or
+        data parallel over a backend whose collectives capture) or as one graph per gradient-bucket section with the
+        collectives issued from the host in between; later calls replay."""
+        key = (prog['mode'], n, train, prog.get('routed', False), self.bwd_levels, self.fold_clear,
+               self.allreduce is not None, self._bucket_opt_on())
         g = self._graphs.get(key)
         if g is None:
-            self._phase_a(prog, train)
-            if train:
-                self._opt(n)
+            self._step_eager(prog, train, n)
             self._graphs[key] = 'warm'
             return
         dp = train and self.allreduce is not None
@@ -1537,34 +1649,39 @@ class Engine:
             if fold and not self._acc_clean:           # (captured without a clearing launch: start from cleared accumulators)
                 self._begin(True)
                 self._acc_clean = True
-            if not dp:                                     # one process: ONE graph per step
-                ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, capture_error_mode=CAPTURE_MODE):
-                    self._phase_a(prog, train)
-                    if train:
-                        self._opt(n)
-                g = self._graphs[key] = ([(ga, None)], None)
-            elif self.dp_one_graph and self.allreduce_capturable:
-                # data parallel, RCCL: the WHOLE step -- sections, the asynchronous bucket all-reduces on the process
-                # group's stream, the waits, the optimizer -- captured as ONE hipGraph (RCCL collectives are
-                # capturable; the collective stream becomes a parallel branch of the graph).  One replay per step
-                # instead of four graph launches and three collective calls from the host.
+            g = None
+            if not dp or (self.dp_one_graph and self.allreduce_capturable):
+                # One process: ONE graph per step.  Data parallel over RCCL: the WHOLE step -- sections, the asynchronous
+                # bucket all-reduces on the process group's stream, the per-bucket updates behind them, the waits --
+                # is ONE hipGraph as well (RCCL collectives capture; the collective stream and the update stream become
+                # parallel branches of the graph): one replay per step instead of four graph launches and three
+                # collective calls from the host.
+                err = None
                 try:
                     ga = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(ga, capture_error_mode=CAPTURE_MODE):
-                        self._phase_a(prog, train)
-                        self._opt(n)
-                    g = self._graphs[key] = ([(ga, None)], 'whole')
-                except Exception as e:                         # (a stack whose collectives do not capture: section graphs)
-                    import warnings
-                    warnings.warn('capturing the data-parallel step as one hipGraph failed (%r): falling back to one graph '
-                                  'per gradient-bucket section' % (e,))
+                        self._step_eager(prog, train, n)
+                    g = ([(ga, None)], 'whole')
+                except Exception as e:
+                    if not dp:
+                        raise
+                    err = e
+                if dp:
+                    # EVERY rank must replay the same form (a rank that fell back issues its collectives from the
+                    # host, the others inside their graphs): the ranks agree on the outcome of the capture
                     torch.cuda.synchronize()
-                    self.dp_one_graph = False
-                    self._acc_clean = False
-                    self._graphs[key] = 'warm'
-                    return self._run_graphed(prog, train, n)
-            else:
+                    ok = self.dp_agree(err is None) if self.dp_agree is not None else err is None
+                    if not ok:
+                        import warnings
+                        warnings.warn('capturing the data-parallel step as one hipGraph failed on some rank (here: %r): '
+                                      'every rank falls back to one graph per gradient-bucket section' % (err,))
+                        g = None
+                        self.dp_one_graph = False
+                        self._acc_clean = False
+                        if fold:
+                            self._begin(True)
+                            self._acc_clean = True
+            if g is None:
                 # data parallel: one graph per section (the step up to the point where a gradient bucket
                 # is final), the bucket's all-reduce issued between the replays, and a graph for the optimizer
                 secs = []
@@ -1575,10 +1692,13 @@ class Engine:
                             self._clear_if_needed(prog, train)
                         self._launch(ops, k)
                     secs.append((gk, bucket))
-                gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, capture_error_mode=CAPTURE_MODE):
-                    self._opt(n)
-                g = self._graphs[key] = (secs, gb)
+                gb = None
+                if not self._bucket_opt_on():
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb, capture_error_mode=CAPTURE_MODE):
+                        self._opt(n)
+                g = (secs, gb)
+            self._graphs[key] = g
         secs, gb = g
         if fold and not self._acc_clean:               # something outside run() left the accumulators dirty
             self._begin(True)
@@ -1588,8 +1708,12 @@ class Engine:
         for gk, bucket in secs:
             gk.replay()
             if bucket is not None:
-                handles.append(self._reduce_bucket(bucket))
-        if dp and gb != 'whole':
+                h = self._reduce_bucket(bucket)
+                if self._bucket_opt_on():
+                    self._opt_bucket(n, bucket, h)         # (eager launches behind the collective)
+                else:
+                    handles.append(h)
+        if dp and gb != 'whole' and gb is not None:
             self._wait(handles)
             gb.replay()
         if train:

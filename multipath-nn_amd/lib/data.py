@@ -41,8 +41,39 @@ def _draw_augmentation(n, n_src, y, m_sym, r_shift, sym_src=None):
     return np.array(j, np.int64), np.array(flip, bool), np.array(sh, np.int64).reshape(n, 2)
 
 
-def augmented_batch(x0, y, n, m_sym, r_shift):
-    j, flip, sh = _draw_augmentation(n, len(x0), y, m_sym, r_shift)
+def _draw_augmentation_fast(n, n_src, sym_u8, r_shift, out=None, all_sym=False):
+    """The same draws as _draw_augmentation -- same values, same position of numpy's global stream afterwards --
+    without the per-sample Python calls: RAW 32-bit outputs are pulled from numpy's own generator
+    (randint(0, 2**32, size, uint32) returns consecutive MT19937 words) and the library's host function
+    mpnn_draw_augmentation consumes them exactly as randint / rand would (numpy's legacy masked-rejection bounded
+    integers, random_sample's two-word double).  Rejection sampling makes the number of words a batch needs
+    unknowable in advance, and the stream must not be over-drawn (other code draws from it between two batches):
+    each round fetches exactly the MINIMUM the remaining draws need, the function consumes all of it and reports the
+    new minimum (640 -> 240 -> 88 -> ... words for a batch of 128).  ~20 us per batch instead of 0.3-0.4 ms.
+    Returns an int32 [n, 4] array (j, flip, du, dv): the record mpnn_augment_batch reads."""
+    import ctypes as C
+    from . import _hip
+    lib = _hip.load()
+    if out is None:
+        out = np.empty((n, 4), np.int32)
+    state = np.zeros(4, np.int64)
+    state[3] = 1 if all_sym else 0                    # (every source is mirror-symmetric: two more words per sample are certain)
+    p_sym, p_out, p_state = (a.ctypes.data_as(C.c_void_p) for a in (sym_u8, out, state))
+    need = lib.mpnn_draw_augmentation(None, 0, n, n_src, p_sym, r_shift, p_out, p_state)
+    while need > 0:
+        raw = rand.randint(0, 2 ** 32, size=need, dtype=np.uint32)
+        need = lib.mpnn_draw_augmentation(raw.ctypes.data_as(C.c_void_p), need, n, n_src, p_sym, r_shift, p_out, p_state)
+    if need < 0:
+        raise _hip.HipError('mpnn_draw_augmentation: status %d' % need)
+    return out
+
+
+def augmented_batch(x0, y, n, m_sym, r_shift, draws=None):
+    """draws: an [n, 4] record array (j, flip, du, dv) from _draw_augmentation_fast instead of drawing here."""
+    if draws is None:
+        j, flip, sh = _draw_augmentation(n, len(x0), y, m_sym, r_shift)
+    else:
+        j, flip, sh = draws[:, 0].astype(np.int64), draws[:, 1].astype(bool), draws[:, 2:4].astype(np.int64)
     h, w = x0.shape[1:3]
     src = x0[j].astype(np.float64)
     src[flip] = src[flip][:, :, ::-1]
@@ -93,8 +124,12 @@ class Dataset:
     def augmented_training_batch(self, n=128, r_shift=4):
         return augmented_batch(self.x0_tr, self.y_tr, n, self.m_sym, r_shift)
 
-    # ---- device-resident path (mpnn_augment_batch): the dataset is uploaded once, a step costs a
-    # 2 KB upload of the draws and one gather launch; the draws are the reference's, call for call.
+    # ---- device-resident path (mpnn_augment_batch): the dataset is uploaded once; a step costs the draws (the
+    # reference's, call for call, replayed by the library's host function: ~20 us), a 2 KB asynchronous upload through
+    # a ring of pinned buffers and one gather launch -- which, once bind_engine() has installed it, is part of the
+    # training step's hipGraph.
+    RING = 8
+
     def to_device(self, device='cuda:0'):
         import torch
         self._dev = device
@@ -102,32 +137,64 @@ class Dataset:
         self._y_dev = torch.from_numpy(np.ascontiguousarray(self.y_tr, dtype=np.float32)).to(device)
         self._x_ts_dev = torch.from_numpy(np.ascontiguousarray(self.x0_ts, dtype=np.float32)).to(device)
         self._y_ts_dev = torch.from_numpy(np.ascontiguousarray(self.y_ts, dtype=np.float32)).to(device)
-        self._draw_host = None
+        self._sym_u8 = np.ascontiguousarray(_sym_of_sources(self.y_tr, self.m_sym), dtype=np.uint8)
+        self._all_sym = bool(self._sym_u8.all())
+        self._ring, self._slot, self._draw_dev = None, -1, None
         return self
+
+    def stage_training_draws(self, n=128, r_shift=4):
+        """Draw one batch's augmentation records -- (j, flip, du, dv) per sample, the reference's numpy.random call
+        sequence (scripts/lib/data.py:24-34) -- and queue their upload into the static device buffer the augmentation
+        launch reads.  Asynchronous: a ring of pinned host buffers, each reused only after the event behind its last
+        copy has completed (under hipGraph replay the host runs several steps ahead of the stream)."""
+        import torch
+        from . import _hip
+        if getattr(self, '_x_dev', None) is None:
+            raise _hip.HipError('Dataset.to_device() first: the augmentation kernel gathers from device memory')
+        if self._ring is None or self._ring[0][0].shape[0] < n:
+            self._ring = [(torch.zeros((n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING)]
+            self._draw_dev = torch.zeros((n, 4), dtype=torch.int32, device=self._dev)
+        k = self._slot = (self._slot + 1) % self.RING
+        buf, ev = self._ring[k]
+        if ev is not None:
+            ev.synchronize()
+        _draw_augmentation_fast(n, len(self.x0_tr), self._sym_u8, r_shift, out=buf.numpy()[:n], all_sym=self._all_sym)
+        self._draw_dev[:n].copy_(buf[:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._ring[k] = (buf, ev)
+        return self._draw_dev
+
+    def _augment_launch(self, n, x_out, y_out, stream):
+        from . import _hip
+        h, w, c = self.x0_tr.shape[1:]
+        _hip.check(_hip.load().mpnn_augment_batch(self._x_dev.data_ptr(), self._y_dev.data_ptr(), self._draw_dev.data_ptr(),
+                                                  x_out.data_ptr(), y_out.data_ptr(), n, h, w, c, self.y_tr.shape[1], stream),
+                   'augment_batch')
 
     def augmented_training_batch_device(self, n=128, r_shift=4, x_out=None, y_out=None):
         """Same batch as augmented_training_batch (same numpy RNG draws), assembled on the GPU in fp32.
         Returns (x, y) device tensors; pass x_out / y_out (e.g. the engine's input buffers) to fill them."""
         import torch
-        from . import _hip
-        if getattr(self, '_x_dev', None) is None:
-            raise _hip.HipError('Dataset.to_device() first: the augmentation kernel gathers from device memory')
-        lib = _hip.load()
-        if getattr(self, '_sym_src', None) is None:
-            self._sym_src = _sym_of_sources(self.y_tr, self.m_sym)
-        j, flip, sh = _draw_augmentation(n, len(self.x0_tr), self.y_tr, self.m_sym, r_shift, self._sym_src)
-        draw = np.stack([j, flip.astype(np.int64), sh[:, 0], sh[:, 1]], 1).astype(np.int32)
-        d = torch.from_numpy(draw).to(self._dev, non_blocking=False)
+        self.stage_training_draws(n, r_shift)
         h, w, c = self.x0_tr.shape[1:]
-        n_cls = self.y_tr.shape[1]
         if x_out is None:
             x_out = torch.empty((n, h, w, c), device=self._dev)
         if y_out is None:
-            y_out = torch.empty((n, n_cls), device=self._dev)
-        _hip.check(lib.mpnn_augment_batch(self._x_dev.data_ptr(), self._y_dev.data_ptr(), d.data_ptr(),
-                                          x_out.data_ptr(), y_out.data_ptr(), n, h, w, c, n_cls,
-                                          torch.cuda.current_stream().cuda_stream), 'augment_batch')
-        self._keep = d                                  # until the stream has consumed it
+            y_out = torch.empty((n, self.y_tr.shape[1]), device=self._dev)
+        self._augment_launch(n, x_out, y_out, torch.cuda.current_stream().cuda_stream)
+        return x_out, y_out
+
+    def bind_engine(self, eng, n=128):
+        """Make the batch assembly the FIRST launch of the engine's training step (part of its hipGraph): every
+        net.train.run then gathers the batch described by the latest stage_training_draws() straight into the
+        engine's input buffers.  Returns the (x0, y) views to put into the feed."""
+        if getattr(self, '_x_dev', None) is None:
+            self.to_device(str(eng.dev))
+        eng._ensure_capacity(n)
+        self.stage_training_draws(n)                     # (allocates the static draw buffer)
+        x_out, y_out = eng.x0[:n], eng.y[:n]
+        eng.set_prologue(lambda stream: self._augment_launch(n, x_out, y_out, stream))
         return x_out, y_out
 
     def training_batch(self, n=128):

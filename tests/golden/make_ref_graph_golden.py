@@ -32,6 +32,10 @@ CASES = {
     'cr': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9), tau=0.5, n=4),
     'cr_opt_cls': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9, optimistic=True, use_cls_err=True), tau=0.3, n=3),
     'sr3': dict(ctor='sr_chain', args=(3,), hypers={}, tau=None, n=3),
+    # the deepest statically-routed chain (scripts/train-nets:81-88), on CIFAR-shaped and on MNIST-shaped (one channel,
+    # prep-data:35-38) inputs.  (New keys sort AFTER the old ones: a case's seed is its index in sorted(CASES).)
+    'sr8': dict(ctor='sr_chain', args=(8,), hypers={}, tau=None, n=3),
+    'sr8_mnist': dict(ctor='sr_chain', args=(8,), hypers={}, tau=None, n=3, c0=1),
     # a 3-way switch over two sub-chains, built from the spec's own rcm / reg / pyr (the reference's dr_tree
     # cannot run at this revision: `y_shape` scoping bug, arch_and_hypers.py:99-106)
     'ac_tree3': dict(ctor='small_tree', net='ActorNet', hypers=dict(k_cpt=1.6e-8), tau=0.8, n=4),
@@ -79,7 +83,7 @@ def param_value(name, shape, rng):
 def case_inputs(case, seed):
     rng = np.random.RandomState(1000 + seed)
     n = case['n']
-    x0 = rng.random_sample((n, 32, 32, 3))
+    x0 = rng.random_sample((n, 32, 32, case.get('c0', 3)))
     y = np.eye(10)[rng.randint(0, 10, n)]
     kc = np.asarray(K_CPTS)[rng.randint(0, len(K_CPTS), n)] if case.get('dyn') else None
     return x0, y, kc
@@ -124,7 +128,7 @@ def main():
     out = {}
     for seed, (key, case) in enumerate(sorted(CASES.items())):
         tf_standin.reset()
-        net = make_case(A, NT, case)((32, 32, 3), (10,))
+        net = make_case(A, NT, case)((32, 32, case.get('c0', 3)), (10,))
         rng = np.random.RandomState(seed)
         params = ordered_params(net, NT.params_list_rec)
         for name, var in params:

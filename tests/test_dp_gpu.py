@@ -22,12 +22,24 @@ def _batch(rank):
     return g.random((N, 32, 32, 3)).astype(np.float32), np.eye(10, dtype=np.float32)[g.integers(0, 10, N)]
 
 
-def _net():
+def _net(buckets=3):
+    """(the bucketed form -- exits | deep blocks | rest -- unless asked otherwise: it exercises every piece of the
+    data-parallel machinery; the shipped default is ONE bucket, test_default_is_one_bucket)"""
     for p in (ROOT, os.path.join(ROOT, 'multipath-nn_amd')):
         if p not in sys.path:
             sys.path.insert(0, p)
     import arch_and_hypers as A
-    return A.ac_chain(k_cpt=1.6e-8, seed=21)((32, 32, 3), (10,))
+    old = os.environ.get('MPNN_DP_BUCKETS')
+    os.environ['MPNN_DP_BUCKETS'] = str(buckets)
+    try:
+        net = A.ac_chain(k_cpt=1.6e-8, seed=21)((32, 32, 3), (10,))
+        net.engine()
+    finally:
+        if old is None:
+            os.environ.pop('MPNN_DP_BUCKETS')
+        else:
+            os.environ['MPNN_DP_BUCKETS'] = old
+    return net
 
 
 def _feed(net, x0, y):
@@ -83,7 +95,8 @@ def test_two_ranks_match_hand_summed_gradients():
     xa, ya = _batch(0)
     xb, yb = _batch(1)
     ea.world = eb.world = 2
-    box = {}
+    ea.dp_bucket_opt = False       # a: forward + backward only (its update is applied below, from b's reduced G); b applies each
+    box = {}                       # bucket behind its "collective", the shipped form
     # the engine hands the collective one gradient BUCKET at a time (a view into G): b's "collective"
     # adds a's gradients of the same range
     def add_a(view):
@@ -121,6 +134,7 @@ def _rccl_one_rank(_idx, port, out, one_graph='1'):
         net.train.run(_feed(net, x0, y))
     _dp.sync_state(net)
     torch.cuda.synchronize()
+    out['selftest'] = _dp.captured_collectives_work()      # (what a run with more than one rank checks before it captures)
     key = [k for k in eng._graphs if k[0] == 'tr'][0]
     secs, gb = eng._graphs[key]
     out['sections'] = [b for _, b in secs]
@@ -140,6 +154,7 @@ def test_rccl_path_on_one_gpu_matches_single_process():
     # RCCL collectives capture: the whole step (bucket sections, async all-reduces, waits, optimizer) is ONE hipGraph
     assert out['buckets'] == ['exit', 'mid', 'end']
     assert out['whole'] and out['sections'] == [None]
+    assert out['selftest'] is True
     net = _net()
     x0, y = _batch(0)
     for _ in range(4):
@@ -165,6 +180,80 @@ def test_rccl_section_graphs_on_one_gpu():
     torch.cuda.synchronize()
     ref = net.engine().P.cpu().numpy()
     assert np.abs(out['P'] - ref).max() <= 3e-4 * np.abs(ref).max()
+
+
+def test_default_is_one_bucket():
+    """The shipped form: the whole of G (TALR statistics at its head) in ONE all-reduce after the backward pass."""
+    for p in (ROOT, os.path.join(ROOT, 'multipath-nn_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import arch_and_hypers as A
+    assert 'MPNN_DP_BUCKETS' not in os.environ
+    net = A.ac_chain(k_cpt=1.6e-8, seed=21)((32, 32, 3), (10,))
+    eng = net.engine()
+    assert list(eng.dp_buckets) == ['end'] and eng.dp_buckets['end'] == (0, eng.G.numel())
+    assert eng.node_stat.data_ptr() == eng.G.data_ptr() and eng.dp_reserve_cus == 0 and not eng._bucket_opt_on()
+    P, res = _standin_run(0, False, net=net)
+    ref = _net()
+    x0, y = _batch(0)
+    for _ in range(4):
+        ref.train.run(_feed(ref, x0, y))
+    torch.cuda.synchronize()
+    r = ref.engine().P.cpu().numpy()
+    assert np.abs(P - r).max() <= 3e-4 * np.abs(r).max()
+
+
+def _standin_run(reserve, bucket_opt, k=8, T=10.0, steps=4, net=None):
+    """The one-graph data-parallel step with the collective replaced by the co-runner stand-in of
+    tools/dp_corunner_probe.py (k spinning workgroups on a side stream at every bucket point)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import dp_corunner_probe as probe
+    net = _net() if net is None else net
+    eng = net.engine()
+    eng.dp_reserve_cus, eng.dp_bucket_opt = reserve, bucket_opt
+    probe.install_corunner(eng, k, T)
+    x0, y = _batch(0)
+    for _ in range(steps):
+        net.train.run(_feed(net, x0, y))
+    torch.cuda.synchronize()
+    key = [q for q in eng._graphs if q[0] == 'tr'][0]
+    assert eng._graphs[key][1] == 'whole'
+    prog = eng.program('tr', N)
+    res = sorted({getattr(op, 'reserve', 0) for op in prog['bwd'] if op.what == 'bwd_scale'})
+    return eng.P.cpu().numpy().copy(), res
+
+
+def test_reserved_cus_and_per_bucket_updates_do_not_change_the_step():
+    """Grids that leave compute units to a co-running collective (mpnn_set_reserved_cus) and updates applied bucket
+    by bucket on a side stream are a SCHEDULE: four steps give the parameters of the plain single-process step."""
+    net = _net()
+    x0, y = _batch(0)
+    for _ in range(4):
+        net.train.run(_feed(net, x0, y))
+    torch.cuda.synchronize()
+    ref = net.engine().P.cpu().numpy()
+    scale = np.abs(ref).max()
+    for reserve, bucket_opt in ((0, False), (16, True), (32, True), (16, False)):
+        P, res = _standin_run(reserve, bucket_opt)
+        assert res == [reserve], res                  # every trunk-backward launch was built with the reservation
+        assert np.abs(P - ref).max() <= 3e-4 * scale, (reserve, bucket_opt, np.abs(P - ref).max())
+    lib = net.engine().lib
+    assert lib.mpnn_set_reserved_cus(-1) == 0         # nothing leaks out of a step
+
+
+def test_reserved_cus_shrink_the_slot_counts():
+    for p in (ROOT, os.path.join(ROOT, 'multipath-nn_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from lib import _hip
+    lib = _hip.load()
+    full = lib.mpnn_msconv_bwd_scale_slots(4, 4, 128, 1, 1, 4096)
+    assert lib.mpnn_set_reserved_cus(32) == 0
+    try:
+        less = lib.mpnn_msconv_bwd_scale_slots(4, 4, 128, 1, 1, 4096)
+    finally:
+        lib.mpnn_set_reserved_cus(0)
+    assert 0 < less < full and full - less == 32 * (full // 256), (full, less)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs of one node')
@@ -197,7 +286,7 @@ def test_bench_two_ranks_functional_on_one_gpu(tmp_path):
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     line = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['global_batch'] == 256 and line['config']['rccl_ranks'] == 2
-    assert set(line['config']['allreduce']) == {'exit', 'mid', 'end'}
+    assert set(line['config']['allreduce']) == {'end'}
     assert line['value'] > 0 and line['steady_state']['steps'] == 400
 
 

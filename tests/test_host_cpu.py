@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(_hip.LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()
-    declared = set(re.findall(r'^(?:int|const char \*)\s*(mpnn_\w+)\(', open(HEADER).read(), re.M))
+    declared = set(re.findall(r'^(?:int|long|const char \*)\s*(mpnn_\w+)\(', open(HEADER).read(), re.M))
     assert declared and declared == set(_hip.EXPORTS), declared ^ set(_hip.EXPORTS)
     lib = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
@@ -237,3 +237,47 @@ def test_bench_launcher_spawns_ranks_without_touching_the_gpu(monkeypatch):
     assert cmd[-6:] == ['--gpus', '4', '--steps', '3', '--warmup', '1'] and cmd[-7].endswith('bench.py')
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
     assert not torch.cuda.is_initialized()
+
+
+def test_fast_augmentation_draws_replay_numpy_stream_exactly():
+    """lib/data.py:_draw_augmentation_fast (the library's host function mpnn_draw_augmentation over raw MT19937 words)
+    against the per-call numpy loop that mirrors scripts/lib/data.py:24-34: same (j, flip, du, dv) for every sample AND
+    the same position of numpy's global stream afterwards, for set sizes on both sides of a power of two, shift ranges
+    incl. 0, all / some / no symmetric classes, a one-image set (randint(0, 1) consumes no word)."""
+    import numpy.random as rand
+    from lib.data import _draw_augmentation, _draw_augmentation_fast, _sym_of_sources
+    cases = [(0, 50000, 4, 10), (1, 60000, 4, 5), (2, 4096, 4, 10), (3, 1, 4, 0), (4, 65536, 0, 3), (5, 1000, 2, 7),
+             (6, 50000, 4, 0), (7, 1, 0, 0), (8, 1, 0, 10), (9, 3, 1, 10), (10, 65537, 7, 9)]
+    for seed, n_src, r, nsym in cases:
+        g = np.random.default_rng(seed)
+        y = np.eye(10)[g.integers(0, 10, n_src)]
+        m_sym = np.zeros(10, bool); m_sym[:nsym] = True
+        sym = _sym_of_sources(y, m_sym)
+        su8 = np.asarray(sym, np.uint8)
+        rand.seed(seed)
+        ref = [_draw_augmentation(37, n_src, y, m_sym, r, sym) for _ in range(3)]
+        tail_ref = rand.rand(3)
+        for all_sym in ([False, True] if su8.all() else [False]):
+            rand.seed(seed)
+            out = [_draw_augmentation_fast(37, n_src, su8, r, all_sym=all_sym).copy() for _ in range(3)]
+            tail = rand.rand(3)
+            for (j, f, sh), o in zip(ref, out):
+                assert np.array_equal(o[:, 0], j) and np.array_equal(o[:, 1].astype(bool), f) and np.array_equal(o[:, 2:], sh), (seed,)
+            assert np.array_equal(tail, tail_ref), ('stream position', seed)
+
+
+def test_fast_draws_reproduce_the_reference_fixtures():
+    """The fixtures produced by the reference's own data.py (tests/golden/data_aug_golden.npz: seed, batch size, shift
+    range and the batch the REFERENCE returned): the records of the fast path, pushed through the vectorised pixel
+    assembly, give the reference's batches bit for bit."""
+    import numpy.random as rand
+    from lib.data import augmented_batch, _draw_augmentation_fast, _sym_of_sources
+    G = np.load(os.path.join(ROOT, 'tests', 'golden', 'data_aug_golden.npz'))
+    x0, y, m_sym = G['x0'], G['y'], G['m_sym']
+    su8 = np.asarray(_sym_of_sources(y, m_sym), np.uint8)
+    for k in range(3):
+        seed, n, r = (int(v) for v in G['case%d_args' % k])
+        rand.seed(seed)
+        rec = _draw_augmentation_fast(n, len(x0), su8, r)
+        xb, yb = augmented_batch(x0, y, n, m_sym, r, draws=rec)
+        assert np.array_equal(xb, G['case%d_x' % k]) and np.array_equal(yb, G['case%d_y' % k]), k

@@ -239,6 +239,28 @@ def test_bench_config_ac_chain_kcpt0_batch_128():
     run_case(A.ac_chain(k_cpt=0.0), 128, lambda net, t: {net.τ: A.τ_ds(0)}, steps=2)
 
 
+def test_baseline_cifar10_sr_chain8_batch_128():
+    """BASELINE.json `cifar10-sr` at the training batch (scripts/train-nets:81-88: sr_chain(8) is the deepest
+    statically-routed net of every *-sr experiment; arch_and_hypers.py:35: batch 128)."""
+    import arch_and_hypers as A
+    run_case(A.sr_chain(8), 128, lambda net, t: {}, steps=1)
+
+
+def test_baseline_mnist_sr_chain8_batch_128():
+    """BASELINE.json `mnist-sr` as bench.py times it: sr_chain(8) on 32x32x1 inputs (prep-data:35-38 resizes MNIST to
+    32x32, one channel), batch 128."""
+    import arch_and_hypers as A
+    run_case(A.sr_chain(8), 128, lambda net, t: {}, steps=1, c0=1)
+
+
+def test_baseline_hybrid_dyn_k_cpt_batch_128():
+    """BASELINE.json's hybrid adaptive net (scripts/train-adaptive-nets:24-45): ac_chain(dyn_k_cpt=True), a k_cpt per
+    sample drawn from k_cpts, batch 128."""
+    import arch_and_hypers as A
+    kv = lambda t, n: np.random.default_rng(t).choice(A.k_cpts, n).astype(np.float32)
+    run_case(A.ac_chain(dyn_k_cpt=True), 128, lambda net, t: {net.τ: A.τ_ds(0)}, steps=1, k_cpt_vec=kv)
+
+
 def test_batch_of_one_eval():
     """A single image through the evaluation path (BatchNorm moving averages; batch statistics of
     one sample would be degenerate in 'tr')."""

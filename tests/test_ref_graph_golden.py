@@ -48,7 +48,7 @@ def test_oracle_matches_the_reference_graph_code(key):
     from oracle.ref_net import RefNet
     case = M.CASES[key]
     seed = sorted(M.CASES).index(key)
-    net = M.make_case(A, NT, case)((32, 32, 3), (10,))
+    net = M.make_case(A, NT, case)((32, 32, case.get('c0', 3)), (10,))
     params = ordered(net)
     assert [n for n, _ in params] == list(GOLD['%s/names' % key])        # same parameters, same order
     rng = np.random.RandomState(seed)
@@ -102,7 +102,7 @@ def test_product_matches_the_reference_graph_code(key):
     import lib.net_types as NT
     case = M.CASES[key]
     seed = sorted(M.CASES).index(key)
-    net = M.make_case(A, NT, case)((32, 32, 3), (10,))
+    net = M.make_case(A, NT, case)((32, 32, case.get('c0', 3)), (10,))
     net.engine()
     params = ordered(net)
     rng = np.random.RandomState(seed)

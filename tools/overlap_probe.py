@@ -65,3 +65,4 @@ for d in sorted(levels):
     print('level %2d: %-60s each %s  serial %6.1f  concurrent %6.1f  (max member %5.1f)' % (
         d, ' | '.join('%s[b%d]' % (ops[k].tag, keys[k][0]) for k in idx), ' '.join('%5.1f' % t for t in each), ser, con, max(each)))
 print('sum: serial %.1f us, concurrent (saturated streams) %.1f us, sum of max members %.1f us' % (tot_s, tot_c, tot_m))
+eng.mark_dirty()          # (program ops were launched outside run(): the next step must clear the accumulators)
