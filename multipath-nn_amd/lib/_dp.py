@@ -95,6 +95,19 @@ def sync_state(net):
     return net
 
 
+def quiesce():
+    """Call before capturing a hipGraph that contains collectives.  The process group's watchdog thread polls the end
+    event of every collective issued OUTSIDE a capture until it has seen it complete (one pass every ~100 ms); an
+    event query that lands while the collective's stream is being captured fails with hipErrorCapturedEvent and takes
+    the process down (seen on this stack: 'operation not permitted on an event last recorded in a capturing stream' from
+    the watchdog).  After a device synchronize every pending collective is complete; two watchdog periods later the
+    watchdog has dropped them all and has nothing left to poll."""
+    import time
+    if dist.is_initialized() and dist.get_backend() == 'nccl':
+        torch.cuda.synchronize()
+        time.sleep(0.3)
+
+
 def agree(ok):
     """Logical AND of a local flag over the ranks (every rank must take the same form of the step: a rank whose
     graph capture failed issues its collectives from the host, the others inside their graphs)."""
@@ -117,7 +130,7 @@ def captured_collectives_work():
         src = torch.full((1024,), float(rank + 1), device=dev)
         side = torch.cuda.Stream(device=dev)
         dist.all_reduce(buf.clone(), op=dist.ReduceOp.SUM)        # (communicator set-up outside the capture)
-        torch.cuda.synchronize()
+        quiesce()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
             buf.copy_(src)
@@ -149,6 +162,7 @@ def attach(net, force=False):
     eng.allreduce = allreduce_async
     eng.allreduce_capturable = dist.get_backend() == 'nccl' and eng.P.is_cuda     # RCCL collectives capture into hipGraphs
     eng.dp_agree = agree
+    eng.dp_quiesce = quiesce
     if eng.allreduce_capturable and eng.dp_one_graph and eng.world > 1 and eng.use_graph:
         # the one-graph step has only ever run with a forced ONE-rank group on the pool's one-GPU boxes: with more
         # ranks it is taken only if a captured all-reduce verifiably works on this stack, and every rank agrees
@@ -169,6 +183,6 @@ def attach(net, force=False):
 def detach(net):
     """Back to single-process training (bench: after the 1-rank structure measurement)."""
     eng = net.engine()
-    eng.world, eng.allreduce, eng.allreduce_capturable, eng.dp_agree = 1, None, False, None
+    eng.world, eng.allreduce, eng.allreduce_capturable, eng.dp_agree, eng.dp_quiesce = 1, None, False, None, None
     eng._graphs.clear()
     return net

@@ -98,6 +98,7 @@ class Engine:
         self.allreduce = None            # callable(G) installed by lib/_dp.py
         self.allreduce_capturable = False  # the collective may be captured into a hipGraph (RCCL on device tensors)
         self.dp_agree = None             # callable(bool) -> bool: logical AND over the ranks (lib/_dp.py)
+        self.dp_quiesce = None           # callable(): no collective of the process group is pending or being polled
         self.dp_one_graph = bool(int(os.environ.get('MPNN_DP_ONE_GRAPH', '1')))
         # data parallel with SEVERAL gradient buckets (MPNN_DP_BUCKETS > 1; the default is one, see _alloc_params):
         # compute units the backward launches that run beside a bucket's all-reduce leave to the collective's
@@ -1657,6 +1658,8 @@ class Engine:
                 # parallel branches of the graph): one replay per step instead of four graph launches and three
                 # collective calls from the host.
                 err = None
+                if dp and self.dp_quiesce is not None:
+                    self.dp_quiesce()                      # (the watchdog must not poll an eager collective during the capture)
                 try:
                     ga = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(ga, capture_error_mode=CAPTURE_MODE):

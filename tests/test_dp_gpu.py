@@ -67,7 +67,7 @@ def _worker(rank, world, port, out):
     for _ in range(3):                       # eager step, graph capture, graph replay
         net.train.run(_feed(net, x0, y))
     torch.cuda.synchronize()
-    out[rank] = eng.P.cpu().numpy().copy()
+    np.save(os.path.join(out, 'P%d.npy' % rank), eng.P.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,12 +79,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_ranks_match_hand_summed_gradients():
+def test_two_ranks_match_hand_summed_gradients(tmp_path):
     world, port = 2, _free_port()
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    p0, p1 = out[0], out[1]
+    # (results come back through files: a multiprocessing.Manager forked from a process that holds a HIP context was
+    # seen to drop its connections in the middle of a long pytest run)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    p0, p1 = (np.load(str(tmp_path / ('P%d.npy' % r))) for r in range(2))
     assert np.array_equal(p0, p1), 'replicas diverged'
 
     # single-process emulation of rank 0: the "collective" adds rank 1's gradients, which are
@@ -134,23 +134,31 @@ def _rccl_one_rank(_idx, port, out, one_graph='1'):
         net.train.run(_feed(net, x0, y))
     _dp.sync_state(net)
     torch.cuda.synchronize()
-    out['selftest'] = _dp.captured_collectives_work()      # (what a run with more than one rank checks before it captures)
+    res = {'selftest': _dp.captured_collectives_work()}    # (what a run with more than one rank checks before it captures)
     key = [k for k in eng._graphs if k[0] == 'tr'][0]
     secs, gb = eng._graphs[key]
-    out['sections'] = [b for _, b in secs]
-    out['whole'] = gb == 'whole'
-    out['buckets'] = list(eng.dp_buckets)
-    out['P'] = eng.P.cpu().numpy().copy()
+    res['sections'] = [b for _, b in secs]
+    res['whole'] = gb == 'whole'
+    res['buckets'] = list(eng.dp_buckets)
+    np.save(os.path.join(out, 'P.npy'), eng.P.cpu().numpy())
+    import json
+    json.dump(res, open(os.path.join(out, 'res.json'), 'w'))
     dist.destroy_process_group()
 
 
-def test_rccl_path_on_one_gpu_matches_single_process():
+def _run_rccl_one_rank(tmp_path, one_graph='1'):
+    import json
+    mp.spawn(_rccl_one_rank, args=(_free_port(), str(tmp_path), one_graph), nprocs=1, join=True)
+    out = json.load(open(str(tmp_path / 'res.json')))
+    out['P'] = np.load(str(tmp_path / 'P.npy'))
+    return out
+
+
+def test_rccl_path_on_one_gpu_matches_single_process(tmp_path):
     """The real collective backend (nccl = RCCL) with ONE rank: process-group init, asynchronous
     bucket all-reduces issued between the section graphs, stream-level waits, optimizer graph.  A
     one-rank sum is the identity, so the parameters must equal a plain single-process run."""
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_rccl_one_rank, args=(_free_port(), out), nprocs=1, join=True)
+    out = _run_rccl_one_rank(tmp_path)
     # RCCL collectives capture: the whole step (bucket sections, async all-reduces, waits, optimizer) is ONE hipGraph
     assert out['buckets'] == ['exit', 'mid', 'end']
     assert out['whole'] and out['sections'] == [None]
@@ -166,12 +174,10 @@ def test_rccl_path_on_one_gpu_matches_single_process():
     assert np.abs(out['P'] - ref).max() <= 3e-4 * np.abs(ref).max()
 
 
-def test_rccl_section_graphs_on_one_gpu():
+def test_rccl_section_graphs_on_one_gpu(tmp_path):
     """The fallback form (MPNN_DP_ONE_GRAPH=0, or a stack whose collectives do not capture): one graph per bucket
     section, the all-reduces issued from the host between the replays, a graph for the optimizer."""
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_rccl_one_rank, args=(_free_port(), out, '0'), nprocs=1, join=True)
+    out = _run_rccl_one_rank(tmp_path, '0')
     assert not out['whole'] and out['sections'] == ['exit', 'mid', 'end']
     net = _net()
     x0, y = _batch(0)
