@@ -434,7 +434,7 @@ def main():
         # (a) of a truly EMPTY kernel (one wave that returns: what a grid boundary costs, comparable across rounds and with
         # the guide's figure), (b) of the smallest kernel of the library that does work (a 1-item slab reduction: two
         # dependent memory round trips; this is what rounds 1-3 reported as `launch_floor`)
-        n_launch = len(ops) + 1                                   # + the optimizer
+        n_launch = len(ops) + (0 if eng.program('tr', n).get('fused_opt') else 1)     # (+ the optimizer when it is a launch of its own)
         st = torch.cuda.current_stream()
         tab = torch.tensor([0, 0, 4, 1, 4, 0], dtype=torch.int32, device=dev)
         buf = torch.zeros(64, device=dev)

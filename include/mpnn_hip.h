@@ -506,6 +506,20 @@ int mpnn_backward_finish(const float *slabs, float *grads, const int *slab_table
                          double *sums, double *reds, float *state, const int *bn_table,
                          int n_bn, float decay, int n_img, double *sums_keep, void *stream);
 
+/* mpnn_backward_finish AND mpnn_talr_momentum_step in ONE launch (single-process training: nothing sits between the
+ * gradients and their use; under data parallelism the all-reduce does, and the two stay separate).  Every slab item's
+ * workgroup applies the update to the elements it has just reduced (item_seg: one MPNN_SEG_INTS row per slab item, same
+ * fields as the optimizer's work items, count <= MPNN_SLAB_ITEM), every BatchNorm's workgroup to its gamma / beta
+ * (bn_opt: 4 ints per record of bn_table: tree node, l2 bits of gamma, l2 bits of beta, reserved), and n_plain further
+ * workgroups run the optimizer work items plain_seg whose gradients are already final in `grads`.  Element for element
+ * the arithmetic of the two launches it replaces. */
+int mpnn_backward_finish_opt(const float *slabs, const int *slab_table, int n_items, const int *item_seg,
+                             double *sums, double *reds, float *state, const int *bn_table, int n_bn,
+                             const int *bn_opt, float decay, int n_img, double *sums_keep,
+                             float *params, float *accum, float *grads, const float *node_stat,
+                             const float *hyp, int talr, float inv_n, float grad_scale, const float *w_eq,
+                             float *packs, const int *plain_seg, int n_plain, void *stream);
+
 /* Workgroups of the mpnn_msconv_bwd_scale kernel (the variant for this shape, with or without a
  * dgrad-vert body) for an H x W x Cout scale that are resident on the
  * device at once (occupancy x compute units; needs a GPU).  The caller gives the weight-gradient

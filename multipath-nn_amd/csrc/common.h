@@ -188,10 +188,14 @@ __device__ __forceinline__ void bn_bwd_row(const mpnn_act &b, const double *red,
 
 // One BatchNorm of mpnn_bn_finalize (table record t: see misc.hip): moving averages from the forward
 // sums, dgamma / dbeta from the backward reductions.  Shared by bn_finalize_k and backward_finish_k.
+struct BnNoHook { __device__ __forceinline__ void operator()(int, float, int, float) const {} };
+// on_grad(beta offset, dbeta, gamma offset, dgamma): called for every channel whose gradients were written (the fused
+// end of the backward pass applies the parameter update there)
+template <class F = BnNoHook>
 __device__ __forceinline__ void bn_finalize_body(double *__restrict__ sums, double *__restrict__ reds,
                                                  float *__restrict__ state, float *__restrict__ grads,
                                                  const int *__restrict__ t, float decay, int n_img,
-                                                 double *__restrict__ sums_keep) {
+                                                 double *__restrict__ sums_keep, F on_grad = F()) {
     const int C = t[3], ns = t[7];
     const double inv = 1.0 / ((double)t[4] * (double)n_img);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -207,8 +211,11 @@ __device__ __forceinline__ void bn_finalize_body(double *__restrict__ sums, doub
             *v = decay * *v + (1.f - decay) * (float)var;
         }
         if (reds && grads && t[5] >= 0) {
-            grads[t[6] + c] = (float)slot_sum(reds + t[0], 2 * C, c, ns);          // dbeta  = sum dz
-            grads[t[5] + c] = (float)slot_sum(reds + t[0], 2 * C, C + c, ns);      // dgamma = sum dz * xhat
+            const float dbeta = (float)slot_sum(reds + t[0], 2 * C, c, ns);            // dbeta  = sum dz
+            const float dgamma = (float)slot_sum(reds + t[0], 2 * C, C + c, ns);       // dgamma = sum dz * xhat
+            grads[t[6] + c] = dbeta;
+            grads[t[5] + c] = dgamma;
+            on_grad(t[6] + c, dbeta, t[5] + c, dgamma);
         }
         // This is the LAST reader of the step's slot sums: with sums_keep set it leaves them cleared for the next
         // step (the forward convs and the backward epilogues add to them with atomics), so that a training step

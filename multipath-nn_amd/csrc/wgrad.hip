@@ -22,6 +22,7 @@
 // 2 pixel groups of a ds_read_b32 wave-half fall on 32 distinct banks; the g
 // tile as [64 pixels][OT*16 + 4].
 #include "bwd_bodies.h"
+#include "opt_body.h"
 
 template <int GK, int OT>
 __global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
@@ -263,7 +264,10 @@ extern "C" int mpnn_msconv_bwd_scale(const mpnn_dgrad_horz_args *h, const mpnn_d
 // (History: fixed 256-element items, slabs dealt to the four waves: 6 500 workgroups of two loads per
 // thread for the chains -- latency, not bandwidth: 2 TB/s.)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void slab_item(const float *__restrict__ slabs, float *__restrict__ grads, const int *__restrict__ t) {
+// gl (optional, LDS, >= count floats): the reduced values are ALSO left there (mpnn_backward_finish_opt applies the
+// parameter update to them in the same workgroup).
+__device__ __forceinline__ void slab_item(const float *__restrict__ slabs, float *__restrict__ grads, const int *__restrict__ t,
+                                          float *gl = nullptr) {
     const int src = t[0], dst = t[1], cnt = t[2], ns = t[3], stride = t[4];
     __shared__ f32x4 part[256];
     const int quads = (cnt + 3) >> 2;
@@ -309,6 +313,7 @@ __device__ __forceinline__ void slab_item(const float *__restrict__ slabs, float
     if (on_t && grp == 0) {
         if (vec && i + 4 <= cnt) *(f32x4 *)(grads + dst + i) = tot;
         else for (int j = 0; j < 4 && i + j < cnt; ++j) grads[dst + i + j] = tot[j];
+        if (gl) for (int j = 0; j < 4 && i + j < cnt; ++j) gl[i + j] = tot[j];
     }
 }
 
@@ -334,6 +339,62 @@ extern "C" int mpnn_backward_finish(const float *slabs, float *grads, const int 
     if (n_items < 0 || n_bn < 0 || n_items + n_bn == 0) return n_items + n_bn == 0 ? 0 : MPNN_E_ARG;
     hipLaunchKernelGGL(backward_finish_k, dim3(n_items + n_bn), dim3(256), 0, (hipStream_t)stream, slabs, grads, slab_table,
                        n_items, sums, reds, state, bn_table, decay, n_img, sums_keep);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+// mpnn_backward_finish_opt: mpnn_backward_finish AND mpnn_talr_momentum_step as one launch (single-process training:
+// nothing sits between the gradients and their use).  Workgroups:
+//   [0, n_items)              a slab item: the sum over the slabs, then the update of exactly those elements (the
+//                             gradient goes from the reduction to the update through LDS; seg row = item_seg[item])
+//   [.., + n_bn)              a BatchNorm: moving averages, dgamma / dbeta, and their update (bn_opt[bn] = node, l2 bits
+//                             of gamma, l2 bits of beta, -)
+//   [.., + n_plain)           an optimizer work item whose gradient is already final in `grads` (exit parameters,
+//                             tensors whose weight gradient was written without slabs)
+// Same arithmetic, element for element, as the two launches it replaces.
+__global__ __launch_bounds__(256) void finish_opt_k(const float *__restrict__ slabs, const int *__restrict__ slab_table,
+                                                    int n_items, const int *__restrict__ item_seg,
+                                                    double *__restrict__ sums, double *__restrict__ reds,
+                                                    float *__restrict__ state, const int *__restrict__ bn_table, int n_bn,
+                                                    const int *__restrict__ bn_opt, float decay, int n_img,
+                                                    double *__restrict__ sums_keep, const OptP o,
+                                                    const int *__restrict__ plain_seg) {
+    __shared__ float wl[2048];
+    __shared__ float gl[MPNN_SLAB_ITEM];
+    const int b = blockIdx.x;
+    if (b < n_items) {
+        slab_item(slabs, const_cast<float *>(o.grads), slab_table + b * 6, gl);
+        __syncthreads();
+        opt_seg(o, item_seg + b * MPNN_SEG_INTS, gl, wl);
+    } else if (b < n_items + n_bn) {
+        const int k = b - n_items;
+        const int node = bn_opt[k * 4];
+        const float l2g = __int_as_float(bn_opt[k * 4 + 1]), l2b = __int_as_float(bn_opt[k * 4 + 2]);
+        float scale, pbar;
+        opt_node(o, node, 0, scale, pbar);
+        bn_finalize_body(sums, reds, state, const_cast<float *>(o.grads), bn_table + k * 8, decay, n_img, sums_keep,
+                         [&](int off_b, float db, int off_g, float dg) {
+                             opt_elem(o, off_b, db, l2b, scale, pbar);
+                             opt_elem(o, off_g, dg, l2g, scale, pbar);
+                         });
+    } else {
+        opt_seg(o, plain_seg + (b - n_items - n_bn) * MPNN_SEG_INTS, nullptr, wl);
+    }
+}
+
+extern "C" int mpnn_backward_finish_opt(const float *slabs, const int *slab_table, int n_items, const int *item_seg,
+                                        double *sums, double *reds, float *state, const int *bn_table, int n_bn,
+                                        const int *bn_opt, float decay, int n_img, double *sums_keep,
+                                        float *params, float *accum, float *grads, const float *node_stat,
+                                        const float *hyp, int talr, float inv_n, float grad_scale, const float *w_eq,
+                                        float *packs, const int *plain_seg, int n_plain, void *stream) {
+    if (n_items < 0 || n_bn < 0 || n_plain < 0) return MPNN_E_ARG;
+    if (n_items + n_bn + n_plain == 0) return 0;
+    if ((n_items && (!slabs || !slab_table || !item_seg)) || (n_bn && (!bn_table || !bn_opt)) || (n_plain && !plain_seg) ||
+        !params || !accum || !grads || !node_stat || !hyp) return MPNN_E_ARG;
+    const OptP o = {params, accum, grads, node_stat, hyp, talr, inv_n, grad_scale, w_eq, packs};
+    hipLaunchKernelGGL(finish_opt_k, dim3(n_items + n_bn + n_plain), dim3(256), 0, (hipStream_t)stream, slabs, slab_table,
+                       n_items, item_seg, sums, reds, state, bn_table, n_bn, bn_opt, decay, n_img, sums_keep, o, plain_seg);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

@@ -112,6 +112,8 @@ class Engine:
         self.dp_bucket_opt = bool(int(os.environ.get('MPNN_DP_BUCKET_OPT', '0')))
         self._opt_stream = None
         self.prologue = None             # callable(stream): first launch of every training step (the input pipeline)
+        # single process: the launch that ends the backward pass also applies the update (mpnn_backward_finish_opt)
+        self.fuse_opt = bool(int(os.environ.get('MPNN_FUSE_OPT', '1')))
         self._keep = []
         self._progs = {}
         self._graphs = {}
@@ -356,13 +358,18 @@ class Engine:
         self.pack_desc = torch.tensor(desc, dtype=torch.int32, device=dev)
         # `res` layers (layer_types.py:46,52,65-72): L2 pulls towards w_eq, the identity part of the init
         seg, eqs, eq_off = [], [], 0
+        self._seg_owner = []                                # parameter of every optimizer work item
+        self._opt_info = {}                                 # id(p) -> (l2 bits, w_eq offset | -1, pack fields)
+
         for p in self.trainable:
             l2 = np.float32(p.l2).view(np.int32)
             has_eq = bool(p.l2) and p.eq is not None
             pk = pack_of.get(id(p), (0, 0, 0, -1, -1))     # conv weights: the optimizer also refreshes their packs
+            self._opt_info[id(p)] = (int(l2), eq_off if has_eq else -1, pk)
             for s in range(0, p.size, OPT_CHUNK):
                 seg += [p.offset + s, min(OPT_CHUNK, p.size - s), p.node, p.is_router, int(l2), eq_off + s if has_eq else -1,
                         pk[0], pk[1], pk[2], pk[3], pk[4], 0]
+                self._seg_owner.append(id(p))
             if has_eq:
                 eqs.append(np.asarray(p.eq, np.float32).reshape(-1))
                 eq_off += p.size
@@ -718,7 +725,7 @@ class Engine:
             raise NotImplementedError('data-parallel training runs on the single-stream schedule (MPNN_STREAMS=0)')
         dp = mode == 'tr' and self.allreduce is not None
         reserve = self.dp_reserve_cus if (dp and len(self.dp_buckets) > 1) else 0
-        key = (mode, n, self.multi_stream, self.group_fwd, routed, dp, self.bwd_levels, self.fold_clear, reserve)
+        key = (mode, n, self.multi_stream, self.group_fwd, routed, dp, self.bwd_levels, self.fold_clear, reserve, self.fuse_opt)
         if key in self._progs:
             return self._progs[key]
         self._ensure_capacity(n, mode == 'tr')
@@ -940,7 +947,8 @@ class Engine:
         lib.mpnn_set_reserved_cus(reserve)           # (program() resets it)
         bwd.append(marker('fork'))
         dz_written = set()
-        slab_members = []                                   # (is_cut_block, table rows, [(args, field, offset)])
+        slab_members = []                                   # (is_cut_block, table rows, [(args, field, offset)], optimizer rows)
+        slab_params = set()                                 # parameters whose gradient comes out of a slab reduction
         use_levels = self.bwd_levels and not self.multi_stream
         cut_kb = self.dp_cut_block if dp else None
 
@@ -1024,16 +1032,25 @@ class Engine:
                     stride = (sum(sizes) + 3) // 4 * 4
                     off = slab_plan['size']
                     slab_plan['size'] += split * stride
-                    rows, ptrs = [], []
+                    rows, ptrs, srows = [], [], []
                     for prm, sz in zip((pa, pv, pb), sizes):
                         if prm is None:
                             continue
                         item = _hip.slab_item_size(split)
+                        l2b, eqo, pk = self._opt_info[id(prm)]
+                        if pk[1] and pk[1] % 4 == 0:
+                            # a weight tensor [9 * Cin][Cout]: items of whole 4-row groups, so that the update applied by
+                            # the item's workgroup (mpnn_backward_finish_opt) can write the weight packs as contiguous runs
+                            item = min(_hip.SLAB_ITEM, max(item, 4 * pk[2]))
                         for k in range(0, sz, item):
-                            rows += [off + k, prm.offset + k, min(item, sz - k), split, stride, 0]
+                            cnt = min(item, sz - k)
+                            rows += [off + k, prm.offset + k, cnt, split, stride, 0]
+                            srows += [prm.offset + k, cnt, prm.node, prm.is_router, l2b, eqo + k if eqo >= 0 else -1,
+                                      pk[0], pk[1], pk[2], pk[3], pk[4], 0]
+                        slab_params.add(id(prm))
                         ptrs.append((a, {id(pa): 'dwa', id(pb): 'db'}.get(id(prm), 'dwv'), off))
                         off += sz
-                    slab_members.append((cut_kb is not None and kb <= cut_kb, rows, ptrs))
+                    slab_members.append((cut_kb is not None and kb <= cut_kb, rows, ptrs, srows))
                     a.split_stride = stride
                 keep.append(a)
                 return a
@@ -1092,7 +1109,7 @@ class Engine:
                     bwd.append(call(lib.mpnn_msconv_bwd_level, 'bwd_scale', mem, len(built), dev_rec.data_ptr(),
                                     flops=sum(x[4] for x in built), tag=' | '.join(x[5] for x in built)))
                 if last_cut is not None and g == last_cut:
-                    if any(c for c, _, _ in slab_members):
+                    if any(m[0] for m in slab_members):
                         mid_pos = len(bwd)
                         bwd.append(None)                      # mpnn_slab_reduce of the cut blocks' items (filled in below)
                     bwd.append(marker('bucket', 'mid'))
@@ -1117,11 +1134,12 @@ class Engine:
         keep_ptr = self.dsum_last.data_ptr() if fold else None
         if slab_plan['size']:
             slab = torch.empty(slab_plan['size'], device=self.dev)
-            rows, first = [], 0
+            rows, srows, first = [], [], 0
             for want_cut in (True, False):                  # the cut blocks' items first: the 'mid' reduction takes a prefix
-                for is_cut, r, ptrs in slab_members:
+                for is_cut, r, ptrs, sr in slab_members:
                     if is_cut == want_cut:
                         rows += r
+                        srows += sr
                         for a, field, off in ptrs:
                             setattr(a, field, slab[off:].data_ptr())
                 if want_cut:
@@ -1137,10 +1155,36 @@ class Engine:
                                     tab.data_ptr(), first)
             else:
                 first = 0
-            # slab reduction + BatchNorm finalisation (moving averages, dgamma/dbeta): one launch
-            bwd.append(call(lib.mpnn_backward_finish, 'backward_finish', slab.data_ptr(), self.G.data_ptr(),
-                            tab[6 * first:].data_ptr(), n_items - first, self.dsum.data_ptr(), self.dred.data_ptr(),
-                            self.S.data_ptr(), self.bn_table.data_ptr(), self.n_bn, self.bn_decay, n, keep_ptr))
+            if not dp and self.fuse_opt and not self.multi_stream:
+                # single process: slab reduction + BatchNorm finalisation + the TALR / momentum update of EVERY parameter
+                # as one launch -- each workgroup updates the elements whose gradient it has just produced; the
+                # parameters whose gradients were final before (exits; tensors written without slabs) get workgroups
+                # of their own
+                bn_opt, fused_bn = [], set()
+                for b in self.blocks:
+                    for i in range(b.L):
+                        bn = b.bns[i].params
+                        bn_opt += [b.node.idx, int(np.float32(bn.γ.l2).view(np.int32)), int(np.float32(bn.β.l2).view(np.int32)), 0]
+                        fused_bn |= {id(bn.γ), id(bn.β)}
+                segs = self.seg.cpu().numpy().reshape(-1, _hip.SEG_INTS)
+                plain = [segs[k] for k, pid in enumerate(self._seg_owner) if pid not in slab_params and pid not in fused_bn]
+                t_seg = torch.tensor(srows, dtype=torch.int32, device=self.dev)
+                t_bno = torch.tensor(bn_opt, dtype=torch.int32, device=self.dev)
+                t_plain = torch.from_numpy(np.concatenate(plain) if plain else np.zeros(_hip.SEG_INTS, np.int32)).to(self.dev)
+                keep += [t_seg, t_bno, t_plain]
+                talr = 1 if (self.net._net_kind != 'sr' and getattr(self.net.hypers, 'talr', False)) else 0
+                bwd.append(call(lib.mpnn_backward_finish_opt, 'backward_finish', slab.data_ptr(), tab.data_ptr(), n_items,
+                                t_seg.data_ptr(), self.dsum.data_ptr(), self.dred.data_ptr(), self.S.data_ptr(),
+                                self.bn_table.data_ptr(), self.n_bn, t_bno.data_ptr(), self.bn_decay, n, keep_ptr,
+                                self.P.data_ptr(), self.A.data_ptr(), self.G.data_ptr(), self.node_stat.data_ptr(),
+                                self.hyp.data_ptr(), talr, 1.0 / n, 1.0, self.w_eq.data_ptr() if self.w_eq is not None else None,
+                                self.packs.data_ptr(), t_plain.data_ptr(), len(plain)))
+                prog['fused_opt'] = True
+            else:
+                # slab reduction + BatchNorm finalisation (moving averages, dgamma/dbeta): one launch
+                bwd.append(call(lib.mpnn_backward_finish, 'backward_finish', slab.data_ptr(), self.G.data_ptr(),
+                                tab[6 * first:].data_ptr(), n_items - first, self.dsum.data_ptr(), self.dred.data_ptr(),
+                                self.S.data_ptr(), self.bn_table.data_ptr(), self.n_bn, self.bn_decay, n, keep_ptr))
         else:
             bwd.append(call(lib.mpnn_bn_finalize, 'bn_finalize', self.dsum.data_ptr(), self.dred.data_ptr(),
                             self.S.data_ptr(), self.G.data_ptr(), self.bn_table.data_ptr(), self.n_bn,
@@ -1604,7 +1648,7 @@ class Engine:
         """One step as eager launches (also what a whole-step hipGraph captures): everything up to the optimizer, then
         the optimizer -- unless the data-parallel step already applied every bucket behind its all-reduce."""
         self._phase_a(prog, train, n)
-        if train and not (self.allreduce is not None and self._bucket_opt_on()):
+        if train and not prog.get('fused_opt') and not (self.allreduce is not None and self._bucket_opt_on()):
             self._opt(n)
 
     def set_prologue(self, fn):
