@@ -88,7 +88,7 @@ class Engine:
         self.multi_stream = bool(int(os.environ.get('MPNN_STREAMS', '0')))
         self.group_fwd = bool(int(os.environ.get('MPNN_FWD_GROUP', '1')))   # wavefront-grouped forward launches
         self.bwd_levels = bool(int(os.environ.get('MPNN_BWD_LEVELS', '1')))  # one backward launch per dependency level
-        self.routed_min_batch = int(os.environ.get('MPNN_ROUTED_MIN_BATCH', '2048'))
+        self.routed_min_batch = int(os.environ.get('MPNN_ROUTED_MIN_BATCH', '1280'))
         self.fold_clear = bool(int(os.environ.get('MPNN_FOLD_CLEAR', '1')))  # no clearing launch in a training step
         self._acc_clean = False          # the step's accumulators (slot sums, TALR statistics, loss) are cleared
         self._streams = []
@@ -713,12 +713,30 @@ class Engine:
         finally:
             self.lib.mpnn_set_reserved_cus(0)      # (a data-parallel training program is built with a reservation in place)
 
+    def routed_prefix(self, n):
+        """Depth from which the routed evaluation gathers (>= 1; see _program_ev).  The blocks above it run on every
+        sample in wavefront-grouped launches: early blocks lose few samples, so routing them saves little work and
+        costs the block-serial schedule (one launch per scale, then the exit, per block) -- which is what made the
+        fully routed program slower than the dense one below ~2 000 samples (profiles/r04_eval_sweep.txt).
+        MPNN_ROUTED_PREFIX overrides the batch-size rule."""
+        env = os.environ.get('MPNN_ROUTED_PREFIX')
+        if env:
+            return max(1, int(env))
+        for lim, d0 in self._ROUTED_PREFIX:
+            if n >= lim:
+                return d0
+        return self._ROUTED_PREFIX[-1][1]
+    _ROUTED_PREFIX = ((6144, 1), (3072, 2), (1536, 3), (0, 4))
+
     def _program(self, mode, n, routed):
         # routed='auto': routed above ROUTED_MIN_BATCH samples, dense below (the routed schedule is block-serial --
         # 28 launches against 13 -- and only pays once the launches are throughput-bound; profiles/r03_eval_sweep.txt)
         if routed == 'auto':
             routed = n >= self.routed_min_batch
+        explicit = routed if (isinstance(routed, int) and not isinstance(routed, bool) and routed >= 1) else None
         routed = bool(routed) and mode != 'tr' and bool(self.switches) and self.net._net_kind != 'sr'
+        if routed:                                   # (an int >= 1: blocks of a smaller depth run on every sample)
+            routed = explicit if explicit is not None else self.routed_prefix(n)
         if mode == 'tr' and self.allreduce is not None and self.multi_stream:
             # one section would fork and re-join the same side streams twice inside one capture (ROCm 7.2 crashes in
             # hipStreamEndCapture), and the DAG schedule has no bucket boundaries to overlap the collectives with
@@ -1235,6 +1253,10 @@ class Engine:
         depth = {}
         for b in self.blocks:
             depth[id(b)] = 0 if b.parent is None else depth[id(b.parent)] + 1
+        # routed = d0 >= 1: the CONVS of blocks with depth < d0 run on every sample (wavefront groups, like the dense
+        # program); from depth d0 on a block's convs gather through its sample list.  Every EXIT runs on its block's list
+        # (so that r / c_err / d_cor are only written where a sample reaches the node), whatever the depth.
+        d0 = int(routed)
         # sample lists: a block below a dynamic switch owns one; below a static node it shares its parent's
         for b in self.blocks:
             par = b.parent
@@ -1244,6 +1266,7 @@ class Engine:
                 b.ev_list = (b.ev_idx, b.ev_cnt)
             else:
                 b.ev_list = par.ev_list
+            b.ev_conv_list = b.ev_list if (routed and depth[id(b)] >= d0) else None
 
         def fwd_args(b, i, a):
             cp = b.conv.params
@@ -1259,8 +1282,8 @@ class Engine:
             a.out_sum = None
             a.out_nslot = self._nslot(b, i)
             a.n, a.H, a.W, a.Cout = n, b.H[i], b.W[i], b.C[i]
-            if b.ev_list is not None:
-                a.idx, a.cnt = b.ev_list[0].data_ptr(), b.ev_list[1].data_ptr()
+            if b.ev_conv_list is not None:
+                a.idx, a.cnt = b.ev_conv_list[0].data_ptr(), b.ev_conv_list[1].data_ptr()
 
         fl_f = lambda b, i: 2.0 * n * b.H[i] * b.W[i] * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
         tag_f = lambda b, i: 'h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])
@@ -1315,37 +1338,42 @@ class Engine:
             _hip.check(lib.mpnn_exit_ev_check(C.byref(e)), 'exit_ev record')
             recs[id(b)] = e
 
-        if not routed:
-            kidx = {h: k for k, h in enumerate(sorted({h for b in self.blocks for h in b.H}, reverse=True))}
+        kidx = {h: k for k, h in enumerate(sorted({h for b in self.blocks for h in b.H}, reverse=True))}
+
+        def wavefront(blocks):
             levels = {}
-            for b in self.blocks:
+            for b in blocks:
                 for i in range(b.L):
                     levels.setdefault(depth[id(b)] + kidx[b.H[i]], []).append((b, i))
             for d in sorted(levels):
                 group_launches(levels[d])
-            order = [recs[id(b)] for b in self.blocks if id(b) in recs]
+
+        def exits_of(blocks):
+            order = [recs[id(b)] for b in blocks if id(b) in recs]
             if order:
                 tab = _hip.to_device_table(order, self.dev)
                 keep.append(tab)
                 fwd.append(call(lib.mpnn_exit_ev, 'exit_ev', tab.data_ptr(), len(order), n))
+
+        if not routed:
+            wavefront(self.blocks)
+            exits_of(self.blocks)
         else:
             by_depth = {}
             for b in self.blocks:
                 by_depth.setdefault(depth[id(b)], []).append(b)
+            wavefront([b for b in self.blocks if depth[id(b)] < d0])
             for d in sorted(by_depth):
                 bs = by_depth[d]
-                for i in range(max(b.L for b in bs)):
-                    members = [(b, i) for b in bs if i < b.L]
-                    # a launch holds members that all carry a list, or none (the root block: every sample)
-                    for with_list in (False, True):
-                        part = [(b, i) for b, i in members if (b.ev_list is not None) == with_list]
-                        if part:
-                            group_launches(part)
-                order = [recs[id(b)] for b in bs if id(b) in recs]
-                if order:
-                    tab = _hip.to_device_table(order, self.dev)
-                    keep.append(tab)
-                    fwd.append(call(lib.mpnn_exit_ev, 'exit_ev', tab.data_ptr(), len(order), n))
+                if d >= d0:
+                    for i in range(max(b.L for b in bs)):
+                        members = [(b, i) for b in bs if i < b.L]
+                        # a launch holds members that all carry a list, or none (the root block: every sample)
+                        for with_list in (False, True):
+                            part = [(b, i) for b, i in members if (b.ev_conv_list is not None) == with_list]
+                            if part:
+                                group_launches(part)
+                exits_of(bs)            # (the exits of one depth: their lists come from the depth above)
 
         ra = self._route_args(n, 'ev', self.loss_ev)
         fwd.append(call(lib.mpnn_route, 'route', C.byref(ra)))

@@ -147,9 +147,12 @@ class Net(metaclass=ABCMeta):
         """Forward pass + routing in evaluation mode ('ev': BatchNorm moving averages, hard routing);
         per-layer results are then readable as ``ℓ.p_ev``, ``ℓ.δ_cor`` ... device tensors.
 
-        routed='auto' picks the routed evaluation from 2 048 samples per launch on and the dense one below
-        (Engine.routed_min_batch); routed=True runs the ROUTED evaluation: every block only processes the samples its ancestors'
-        routers sent to it (sample lists compacted on the device, no host sync).  ``p_ev`` and every
+        routed='auto' picks the routed evaluation from 1 280 samples per launch on and the dense one below
+        (Engine.routed_min_batch); routed=True runs the ROUTED evaluation: a block only processes the samples its ancestors'
+        routers sent to it (sample lists compacted on the device, no host sync) -- from a depth the engine picks by
+        batch size (Engine.routed_prefix: the first blocks lose few samples, and below ~6 000 samples running their
+        convs on everybody in wavefront-grouped launches is faster than gathering); routed=<int d> sets that depth
+        (1: every block below the root gathers).  ``p_ev`` and every
         p_ev-weighted statistic (acc, moc, p_cor, p_inc, *_by_cls: all that the reference's figure
         scripts read) are identical to the dense pass; per-leaf ``c_err`` / ``δ_cor`` and ``router.x``
         are those of the dense pass where the sample reaches the node and 0 elsewhere."""

@@ -92,13 +92,22 @@ def snapshot(net):
     return out
 
 
-def check_routed_equals_dense(net, x0, y, feed_extra=None):
+def check_routed_equals_dense(net, x0, y, feed_extra=None, modes=(True, 1, 3)):
+    """modes: routed=True (the engine picks the depth from which blocks gather by batch size), 1 (every block below the
+    root gathers: the work-minimal program), 3 (the convs of blocks 0-2 run on every sample, deeper blocks gather)."""
+    dense = None
+    for mode in modes:
+        dense = _check_routed_equals_dense(net, x0, y, feed_extra, mode)
+    return dense
+
+
+def _check_routed_equals_dense(net, x0, y, feed_extra, mode):
     eng = net.engine()
     feed = {net.x0: x0, net.y: y, **(feed_extra or {})}
     net.eval(feed)
     torch.cuda.synchronize()
     dense = snapshot(net)
-    net.eval(feed, routed=True)
+    net.eval(feed, routed=mode)
     torch.cuda.synchronize()
     routed = snapshot(net)
     parent_leaf = {nd.idx: nd.parent for nd in eng.leaves}
@@ -162,7 +171,7 @@ def test_all_exit_0_at_initialisation():
         for t in b.s:
             t.fill_(float('nan'))
     dense_feed = {net.x0: x0, net.y: y}
-    net.eval(dense_feed, routed=True)
+    net.eval(dense_feed, routed=1)           # (every block below the root gathers: nothing else may run)
     torch.cuda.synchronize()
     hist = [float(nd.layer.p_ev.mean()) for nd in eng.leaves]
     assert hist == [1.0] + [0.0] * 7

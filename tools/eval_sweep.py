@@ -18,6 +18,16 @@ for nb in [int(a) for a in sys.argv[1:]] or [1024, 4096, 8192]:
     feed = {net.x0: eng.x0[:nb], net.y: eng.y[:nb]}
     bench.set_exit_fractions(net, feed, nb, [1 / 8] * 7)
     res = {}
+    if os.environ.get('PREFIX_SWEEP'):
+        # routed evaluation with the convs of the blocks above depth d0 run on every sample (lib/_plan.py:_program_ev)
+        line = []
+        for d0 in (False, 1, 2, 3, 4, 5, 6):
+            for _ in range(3): net.eval(feed, routed=d0)
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(20): net.eval(feed, routed=d0)
+            torch.cuda.synchronize(); line.append((d0, (time.perf_counter() - t) / 20 * 1e3))
+        print('batch %6d: ' % nb + '  '.join('%s %.3f' % ('dense' if d0 is False else 'd0=%d' % d0, t) for d0, t in line) + '  (ms)', flush=True)
+        continue
     for routed in (False, True, 'auto'):
         for _ in range(3): net.eval(feed, routed=routed)
         torch.cuda.synchronize(); t = time.perf_counter()
