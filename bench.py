@@ -352,14 +352,11 @@ def main():
         # per-branch compaction, lib/_plan.py:_program_ev) on a statistics-pass-sized batch with the
         # router biases set so that 1/8 of the batch leaves at each of the 8 exits.
         def time_eval(feed_, routed, reps):
-            for _ in range(3):
+            # (median over HIP-event-timed chunks: one hiccup of the host must not colour a 20-call mean)
+            for _ in range(4):
                 net.eval(feed_, routed=routed)
             torch.cuda.synchronize()
-            t_ = time.perf_counter()
-            for _ in range(reps):
-                net.eval(feed_, routed=routed)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t_) / reps * 1e3
+            return time_replays(lambda: net.eval(feed_, routed=routed), reps, chunk=5)
         ev_feed = {net.x0: eng.x0[:n], net.y: eng.y[:n]}
         ev_ms = time_eval(ev_feed, False, 100)
         leaves = [nd.layer for nd in eng.leaves]

@@ -536,6 +536,18 @@ int mpnn_msconv_bwd_scale_slots(int H, int W, int Cout, int has_dgrad, int has_v
  * kind, slot 7 = units; slots 8-10: first unit's MFMAs done, next unit staged, epilogue done).  tools/trace_phases.py prints the timeline.  Synchronises the device. */
 int mpnn_debug_set_trace(unsigned long long *buf);
 
+/* ---- MaxPool / GlobalMaxPool of the single-scale layer family (scripts/lib/layer_types.py:86-100; no shipped spec
+ * uses them) on NHWC fp32 maps.  MaxPool: tf.nn.max_pool(..., 'SAME') with window `win` and step `step` -- the
+ * reference passes its hypers as (strides, k_shape), i.e. window = hypers.stride, step = hypers.supp (:90-94);
+ * out = ceil(H / step) x ceil(W / step); backward: each window's gradient goes to its FIRST maximum in row-major order,
+ * overlapping windows add (a gather per input element: no atomics).  global != 0: tf.reduce_max over H x W ->
+ * y [n][C], cnt [n][C] = number of maxima (forward output), backward dx = [x == y] * dy / cnt.  The caller pools
+ * PRE-activation maps (max-pool commutes with the ReLU its consumers apply on load). */
+int mpnn_maxpool_fwd(const float *x, float *y, float *cnt, int n, int H, int W, int C, int win, int step,
+                     int global, void *stream);
+int mpnn_maxpool_bwd(const float *x, const float *y, const float *cnt, const float *dy, float *dx, int n, int H,
+                     int W, int C, int win, int step, int global, void *stream);
+
 /* Host function (no device work, no stream): the augmentation draws of scripts/lib/data.py:24-34 -- per sample
  * randint(0, n_src); rand() < 0.5 if sym[j] (sym == NULL: every class is symmetric); randint(-r_shift, r_shift + 1, 2)
  * -- replayed over consecutive 32-bit outputs of numpy's legacy MT19937 stream with numpy's own bounded-integer and

@@ -180,6 +180,8 @@ _SIGS = {
     'mpnn_conv_nhwc_wgrad': [C.POINTER(ConvNhwcWgradArgs), P],
     'mpnn_backward_finish_opt': [P, P, C.c_int, P, P, P, P, P, C.c_int, P, C.c_float, C.c_int, P, P, P, P, P, P, C.c_int,
                                  C.c_float, C.c_float, P, P, P, C.c_int, P],
+    'mpnn_maxpool_fwd': [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P],
+    'mpnn_maxpool_bwd': [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P],
     'mpnn_set_reserved_cus': [C.c_int],
     'mpnn_debug_spin': [C.c_int, C.c_int, C.c_float, P],
     'mpnn_debug_noop': [P],

@@ -4,7 +4,9 @@ The shipped specs never instantiate ``Conv`` (scripts/lib/layer_types.py:55-74),
 the operator surface north_star names ("3x3 / 1x1 contractions").  This engine runs the nets one
 can build from it with the reference's protocol -- a statically-routed net whose root is a chain of
 ``Conv`` layers (supp 3 or 1, optional ``res`` identity initialisation), each optionally followed by
-``Rect``, with a ``LinTrans -> Softmax -> CrossEntropyError`` leaf::
+``Rect``, optionally interleaved with ``MaxPool`` / ``GlobalMaxPool`` (layer_types.py:86-100: max-pooling commutes with
+the ReLU the consumers apply on load, so the engine pools the stored pre-activation maps -- csrc/pool.hip), with a
+``LinTrans -> Softmax -> CrossEntropyError`` leaf::
 
     SRNet(x0_shape=.., y_shape=.., root=Chain(comps=[Conv(n_chan=16, supp=3), Rect(),
                                                      Conv(n_chan=32, supp=1, res=False), Rect()],
@@ -34,7 +36,7 @@ def is_conv_net(net):
     if net._net_kind != 'sr' or not isinstance(root, Chain) or len(root.sinks) != 1 or not root.comps:
         return False
     names = [type(c).__name__ for c in root.comps]
-    if names[0] != 'Conv' or any(n not in ('Conv', 'Rect') for n in names):
+    if names[0] != 'Conv' or any(n not in ('Conv', 'Rect', 'MaxPool', 'GlobalMaxPool') for n in names):
         return False
     if any(a == 'Rect' and b == 'Rect' for a, b in zip(names, names[1:])):
         return False
@@ -59,22 +61,44 @@ class ConvEngine:
         root, head = net.root, net.root.sinks[0]
         self.x0_shape = tuple(net.hypers.x0_shape)
         self.n_cls = int(net.hypers.y_shape[0])
-        # conv stages: (layer, followed by Rect?)
+        # stages: every Conv / MaxPool / GlobalMaxPool of the chain produces a stored map; a Rect only marks the map in
+        # front of it as "ReLU on load" (pooling keeps the mark: max-pool and ReLU commute).
+        # stage = (layer, relu_on_load_of_its_output, kind, (H_in, W_in), (H_out, W_out))
         self.stages = []
-        for k, c in enumerate(root.comps):
-            if type(c).__name__ == 'Conv':
-                nxt = root.comps[k + 1] if k + 1 < len(root.comps) else None
-                self.stages.append((c, type(nxt).__name__ == 'Rect'))
-        for c, _ in self.stages:
-            if c.hypers.supp not in (1, 3):
-                raise NotImplementedError('Conv supp %r: the kernels cover 3x3 and 1x1' % (c.hypers.supp,))
-            if c.hypers.supp == 3 and (c.params.w.shape[3] % 16 or (c.params.w.shape[2] > 4 and c.params.w.shape[2] % 4)):
-                raise NotImplementedError('3x3 Conv needs a multiple of 16 output channels (and of 4 input channels beyond an image)')
         h, w = self.x0_shape[:2]
-        if h != w or h not in (4, 8) and (w % 16 or h % 4):
-            raise NotImplementedError('maps of %dx%d: the 3x3 body covers 4x4, 8x8 and W %% 16 == 0' % (h, w))
-        self.H, self.W = h, w
-        self.C = [self.x0_shape[2]] + [c.hypers.n_chan for c, _ in self.stages]
+        self.C = [self.x0_shape[2]]
+        relu = False
+        for c in root.comps:
+            kind = type(c).__name__
+            if kind == 'Rect':
+                relu = True
+                if self.stages:
+                    st = self.stages[-1]
+                    self.stages[-1] = (st[0], True) + st[2:]
+                continue
+            if kind == 'Conv':
+                relu = False
+                if c.hypers.supp not in (1, 3):
+                    raise NotImplementedError('Conv supp %r: the kernels cover 3x3 and 1x1' % (c.hypers.supp,))
+                if c.hypers.supp == 3 and (c.params.w.shape[3] % 16 or (c.params.w.shape[2] > 4 and c.params.w.shape[2] % 4)):
+                    raise NotImplementedError('3x3 Conv needs a multiple of 16 output channels (and of 4 input channels beyond an image)')
+                if c.hypers.supp == 3 and (h != w or h not in (4, 8) and (w % 16 or h % 4)):
+                    raise NotImplementedError('3x3 Conv on a %dx%d map: the body covers 4x4, 8x8 and W %% 16 == 0' % (h, w))
+                self.stages.append((c, False, 'conv', (h, w), (h, w)))
+                self.C.append(c.hypers.n_chan)
+            else:
+                if kind == 'MaxPool':
+                    # the reference calls tf.nn.max_pool(x, strides, k_shape, 'SAME') -- hypers in the order (strides,
+                    # k_shape) where TensorFlow expects (ksize, strides): the WINDOW is hypers.stride, the STEP hypers.supp
+                    win, step = int(c.hypers.stride), int(c.hypers.supp)
+                    ho, wo = -(-h // step), -(-w // step)
+                else:
+                    win = step = 0
+                    ho = wo = 1
+                self.stages.append((c, relu, 'gpool' if kind == 'GlobalMaxPool' else 'pool', (h, w), (ho, wo), win, step))
+                self.C.append(self.C[-1])
+                h, w = ho, wo
+        self.H, self.W = h, w                      # the map the head reads
         K = h * w * self.C[-1]
         if self.C[-1] > 128 or K % 16 or self.n_cls > 16:
             raise NotImplementedError('head on a %dx%dx%d map / %d classes: outside the exit kernels\' limits' % (h, w, self.C[-1], self.n_cls))
@@ -138,8 +162,9 @@ class ConvEngine:
         # weight packs of the 3x3 stages
         desc, poff = [], 0
         self.pack = {}
-        for k, (c, _) in enumerate(self.stages):
-            if c.hypers.supp == 3:
+        for k, st_ in enumerate(self.stages):
+            c = st_[0]
+            if st_[2] == 'conv' and c.hypers.supp == 3:
                 ci, co = c.params.w.shape[2], c.params.w.shape[3]
                 fs = 9 * ((ci + 15) // 16) * 16 * co
                 bs = 9 * ((co + 15) // 16) * 16 * ci if ci % 16 == 0 else 0
@@ -173,15 +198,18 @@ class ConvEngine:
         self.n_max = n
         z = lambda *s: torch.zeros(s, device=self.dev)
         self.x0, self.y = z(n, *self.x0_shape), z(n, self.n_cls)
-        self.out = [z(n, self.H, self.W, c) for c in self.C[1:]]          # pre-activation map of every stage
-        self.g = [z(n, self.H, self.W, c) for c in self.C[1:]]            # gradient w.r.t. it
+        self.out = [z(n, st[4][0], st[4][1], c) for st, c in zip(self.stages, self.C[1:])]     # pre-activation map of every stage
+        self.g = [z(n, st[4][0], st[4][1], c) for st, c in zip(self.stages, self.C[1:])]       # gradient w.r.t. it
+        self.gcnt = {k: z(n, self.C[k + 1]) for k, st in enumerate(self.stages) if st[2] == 'gpool'}   # maxima per (sample, channel)
         self.z, self.dz = z(n, self.n_cls), z(n, self.n_cls)
         self.c_err, self.d_cor, self.w_cerr = z(n), z(n), z(n)
         self.p_tr, self.p_ev = z(2 * n), z(2 * n)
         self.r, self.dr = z(2 * n), z(2 * n)
-        tiles = self.lib.mpnn_wgrad_tiles(n, self.H, self.W)
-        self.n_split = max(1, min(64, tiles))
-        self.slab = z(self.n_split * max(p.size for p in self.trainable) * 2 + 1024)
+        self.n_split = {}
+        for k, st in enumerate(self.stages):
+            if st[2] == 'conv' and st[0].hypers.supp == 3:
+                self.n_split[k] = max(1, min(64, self.lib.mpnn_wgrad_tiles(n, st[3][0], st[3][1])))
+        self.slab = z(max(list(self.n_split.values()) + [1]) * max(p.size for p in self.trainable) * 2 + 1024)
 
     # ------------------------------------------------------------------ running
     def _act(self, k):
@@ -220,13 +248,21 @@ class ConvEngine:
             z.zero_()
         HW = self.H * self.W
         # ---- forward ----
-        for k, (c, _) in enumerate(self.stages):
-            a = _hip.ConvNhwcFwdArgs()
-            a.a = self._act(k)
-            a.w = self.packs[self.pack[k][0]:].data_ptr() if c.hypers.supp == 3 else c.params.w.data.data_ptr()
-            a.bias, a.out = c.params.b.data.data_ptr(), self.out[k].data_ptr()
-            a.n, a.H, a.W, a.Cout, a.supp = n, self.H, self.W, self.C[k + 1], c.hypers.supp
-            self._chk(lib.mpnn_conv_nhwc_fwd(C.byref(a), st), 'conv_nhwc_fwd')
+        for k, st_ in enumerate(self.stages):
+            c, kind, (hi, wi) = st_[0], st_[2], st_[3]
+            if kind == 'conv':
+                a = _hip.ConvNhwcFwdArgs()
+                a.a = self._act(k)
+                a.w = self.packs[self.pack[k][0]:].data_ptr() if c.hypers.supp == 3 else c.params.w.data.data_ptr()
+                a.bias, a.out = c.params.b.data.data_ptr(), self.out[k].data_ptr()
+                a.n, a.H, a.W, a.Cout, a.supp = n, hi, wi, self.C[k + 1], c.hypers.supp
+                self._chk(lib.mpnn_conv_nhwc_fwd(C.byref(a), st), 'conv_nhwc_fwd')
+            else:                                  # MaxPool / GlobalMaxPool of the stored pre-activation map
+                src = self.x0 if k == 0 else self.out[k - 1]
+                cnt = self.gcnt[k].data_ptr() if kind == 'gpool' else None
+                self._chk(lib.mpnn_maxpool_fwd(src.data_ptr(), self.out[k].data_ptr(), cnt, n, hi, wi, self.C[k],
+                                               st_[5] if kind == 'pool' else 0, st_[6] if kind == 'pool' else 0,
+                                               1 if kind == 'gpool' else 0, st), 'maxpool_fwd')
         lt, ce = self.head.comps[0], self.head.comps[2]
         a_head = self._act(len(self.stages))
         if train:
@@ -283,13 +319,23 @@ class ConvEngine:
         self._chk(lib.mpnn_exit_tail_bwd(t_tb.data_ptr(), 1, n, st), 'exit_tail_bwd')
         self._chk(lib.mpnn_lin_bwd(t_lb.data_ptr(), 1, n, HW * self.C[-1], st), 'lin_bwd')
         for k in range(last, -1, -1):
-            c, _ = self.stages[k]
+            st_ = self.stages[k]
+            c, kind, (hi, wi) = st_[0], st_[2], st_[3]
+            if kind != 'conv':
+                if k == 0:
+                    break
+                cnt = self.gcnt[k].data_ptr() if kind == 'gpool' else None
+                self._chk(lib.mpnn_maxpool_bwd(self.out[k - 1].data_ptr(), self.out[k].data_ptr(), cnt, self.g[k].data_ptr(),
+                                               self.g[k - 1].data_ptr(), n, hi, wi, self.C[k],
+                                               st_[5] if kind == 'pool' else 0, st_[6] if kind == 'pool' else 0,
+                                               1 if kind == 'gpool' else 0, st), 'maxpool_bwd')
+                continue
             supp = c.hypers.supp
             w = _hip.ConvNhwcWgradArgs()
             w.a, w.g = self._act(k), self.g[k].data_ptr()
-            w.n, w.H, w.W, w.Cout, w.supp = n, self.H, self.W, self.C[k + 1], supp
+            w.n, w.H, w.W, w.Cout, w.supp = n, hi, wi, self.C[k + 1], supp
             pw, pb = c.params.w, c.params.b
-            split = self.n_split if supp == 3 else 1
+            split = self.n_split[k] if supp == 3 else 1
             if supp == 3 and split > 1:
                 stride = (pw.size + pb.size + 3) // 4 * 4
                 w.dw, w.db = self.slab.data_ptr(), self.slab[pw.size:].data_ptr()
@@ -315,7 +361,7 @@ class ConvEngine:
             if self.stages[k - 1][1]:
                 d.relu_src, d.scratch = self.out[k - 1].data_ptr(), self.scratch.data_ptr()
             d.dx = self.g[k - 1].data_ptr()
-            d.n, d.H, d.W, d.Cin, d.supp = n, self.H, self.W, self.C[k], supp
+            d.n, d.H, d.W, d.Cin, d.supp = n, hi, wi, self.C[k], supp
             if supp == 3 and self.pack[k][1] is None:
                 raise NotImplementedError('3x3 Conv above the first stage needs a multiple of 16 input channels')
             self._chk(lib.mpnn_conv_nhwc_dgrad(C.byref(d), st), 'conv_nhwc_dgrad')

@@ -202,18 +202,23 @@ class Softmax(Layer):
 
 
 class MaxPool(Layer):
-    """Reference: layer_types.py:86-94 (unused by every shipped spec)."""
+    """Reference: layer_types.py:86-94 (unused by every shipped spec).  The reference calls
+    ``tf.nn.max_pool(x, strides, k_shape, 'SAME')`` where TensorFlow's signature is ``(value, ksize, strides,
+    padding)``: its window is ``hypers.stride`` and its step ``hypers.supp``.  Kept, so that the same spec gives the
+    same shapes: the output is ceil(H / supp) x ceil(W / supp).  Runs in a single-scale Conv chain (lib/_plan_conv.py,
+    csrc/pool.hip)."""
     default_hypers = Ns(stride=1, supp=1)
 
     def link(self, x, y, mode):
         super().link(x, y, mode)
         h, w, c = _shape(x)
-        s = self.hypers.stride
+        s = self.hypers.supp
         self.x = Sym((-(-h // s), -(-w // s), c), self)
 
 
 class GlobalMaxPool(Layer):
-    """Reference: layer_types.py:96-100 (unused by every shipped spec)."""
+    """Reference: layer_types.py:96-100 (unused by every shipped spec): tf.reduce_max over the spatial dims.  Runs in a
+    single-scale Conv chain (lib/_plan_conv.py, csrc/pool.hip)."""
 
     def link(self, x, y, mode):
         super().link(x, y, mode)

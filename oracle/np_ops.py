@@ -231,3 +231,41 @@ def shift_fill_mean(a, du, dv):
     ub = slice(max(-du, 0), min(h - du, h)); vb = slice(max(-dv, 0), min(w - dv, w))
     b[ub, vb] = a[ua, va]
     return b
+
+
+def max_pool_same(x, win, step):
+    """tf.nn.max_pool(x, ksize=win, strides=step, 'SAME') on NHWC: (y, arg) with arg = flat index (iy * W + ix) of
+    the FIRST maximum of every window in row-major order (TensorFlow's CPU MaxPoolGrad routes the gradient there)."""
+    n, H, W, C = x.shape
+    ho, wo = -(-H // step), -(-W // step)
+    ty, tx = max((ho - 1) * step + win - H, 0), max((wo - 1) * step + win - W, 0)
+    py, px = ty // 2, tx // 2
+    y = np.full((n, ho, wo, C), -np.inf, x.dtype)
+    arg = np.zeros((n, ho, wo, C), np.int64)
+    for oy in range(ho):
+        for ox in range(wo):
+            for dy in range(win):
+                for dx in range(win):
+                    iy, ix = oy * step - py + dy, ox * step - px + dx
+                    if 0 <= iy < H and 0 <= ix < W:
+                        v = x[:, iy, ix, :]
+                        better = v > y[:, oy, ox, :]
+                        y[:, oy, ox, :] = np.where(better, v, y[:, oy, ox, :])
+                        arg[:, oy, ox, :] = np.where(better, iy * W + ix, arg[:, oy, ox, :])
+    return y, arg
+
+
+def max_pool_same_bwd(dy, arg, shape):
+    n, H, W, C = shape
+    dx = np.zeros((n, H * W, C), dy.dtype)
+    ni, ci = np.meshgrid(np.arange(n), np.arange(C), indexing='ij')
+    for oy in range(dy.shape[1]):
+        for ox in range(dy.shape[2]):
+            np.add.at(dx, (ni, arg[:, oy, ox, :], ci), dy[:, oy, ox, :])
+    return dx.reshape(shape)
+
+
+def global_max_pool(x):
+    """tf.reduce_max over H, W: (y, cnt) with cnt = number of maxima (the gradient is shared among them)."""
+    y = x.max(axis=(1, 2))
+    return y, (x == y[:, None, None, :]).sum(axis=(1, 2)).astype(x.dtype)

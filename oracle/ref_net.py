@@ -139,6 +139,18 @@ class RefNet:
         elif name == 'Rect':
             m = forced.get(('relu',) + self._at) if forced else None
             x = torch.relu(x) if m is None else x * torch.as_tensor(m, dtype=self.dtype)
+        elif name == 'MaxPool':                                # layer_types.py:86-94
+            # tf.nn.max_pool(x, strides, k_shape, 'SAME'): the reference hands its hypers over in this order, so
+            # TensorFlow's ksize is hypers.stride and its strides are hypers.supp.  SAME: out = ceil(H / step),
+            # pad_before = pad_total // 2, padded cells never win; gradient to the first maximum of a window.
+            win, step = int(ϕ.stride), int(ϕ.supp)
+            H, W = x.shape[1], x.shape[2]
+            ho, wo = -(-H // step), -(-W // step)
+            ty, tx = max((ho - 1) * step + win - H, 0), max((wo - 1) * step + win - W, 0)
+            xp = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (tx // 2, tx - tx // 2, ty // 2, ty - ty // 2), value=float('-inf'))
+            x = torch.nn.functional.max_pool2d(xp, win, step).permute(0, 2, 3, 1)
+        elif name == 'GlobalMaxPool':                          # layer_types.py:96-100: tf.reduce_max over H, W
+            x = x.amax(dim=(1, 2))                             # (ties share the gradient, as in TensorFlow)
         elif name == 'Select':
             x = x[ϕ.i]
         elif name == 'LinTrans':

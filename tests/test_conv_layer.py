@@ -176,3 +176,113 @@ def test_lintrans_res_is_accepted_by_the_chain_engine():
     g = w.grad.cpu().numpy().astype(np.float64) + 2 * 1e-2 * (v0 - np.asarray(w.eq, np.float64).reshape(-1))
     d = w.numpy().reshape(-1).astype(np.float64) - v0
     assert np.abs(d + 0.1 * g).max() <= 1e-6 * np.abs(d).max() + 1e-9
+
+
+@pytest.mark.parametrize('win,step', [(2, 2), (3, 2), (3, 1), (2, 3), (1, 1)])
+def test_maxpool_kernels_against_numpy(win, step):
+    """mpnn_maxpool_fwd / _bwd (layer_types.py:86-94) on a ragged 7 x 9 map with MANY ties (values quantised to
+    eighths): output and first-maximum gradient routing exact against oracle/np_ops.max_pool_same."""
+    lib = _hip.load()
+    rng = np.random.default_rng(win * 10 + step)
+    n, H, W, Cc = 5, 7, 9, 12
+    x = (np.round(rng.standard_normal((n, H, W, Cc)) * 8) / 8).astype(np.float32)
+    y_ref, arg = O.max_pool_same(x, win, step)
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = O.max_pool_same_bwd(dy.astype(np.float64), arg, x.shape)
+    xd, dyd = dev(x), dev(dy)
+    yd = torch.empty(y_ref.shape, device=DEV)
+    dxd = torch.empty(x.shape, device=DEV)
+    st = stream()
+    _hip.check(lib.mpnn_maxpool_fwd(xd.data_ptr(), yd.data_ptr(), None, n, H, W, Cc, win, step, 0, st), 'maxpool_fwd')
+    _hip.check(lib.mpnn_maxpool_bwd(xd.data_ptr(), yd.data_ptr(), None, dyd.data_ptr(), dxd.data_ptr(), n, H, W, Cc, win, step, 0, st), 'maxpool_bwd')
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), y_ref)
+    assert np.abs(dxd.cpu().numpy() - dx_ref).max() <= 1e-6 * (1 + np.abs(dx_ref).max())
+
+
+def test_global_maxpool_kernels_against_numpy():
+    """GlobalMaxPool (layer_types.py:96-100): tf.reduce_max over H x W; ties SHARE the gradient."""
+    lib = _hip.load()
+    rng = np.random.default_rng(3)
+    n, H, W, Cc = 6, 8, 8, 20
+    x = (np.round(rng.standard_normal((n, H, W, Cc)) * 4) / 4).astype(np.float32)
+    y_ref, cnt_ref = O.global_max_pool(x)
+    assert cnt_ref.max() > 1                       # the quantisation produced ties
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    dx_ref = (x == y_ref[:, None, None, :]) * (dy / cnt_ref)[:, None, None, :]
+    xd, dyd = dev(x), dev(dy)
+    yd, cd, dxd = torch.empty((n, Cc), device=DEV), torch.empty((n, Cc), device=DEV), torch.empty(x.shape, device=DEV)
+    st = stream()
+    _hip.check(lib.mpnn_maxpool_fwd(xd.data_ptr(), yd.data_ptr(), cd.data_ptr(), n, H, W, Cc, 0, 0, 1, st), 'maxpool_fwd')
+    _hip.check(lib.mpnn_maxpool_bwd(xd.data_ptr(), yd.data_ptr(), cd.data_ptr(), dyd.data_ptr(), dxd.data_ptr(), n, H, W, Cc, 0, 0, 1, st), 'maxpool_bwd')
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), y_ref) and np.array_equal(cd.cpu().numpy(), cnt_ref)
+    assert np.abs(dxd.cpu().numpy() - dx_ref).max() <= 1e-6
+
+
+def pooled_conv_net():
+    from lib.layer_types import Chain, Conv, CrossEntropyError, GlobalMaxPool, LinTrans, MaxPool, Rect, Softmax
+    from lib.net_types import SRNet
+
+    def make_net(x0_shape, y_shape):
+        head = Chain(name='LogReg', comps=[LinTrans(n_chan=y_shape[0], k_l2=1e-4), Softmax(), CrossEntropyError()])
+        # (MaxPool hypers as the reference interprets them: window = stride, step = supp -- layer_types.py:90-94)
+        root = Chain(name='ConvStack', sinks=[head], comps=[
+            Conv(n_chan=16, supp=3, k_l2=1e-4), Rect(), MaxPool(stride=2, supp=2),
+            Conv(n_chan=32, supp=3, k_l2=1e-4), MaxPool(stride=3, supp=2), Rect(),
+            Conv(n_chan=32, supp=1, k_l2=1e-4), Rect(), GlobalMaxPool()])
+        return SRNet(x0_shape=x0_shape, y_shape=y_shape, root=root)
+    return make_net
+
+
+def test_conv_net_with_pooling_layers_vs_oracle():
+    """A Chain that mixes Conv / Rect / MaxPool / GlobalMaxPool (the free composition of the single-scale layer
+    family, layer_types.py:55-100): 32x32 -> pool -> 16x16 -> overlapping pool -> 8x8 -> global.  Training steps
+    against the float64 oracle with the device's ReLU decisions; the pooling arg-maxes are left to both sides (a
+    near-tie that flips between fp32 and float64 would show as a large error: seeds are fixed)."""
+    from oracle.ref_net import RefNet
+    net = pooled_conv_net()((32, 32, 3), (10,))
+    eng = net.engine()
+    assert type(eng).__name__ == 'ConvEngine'
+    assert [tuple(o.shape[1:]) for o in eng.out] == [(32, 32, 16), (16, 16, 16), (16, 16, 32), (8, 8, 32), (8, 8, 32), (1, 1, 32)]
+    eng.init_params(6)
+    ref = RefNet(net)
+    n, lr = 16, 0.05
+    for t in range(2):
+        rng = np.random.default_rng(40 + t)
+        x0 = rng.random((n, 32, 32, 3)).astype(np.float32)
+        y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, n)]
+        ref.load_params()
+        for p in net._all_params:
+            ref.accum[id(p)] = torch.tensor(p.accum.cpu().numpy().astype(np.float64).reshape(p.shape))
+        before = {id(p): p.data.clone() for p in net._all_params}
+        net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: lr})
+        # ReLU decisions as the device took them: the sign of the stored map a Rect applies to
+        forced, k = {}, 0
+        for j, c in enumerate(net.root.comps):
+            if type(c).__name__ == 'Rect':
+                forced[('relu', id(net.root), j)] = (eng.out[k - 1][:n] > 0).cpu().numpy()
+            else:
+                k += 1
+        res_ = ref.train_step(x0, y, lr, forced=forced)
+        ce = res_['out'][id(net.root.sinks[0])]['c_err'].detach().numpy()
+        assert np.abs(net.root.sinks[0].c_err.cpu().numpy() - ce).max() < 2e-4 * (1 + np.abs(ce).max())
+        for p in net._all_params:
+            v0 = before[id(p)].cpu().numpy().astype(np.float64)
+            g_ref = res_['grads'][id(p)].numpy().reshape(-1)
+            gp = p.grad.cpu().numpy().astype(np.float64)
+            if p.l2:
+                gp = gp + 2 * p.l2 * v0
+            assert np.abs(gp - g_ref).max() <= 1e-4 * np.abs(g_ref).max() + 1e-6, ('grad', p.owner.name, p.name, t)
+            d = p.data.cpu().numpy().astype(np.float64) - v0
+            d_ref = ref.V(p).detach().numpy().reshape(-1) - v0
+            assert np.abs(d - d_ref).max() <= 1e-4 * np.abs(d_ref).max() + 1e-7, ('update', p.owner.name, p.name, t)
+    x0 = np.random.default_rng(9).random((70, 32, 32, 3)).astype(np.float32)
+    y = np.eye(10, dtype=np.float32)[np.random.default_rng(9).integers(0, 10, 70)]
+    net.eval({net.x0: x0, net.y: y})
+    ref.load_params()
+    r = ref.forward(x0, y, 'ev')
+    leaf = net.root.sinks[0]
+    ce = r['out'][id(leaf)]['c_err'].detach().numpy()
+    assert np.abs(leaf.c_err.cpu().numpy() - ce).max() < 2e-4 * (1 + np.abs(ce).max())
+    assert float(net.state()[(net, 'moc')].mean()) == net.root.n_ops + leaf.n_ops
