@@ -360,6 +360,10 @@ typedef struct {
      * A training step then needs no clearing launch (the BatchNorm slot sums are cleared by their last reader,
      * mpnn_backward_finish / mpnn_bn_finalize). */
     float *clear_f;  int n_clear_f;  double *clear_d;  int n_clear_d;
+    /* Width of the SECOND hidden layer (0: the same as R).  w2 is [R, R2], bias2 / g2 / b2 / m2 / v2 [R2], w3
+     * [R2, n_sinks], h2 [n, R2], bn_save [2 R + 2 R2] = m1, rstd1, m2, rstd2.  The tuned kernels need R2 == R <= 16
+     * and n_cls <= 16; the any-width forms below (mpnn_*_gen) take anything up to mpnn_exit_gen_check's limits. */
+    int R2;
 } mpnn_exit_tail_args;
 int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int count, int n_max,
                        void *stream);
@@ -403,9 +407,28 @@ typedef struct {
     float *r;  int r_stride;
     const int *idx;  const int *cnt;  int n;           /* this node's sample list / capacity */
     int *child_idx[MPNN_MAX_SINKS];  int *child_cnt[MPNN_MAX_SINKS];
+    int R2;                              /* width of the second hidden layer (0: R); see mpnn_exit_tail_args */
 } mpnn_exit_ev_args;
 int mpnn_exit_ev(const mpnn_exit_ev_args *dev_table, int count, int n_max, void *stream);
 int mpnn_exit_ev_check(const mpnn_exit_ev_args *host_record);
+
+/* ---- any-WIDTH forms of the exit path (csrc/exit_gen.hip) -------------------
+ * LinTrans takes any n_chan (layer_types.py:39-53) and the router MLP any hidden width (arch_and_hypers.py:14,45-49);
+ * the tuned kernels above hold n_cls <= 16 and two EQUAL hidden layers of <= 16 units.  The same argument records go
+ * to these plain kernels (a thread per output element, intermediates recomputed from h1 / h2 / bn_save, no scratch, any
+ * batch size; not latency-tuned) for n_cls <= 1024, R, R2 <= 256, C <= 256, HW * C <= 4096 (mpnn_exit_gen_check):
+ *   mpnn_lin_fwd_gen        == mpnn_lin_fwd
+ *   mpnn_lin_bwd_gen        == mpnn_lin_bwd with dx (or NULL); the dz_out fusion is not offered: the caller runs
+ *                              mpnn_bn_bwd_reduce on dx instead
+ *   mpnn_exit_tail_fwd_gen  == mpnn_exit_tail_fwd (batch statistics or, with mode MPNN_ACT_BN_MOVING, the averages)
+ *   mpnn_exit_tail_bwd_gen  == mpnn_exit_tail_bwd
+ *   mpnn_exit_ev_gen        == mpnn_exit_ev (children's lists appended with one atomic per sample) */
+int mpnn_lin_fwd_gen(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void *stream);
+int mpnn_lin_bwd_gen(const mpnn_lin_bwd_args *dev_table, int count, int n_max, int k_max, void *stream);
+int mpnn_exit_tail_fwd_gen(const mpnn_exit_tail_args *dev_table, int count, int n_max, void *stream);
+int mpnn_exit_tail_bwd_gen(const mpnn_exit_tail_bwd_args *dev_table, int count, int n_max, void *stream);
+int mpnn_exit_ev_gen(const mpnn_exit_ev_args *dev_table, int count, int n_max, void *stream);
+int mpnn_exit_gen_check(int C, int K, int n_cls, int R, int R2, int n_sinks);
 
 /* ---- the router: routing probabilities, costs and their gradients ----------
  * Replaces ActorNet._route/_route_sinks_dyn + cost assembly

@@ -96,7 +96,7 @@ class ExitTailArgs(C.Structure):
                 ('g2', P), ('b2', P), ('m2', P), ('v2', P), ('w3', P), ('bias3', P),
                 ('h2', P), ('r', P), ('r_stride', C.c_int), ('bn_save', P),
                 ('bn_eps', C.c_float), ('bn_decay', C.c_float), ('mode', C.c_int), ('n', C.c_int),
-                ('clear_f', P), ('n_clear_f', C.c_int), ('clear_d', P), ('n_clear_d', C.c_int)]
+                ('clear_f', P), ('n_clear_f', C.c_int), ('clear_d', P), ('n_clear_d', C.c_int), ('R2', C.c_int)]
 
 
 class ExitTailBwdArgs(C.Structure):
@@ -114,7 +114,7 @@ class ExitEvArgs(C.Structure):
                 ('g2', P), ('be2', P), ('m2', P), ('v2', P), ('w3', P), ('bias3', P),
                 ('bn_eps', C.c_float), ('r', P), ('r_stride', C.c_int),
                 ('idx', P), ('cnt', P), ('n', C.c_int),
-                ('child_idx', P * 4), ('child_cnt', P * 4)]
+                ('child_idx', P * 4), ('child_cnt', P * 4), ('R2', C.c_int)]
 
 
 class ConvNhwcFwdArgs(C.Structure):
@@ -180,6 +180,12 @@ _SIGS = {
     'mpnn_conv_nhwc_wgrad': [C.POINTER(ConvNhwcWgradArgs), P],
     'mpnn_backward_finish_opt': [P, P, C.c_int, P, P, P, P, P, C.c_int, P, C.c_float, C.c_int, P, P, P, P, P, P, C.c_int,
                                  C.c_float, C.c_float, P, P, P, C.c_int, P],
+    'mpnn_lin_fwd_gen': [P, C.c_int, C.c_int, P],
+    'mpnn_lin_bwd_gen': [P, C.c_int, C.c_int, C.c_int, P],
+    'mpnn_exit_tail_fwd_gen': [P, C.c_int, C.c_int, P],
+    'mpnn_exit_tail_bwd_gen': [P, C.c_int, C.c_int, P],
+    'mpnn_exit_ev_gen': [P, C.c_int, C.c_int, P],
+    'mpnn_exit_gen_check': [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     'mpnn_maxpool_fwd': [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P],
     'mpnn_maxpool_bwd': [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P],
     'mpnn_set_reserved_cus': [C.c_int],

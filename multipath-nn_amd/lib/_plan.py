@@ -168,6 +168,7 @@ class Engine:
         self.n_cls = int(self.net.hypers.y_shape[0])
         # blocks
         self.blocks = []
+        self.generic_exits = bool(int(os.environ.get('MPNN_GENERIC_EXITS', '0')))      # (1: the any-width exit kernels for every net)
         for nd in self.nodes:
             if nd.kind != 'block':
                 continue
@@ -218,21 +219,25 @@ class Engine:
                     b.has_dz[j] = True
             if b.has_exit:
                 b.has_dz[b.L - 1] = True
-            # compile-time limits of the exit kernels (exit_tail.hip, exit_ev.hip, lin.hip): beyond them
-            # the kernels would silently work on a prefix, so refuse here
+            # compile-time limits of the TUNED exit kernels (exit_tail.hip, exit_ev.hip, lin.hip): <= 16 classes, two
+            # equal router layers of <= 16 units, C <= 128 with H*W*C % 16 == 0.  A net with an exit beyond them runs ALL
+            # its exits on the any-width forms (csrc/exit_gen.hip: plain kernels, same records), whose own limits are
+            # checked here; beyond those the engine refuses instead of truncating.
             if b.has_exit:
                 K = b.H[-1] * b.W[-1] * b.C[-1]
-                if b.C[-1] > 128 or K % 16:
-                    raise NotImplementedError('exit on a %dx%dx%d map: the exit kernels need C <= 128 and H*W*C %% 16 == 0'
-                                              % (b.H[-1], b.W[-1], b.C[-1]))
-                if b.head is not None and self.n_cls > 16:
-                    raise NotImplementedError('%d classes: the exit kernels hold at most 16' % self.n_cls)
+                R = R2 = 0
                 if b.router is not None:
-                    widths = [b.router.comps[k].hypers.n_chan for k in (1, 4)]
-                    if widths[0] != widths[1] or widths[0] > 16:
-                        raise NotImplementedError('router widths %r: the exit kernels need two equal hidden layers of <= 16 units' % (widths,))
+                    R, R2 = (b.router.comps[k].hypers.n_chan for k in (1, 4))
                     if len(b.node.layer.sinks) > _hip.MAX_SINKS:
                         raise NotImplementedError('more than %d sinks under one switch' % _hip.MAX_SINKS)
+                tuned = b.C[-1] <= 128 and K % 16 == 0 and (b.head is None or self.n_cls <= 16) and R == R2 and R <= 16
+                if not tuned:
+                    self.generic_exits = True
+                    if self.lib.mpnn_exit_gen_check(b.C[-1], K, self.n_cls if b.head is not None else 0, R, R2,
+                                                    len(b.node.layer.sinks) if b.router is not None else 0):
+                        raise NotImplementedError('exit on a %dx%dx%d map with %d classes and a %d-%d router: outside the any-width '
+                                                  'exit kernels too (C <= 256, H*W*C <= 4096, <= 1024 classes, <= 256 units)'
+                                                  % (b.H[-1], b.W[-1], b.C[-1], self.n_cls, R, R2))
         for nd in self.nodes:
             if nd.kind == 'head' and self.nodes[nd.parent].kind != 'block':
                 raise NotImplementedError('LogReg must hang off a ReConvMax block')
@@ -488,10 +493,10 @@ class Engine:
                 if b.has_exit:
                     b.z = z(n, self.n_cls) if b.head is not None else None
                     if b.router is not None:
-                        R = b.router.comps[1].hypers.n_chan
-                        b.R = R
-                        b.h1, b.h2 = z(n, R), z(n, R)
-                        b.bn_save = z(4 * R)
+                        R, R2 = (b.router.comps[k].hypers.n_chan for k in (1, 4))
+                        b.R, b.R2 = R, R2
+                        b.h1, b.h2 = z(n, R), z(n, R2)
+                        b.bn_save = z(2 * R + 2 * R2)
             nn, nl, ns = len(self.nodes), len(self.leaves), max(len(self.switches), 1)
             self.p_tr, self.p_ev = z(nn * n), z(nn * n)
             self.w_cerr = z(nl * n)
@@ -878,7 +883,7 @@ class Engine:
                 keep += [bpart, bcnt]
                 lb.kpart, lb.kcnt = bpart.data_ptr(), bcnt.data_ptr()
             lb.dx = b.dx.data_ptr()
-            if mode == 'tr' and not b.children and not self.multi_stream:
+            if mode == 'tr' and not b.children and not self.multi_stream and not self.generic_exits:
                 # the exit's dX is the only gradient of this map: lin_bwd masks it and accumulates the
                 # BatchNorm-backward reductions itself (no mpnn_bn_bwd_reduce launch)
                 lb.dx = None
@@ -906,7 +911,7 @@ class Engine:
                 lb.w[1], lb.dy[1], lb.M[1] = lf.w[1], b.dh1.data_ptr(), R
                 lb.dw[1], lb.db[1] = l1.params.w.grad.data_ptr(), l1.params.b.grad.data_ptr()
                 lf.extra_col[1] = lb.extra_col[1] = 1 if dyn else 0
-                tf.h1, tf.R, tf.n_sinks = b.h1.data_ptr(), R, S
+                tf.h1, tf.R, tf.n_sinks, tf.R2 = b.h1.data_ptr(), R, S, b.R2
                 tf.g1, tf.b1 = bn1.params.γ.data.data_ptr(), bn1.params.β.data.data_ptr()
                 tf.m1, tf.v1 = bn1.params.m_avg.data.data_ptr(), bn1.params.v_avg.data.data_ptr()
                 tf.w2, tf.bias2 = l2.params.w.data.data_ptr(), l2.params.b.data.data_ptr()
@@ -935,7 +940,10 @@ class Engine:
         t_lf, t_lb = _hip.to_device_table(lin_f, self.dev), _hip.to_device_table(lin_b, self.dev)
         t_tf, t_tb = _hip.to_device_table(tail_f, self.dev), _hip.to_device_table(tail_b, self.dev)
         keep += [t_lf, t_lb, t_tf, t_tb]
-        if n_exit:
+        if n_exit and self.generic_exits:
+            fwd.append(call(lib.mpnn_lin_fwd_gen, 'lin_fwd', t_lf.data_ptr(), n_exit, n))
+            fwd.append(call(lib.mpnn_exit_tail_fwd_gen, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n))
+        elif n_exit:
             if n <= 512:
                 fwd.append(call(lib.mpnn_lin_fwd_ks, 'lin_fwd', t_lf.data_ptr(), n_exit, n, kmax))
             else:
@@ -954,7 +962,10 @@ class Engine:
         # ---- backward ----
         slab_plan = dict(size=0)
         level_fix = []
-        if n_exit:
+        if n_exit and self.generic_exits:
+            bwd.append(call(lib.mpnn_exit_tail_bwd_gen, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
+            bwd.append(call(lib.mpnn_lin_bwd_gen, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
+        elif n_exit:
             bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
             bwd.append(call(lib.mpnn_lin_bwd_rs if n <= 512 else lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
         if dp and 'exit' in self.dp_buckets:
@@ -976,7 +987,7 @@ class Engine:
             L1 = b.L - 1
             pre = []
             # coarsest scale without a child block: its dy is the exit's dX alone
-            if not b.children and (self.multi_stream or not b.has_exit):
+            if not b.children and (self.multi_stream or not b.has_exit or self.generic_exits):
                 ctx = self._bn_ctx(b, L1, n, with_red=False)
                 pre.append(call(lib.mpnn_bn_bwd_reduce, 'bn_bwd_reduce', b.dx.data_ptr(), C.byref(ctx),
                                 b.dzg[L1].data_ptr(), self.dred[b.sum_off[L1]:].data_ptr(),
@@ -1321,7 +1332,7 @@ class Engine:
                 l1, bn1, l2, bn2, l3 = rc[1], rc[2], rc[4], rc[5], rc[7]
                 sw = b.node.switch_id
                 D = lambda prm: prm.data.data_ptr()
-                e.w1, e.b1, e.R, e.n_sinks = D(l1.params.w), D(l1.params.b), b.R, len(b.node.layer.sinks)
+                e.w1, e.b1, e.R, e.n_sinks, e.R2 = D(l1.params.w), D(l1.params.b), b.R, len(b.node.layer.sinks), b.R2
                 e.extra_col, e.k_cpt, e.alpha_cpt = (1 if dyn else 0), self.k_cpt.data_ptr(), float(_attr(ϕ, 'α_cpt', 0.0))
                 e.g1, e.be1, e.m1, e.v1 = D(bn1.params.γ), D(bn1.params.β), D(bn1.params.m_avg), D(bn1.params.v_avg)
                 e.w2, e.bias2 = D(l2.params.w), D(l2.params.b)
@@ -1335,7 +1346,8 @@ class Engine:
                             e.child_idx[i], e.child_cnt[i] = sb.ev_idx.data_ptr(), sb.ev_cnt.data_ptr()
             if b.ev_list is not None:
                 e.idx, e.cnt = b.ev_list[0].data_ptr(), b.ev_list[1].data_ptr()
-            _hip.check(lib.mpnn_exit_ev_check(C.byref(e)), 'exit_ev record')
+            if not self.generic_exits:
+                _hip.check(lib.mpnn_exit_ev_check(C.byref(e)), 'exit_ev record')
             recs[id(b)] = e
 
         kidx = {h: k for k, h in enumerate(sorted({h for b in self.blocks for h in b.H}, reverse=True))}
@@ -1353,7 +1365,7 @@ class Engine:
             if order:
                 tab = _hip.to_device_table(order, self.dev)
                 keep.append(tab)
-                fwd.append(call(lib.mpnn_exit_ev, 'exit_ev', tab.data_ptr(), len(order), n))
+                fwd.append(call(lib.mpnn_exit_ev_gen if self.generic_exits else lib.mpnn_exit_ev, 'exit_ev', tab.data_ptr(), len(order), n))
 
         if not routed:
             wavefront(self.blocks)

@@ -100,7 +100,9 @@ class ConvEngine:
                 h, w = ho, wo
         self.H, self.W = h, w                      # the map the head reads
         K = h * w * self.C[-1]
-        if self.C[-1] > 128 or K % 16 or self.n_cls > 16:
+        # beyond the tuned exit kernels' limits (<= 16 classes, C <= 128, K % 16 == 0): the any-width forms (csrc/exit_gen.hip)
+        self.generic = self.C[-1] > 128 or K % 16 != 0 or self.n_cls > 16
+        if self.generic and (self.lib.mpnn_exit_gen_check(self.C[-1], K, self.n_cls, 0, 0, 0) or self.C[-1] % 4 or 256 % (self.C[-1] // 4)):
             raise NotImplementedError('head on a %dx%dx%d map / %d classes: outside the exit kernels\' limits' % (h, w, self.C[-1], self.n_cls))
         self.head = head
         # routing tree: root chain (node 0) -> leaf (node 1)
@@ -273,17 +275,18 @@ class ConvEngine:
             tf.c_err, tf.d_cor, tf.mode, tf.n = self.c_err.data_ptr(), self.d_cor.data_ptr(), _hip.ACT_BN_BATCH, n
             t_lf, t_tf = _hip.to_device_table([lf], self.dev), _hip.to_device_table([tf], self.dev)
             keep += [t_lf, t_tf]
-            self._chk(lib.mpnn_lin_fwd(t_lf.data_ptr(), 1, n, st), 'lin_fwd')
-            self._chk(lib.mpnn_exit_tail_fwd(t_tf.data_ptr(), 1, n, st), 'exit_tail_fwd')
+            self._chk((lib.mpnn_lin_fwd_gen if self.generic else lib.mpnn_lin_fwd)(t_lf.data_ptr(), 1, n, st), 'lin_fwd')
+            self._chk((lib.mpnn_exit_tail_fwd_gen if self.generic else lib.mpnn_exit_tail_fwd)(t_tf.data_ptr(), 1, n, st), 'exit_tail_fwd')
         else:
             e = _hip.ExitEvArgs()
             e.a, e.HW, e.n = a_head, HW, n
             e.w_head, e.b_head, e.n_cls = lt.params.w.data.data_ptr(), lt.params.b.data.data_ptr(), self.n_cls
             e.y, e.eps_ce, e.c_err, e.d_cor = self.y.data_ptr(), float(ce.hypers.ϵ), self.c_err.data_ptr(), self.d_cor.data_ptr()
-            self._chk(lib.mpnn_exit_ev_check(C.byref(e)), 'exit_ev record')
+            if not self.generic:
+                self._chk(lib.mpnn_exit_ev_check(C.byref(e)), 'exit_ev record')
             t_e = _hip.to_device_table([e], self.dev)
             keep.append(t_e)
-            self._chk(lib.mpnn_exit_ev(t_e.data_ptr(), 1, n, st), 'exit_ev')
+            self._chk((lib.mpnn_exit_ev_gen if self.generic else lib.mpnn_exit_ev)(t_e.data_ptr(), 1, n, st), 'exit_ev')
         ra = _hip.RouteArgs()
         ra.net_type, ra.n_nodes, ra.n_leaves, ra.n_switches, ra.max_sinks = _hip.NET_SR, 2, 1, 0, 2
         ra.want_grad = 1 if train else 0
@@ -310,14 +313,25 @@ class ConvEngine:
         lb.a, lb.HW, lb.n = a_head, HW, n
         lb.w[0], lb.dy[0], lb.M[0] = lf.w[0], self.dz.data_ptr(), self.n_cls
         lb.dw[0], lb.db[0] = lt.params.w.grad.data_ptr(), lt.params.b.grad.data_ptr()
-        if self.stages[last][1]:               # Rect before the head: masked dX + (discarded) reductions
+        masked = self.stages[last][1]          # Rect before the head: masked dX + (discarded) reductions
+        if masked and not self.generic:
             lb.dz_out, lb.red_out, lb.red_nslot = self.g[last].data_ptr(), self.scratch.data_ptr(), 1
         else:
             lb.dx = self.g[last].data_ptr()
         t_tb, t_lb = _hip.to_device_table([tb], self.dev), _hip.to_device_table([lb], self.dev)
         keep += [t_tb, t_lb]
-        self._chk(lib.mpnn_exit_tail_bwd(t_tb.data_ptr(), 1, n, st), 'exit_tail_bwd')
-        self._chk(lib.mpnn_lin_bwd(t_lb.data_ptr(), 1, n, HW * self.C[-1], st), 'lin_bwd')
+        self._chk((lib.mpnn_exit_tail_bwd_gen if self.generic else lib.mpnn_exit_tail_bwd)(t_tb.data_ptr(), 1, n, st), 'exit_tail_bwd')
+        self._chk((lib.mpnn_lin_bwd_gen if self.generic else lib.mpnn_lin_bwd)(t_lb.data_ptr(), 1, n, HW * self.C[-1], st), 'lin_bwd')
+        if masked and self.generic:
+            # the any-width lin_bwd leaves the plain dX: the ReLU mask is mpnn_bn_bwd_reduce with a plain-ReLU context
+            # (dz = dy where the stored pre-activation is positive; its reductions go to scratch), in place
+            ctx = _hip.BnCtx()
+            ctx.s = self.out[last].data_ptr()
+            ctx.bn = _hip.act(None, self.C[-1], _hip.ACT_RELU, 0, None, n * HW)
+            ctx.red_nslot = 1
+            keep.append(ctx)
+            self._chk(lib.mpnn_bn_bwd_reduce(self.g[last].data_ptr(), C.byref(ctx), self.g[last].data_ptr(), self.scratch.data_ptr(),
+                                             n * HW, st), 'relu mask of the head\'s dX')
         for k in range(last, -1, -1):
             st_ = self.stages[k]
             c, kind, (hi, wi) = st_[0], st_[2], st_[3]

@@ -43,11 +43,11 @@ def from_product(net, n, before):
             masks.append((y > 0).cpu().numpy())
         forced[('relu', id(chain), 2)] = masks
         if b.router is not None:
-            R = b.R
+            R, R2 = b.R, b.R2              # bn_save = m1 [R], rstd1 [R], m2 [R2], rstd2 [R2]
             sv = b.bn_save.cpu().numpy()
             rc = b.router.comps
             f32 = np.float32
-            for k, h, (m, rstd) in ((3, b.h1, (sv[:R], sv[R:2 * R])), (6, b.h2, (sv[2 * R:3 * R], sv[3 * R:4 * R]))):
+            for k, h, (m, rstd) in ((3, b.h1, (sv[:R], sv[R:2 * R])), (6, b.h2, (sv[2 * R:2 * R + R2], sv[2 * R + R2:2 * R + 2 * R2]))):
                 bn = rc[k - 1].params
                 g, be = before[id(bn.γ)].cpu().numpy().astype(f32), before[id(bn.β)].cpu().numpy().astype(f32)
                 hv = h[:n].cpu().numpy().astype(f32)

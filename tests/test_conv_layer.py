@@ -286,3 +286,42 @@ def test_conv_net_with_pooling_layers_vs_oracle():
     ce = r['out'][id(leaf)]['c_err'].detach().numpy()
     assert np.abs(leaf.c_err.cpu().numpy() - ce).max() < 2e-4 * (1 + np.abs(ce).max())
     assert float(net.state()[(net, 'moc')].mean()) == net.root.n_ops + leaf.n_ops
+
+
+def test_conv_net_with_40_classes_runs_on_the_any_width_exit_kernels():
+    """n_cls > 16 on the single-scale engine: the any-width head kernels (csrc/exit_gen.hip), a ReLU in front of the
+    head masked through mpnn_bn_bwd_reduce.  Gradients of every parameter against the float64 oracle."""
+    from oracle.ref_net import RefNet
+    net = pooled_conv_net()((32, 32, 3), (40,))           # (ends ... Rect, GlobalMaxPool: the head's dX needs the mask)
+    eng = net.engine()
+    assert type(eng).__name__ == 'ConvEngine' and eng.generic and eng.stages[-1][1]
+    eng.init_params(4)
+    ref = RefNet(net)
+    n, lr = 20, 0.05
+    rng = np.random.default_rng(1)
+    x0 = rng.random((n, 32, 32, 3)).astype(np.float32)
+    y = np.eye(40, dtype=np.float32)[rng.integers(0, 40, n)]
+    ref.load_params()
+    before = {id(p): p.data.clone() for p in net._all_params}
+    net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: lr})
+    forced, k = {}, 0
+    for j, c in enumerate(net.root.comps):
+        if type(c).__name__ == 'Rect':
+            forced[('relu', id(net.root), j)] = (eng.out[k - 1][:n] > 0).cpu().numpy()
+        else:
+            k += 1
+    res_ = ref.train_step(x0, y, lr, forced=forced)
+    for p in net._all_params:
+        v0 = before[id(p)].cpu().numpy().astype(np.float64)
+        g_ref = res_['grads'][id(p)].numpy().reshape(-1)
+        gp = p.grad.cpu().numpy().astype(np.float64)
+        if p.l2:
+            gp = gp + 2 * p.l2 * (v0 - (np.asarray(p.eq, np.float64).reshape(-1) if p.eq is not None else 0))
+        assert np.abs(gp - g_ref).max() <= 1e-4 * np.abs(g_ref).max() + 1e-6, ('grad', p.owner.name, p.name)
+    net.eval({net.x0: x0, net.y: y})
+    r = ref.forward(x0, y, 'ev')              # (the oracle still holds the pre-step parameters: reload)
+    ref.load_params()
+    r = ref.forward(x0, y, 'ev')
+    leaf = net.root.sinks[0]
+    ce = r['out'][id(leaf)]['c_err'].detach().numpy()
+    assert np.abs(leaf.c_err.cpu().numpy() - ce).max() < 2e-4 * (1 + np.abs(ce).max())

@@ -74,14 +74,14 @@ def rel(a, b):
     return np.abs(a - b).max() / (1e-12 + np.abs(b).max())
 
 
-def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL):
+def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL, n_cls=10):
     """Teacher-forced: before every step the oracle is re-synchronised from the product's
     parameters, momentum accumulators and BatchNorm state, so each step checks one
     forward + backward + TALR/momentum update from IDENTICAL state.  (A free-running
     comparison is meaningless: the float64 oracle alone turns a 1e-5 relative weight
     perturbation into a 7-50 % gradient change through max-pool / ReLU flips.)"""
     from oracle.ref_net import RefNet
-    net = make_net((32, 32, c0), (10,))
+    net = make_net((32, 32, c0), (n_cls,))
     eng = net.engine()
     eng.init_params(1234)
     if net._net_kind != 'sr':
@@ -91,7 +91,7 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL):
     worst = {'grad': 0.0, 'update': 0.0}
     flips_total = decisions_total = 0
     for t in range(steps):
-        x0, y = batch(n, c0, seed=t)
+        x0, y = batch(n, c0, n_cls, seed=t)
         feed = {net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: lr, **feeds(net, t)}
         kw = {}
         if net._net_kind != 'sr':
@@ -160,7 +160,7 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL):
           'decisions that differ from the free float64 run: %d of %d (%.1e)'
           % (steps, worst['grad'], worst['update'], tol, flips_total, decisions_total, flips_total / max(1, decisions_total)))
     # evaluation pass: moving-average BatchNorm, hard routing, statistics
-    x0, y = batch(n, c0, seed=99)
+    x0, y = batch(n, c0, n_cls, seed=99)
     feed = {net.x0: x0, net.y: y, **{k: v for k, v in feeds(net, 0).items()}}
     kw = {}
     if k_cpt_vec is not None:
@@ -259,6 +259,95 @@ def test_baseline_hybrid_dyn_k_cpt_batch_128():
     import arch_and_hypers as A
     kv = lambda t, n: np.random.default_rng(t).choice(A.k_cpts, n).astype(np.float32)
     run_case(A.ac_chain(dyn_k_cpt=True), 128, lambda net, t: {net.τ: A.τ_ds(0)}, steps=1, k_cpt_vec=kv)
+
+
+def _wide_chain(net_type, widths, n_blocks=4, **hypers):
+    """An actor / critic chain of the first `n_blocks` blocks whose routers have hidden layers of `widths` units
+    (arch_and_hypers.router with another router_n_chan, or two different widths): LinTrans(n_chan=...) is free in the
+    reference (layer_types.py:39-53, arch_and_hypers.py:14,45-49)."""
+    import arch_and_hypers as A
+    from lib.layer_types import BatchNorm, Chain, LinTrans, Rect, Select
+
+    def router(n_sinks):
+        if n_sinks < 2:
+            return None
+        hidden = []
+        for w in widths:
+            hidden += [LinTrans(n_chan=w, k_l2=A.k_l2, σ_w=A.σ_w), BatchNorm(), Rect()]
+        return Chain(name='Router', comps=[Select(i=-1), *hidden, LinTrans(n_chan=n_sinks, k_l2=A.k_l2, σ_w=0)])
+
+    def rcm(i, *sinks):
+        ℓ = A.rcm(i, *sinks)
+        ℓ.router = router(len(sinks))
+        return ℓ
+
+    def make_net(x0_shape, y_shape):
+        node = rcm(n_blocks - 1, A.reg(y_shape[0]))
+        for i in range(n_blocks - 2, -1, -1):
+            node = rcm(i, A.reg(y_shape[0]), node)
+        return net_type(x0_shape=x0_shape, y_shape=y_shape, root=A.pyr(node), **hypers)
+    return make_net
+
+
+def test_wide_router_and_100_classes():
+    """Beyond the tuned exit kernels' limits (n_cls <= 16, two equal router layers of <= 16 units): a 32-wide router and
+    100 classes, and two DIFFERENT hidden widths (24, 40), run on the any-width forms (csrc/exit_gen.hip) -- same
+    tolerances as every other whole-step case, training and evaluation, routed evaluation == dense."""
+    from lib.net_types import ActorNet, CriticNet
+    import arch_and_hypers as A
+    run_case(_wide_chain(ActorNet, (32, 32), k_cpt=1.6e-8), 24, lambda net, t: {net.τ: 0.8}, steps=2, n_cls=100)
+    run_case(_wide_chain(CriticNet, (24, 40), k_cpt=8e-9), 20, lambda net, t: {net.τ: 0.3}, steps=2, n_cls=37)
+    run_case(_wide_chain(ActorNet, (48, 16), k_cpt=1.6e-8), 160, lambda net, t: {net.τ: 0.8}, steps=1, n_cls=20)     # beyond 128 samples
+    net = _wide_chain(ActorNet, (32, 32), k_cpt=1.6e-8)((32, 32, 3), (100,))
+    eng = net.engine()
+    assert eng.generic_exits
+    eng.init_params(5)
+    perturb_routers(net)
+    rng = np.random.default_rng(8)
+    for p in net._all_params:                  # moving averages away from (0, 1), as after training
+        if not p.trainable:
+            p.assign(rng.random(p.shape) * 0.5 + (0.75 if p.name == 'v_avg' else -0.25))
+    for ℓ in net.switches:                     # ... and routers that really decide
+        last = ℓ.router.comps[-1].params
+        last.w.assign(rng.standard_normal(last.w.shape) * 2.0)
+    x0, y = batch(300, 3, 100, seed=2)
+    from test_routed_eval import calibrate_exit_fractions
+    calibrate_exit_fractions(net, x0, y, [1 / 4] * 3)          # a quarter of the batch leaves at each of the four exits
+    net.eval({net.x0: x0, net.y: y})
+    dense = [ℓ.p_ev.clone() for ℓ in net.layers]
+    ce = [ℓ.c_err.clone() for ℓ in net.leaves]
+    assert [float(ℓ.p_ev.mean()) for ℓ in net.leaves] == [0.25] * 4
+    net.eval({net.x0: x0, net.y: y}, routed=1)
+    assert all(torch.equal(a, ℓ.p_ev) for a, ℓ in zip(dense, net.layers))
+    for c, ℓ in zip(ce, net.leaves):
+        reach = ℓ.p_ev > 0
+        assert torch.equal(c[reach], ℓ.c_err[reach])
+
+
+def test_tuned_and_any_width_exit_kernels_agree():
+    """The shipped chain on the any-width forms (MPNN_GENERIC_EXITS=1) against the tuned kernels: the same training
+    steps to fp32 summation order."""
+    import os
+    import arch_and_hypers as A
+    outs = []
+    for gen in ('0', '1'):
+        os.environ['MPNN_GENERIC_EXITS'] = gen
+        try:
+            net = A.ac_chain(k_cpt=1.6e-8, seed=3)((32, 32, 3), (10,))
+            eng = net.engine()
+        finally:
+            del os.environ['MPNN_GENERIC_EXITS']
+        assert eng.generic_exits == (gen == '1')
+        perturb_routers(net)
+        x0, y = batch(48, seed=7)
+        for _ in range(2):
+            net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.05, net.τ: 0.8})
+        torch.cuda.synchronize()
+        outs.append((eng.P.cpu().numpy().copy(), [ℓ.p_tr.cpu().numpy().copy() for ℓ in net.layers]))
+    (Pa, pa), (Pb, pb) = outs
+    assert np.abs(Pa - Pb).max() <= 3e-4 * np.abs(Pa).max(), np.abs(Pa - Pb).max()
+    for u, v in zip(pa, pb):
+        assert np.abs(u - v).max() <= 2e-4
 
 
 def test_batch_of_one_eval():
