@@ -124,10 +124,11 @@ int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
  * 32 per operand) in TRAINING mode (a.mode == MPNN_ACT_BN_BATCH) takes the K-split body (512
  * threads, two chunks of a 32-channel unit in parallel); results are the same up to fp32 summation
  * order.  Evaluation-mode launches never take it.  Members on maps with W % 16 == 0 whose input is
- * one to three 16-channel chunks (no 1/3-channel image operand) take the wave-per-strip bodies of
- * conv_strip.h when the record's sample capacity `n` is >= 512 (MPNN_STRIP: minimum, 0 = off): the
- * one-chunk body gives the same bits as mpnn_msconv_fwd, the multi-chunk body the same values up
- * to fp32 summation order.  Groups of 8x8 / 4x4 members with Cout % 32 == 0 in evaluation mode and
+ * one to three 16-channel chunks -- or a 1/3-channel image plus a 16-channel operand V (block 0's
+ * second scale) -- take the wave-per-strip bodies of conv_strip.h when the record's sample capacity
+ * `n` is >= 512 (MPNN_STRIP: minimum, 0 = off), in training mode (batch statistics) as in evaluation
+ * mode: the one-chunk body gives the same bits as mpnn_msconv_fwd, the multi-chunk / image + V bodies
+ * the same values up to fp32 summation order.  Groups of 8x8 / 4x4 members with Cout % 32 == 0 in evaluation mode and
  * `n` >= 1024 (MPNN_FWD_WIDE) use 32-channel output tiles: the same bits.  Which body runs depends only on the shapes and on `n` -- never on the
  * grouping, the index list or the device-side count -- so a conv gives bit-identical rows on all
  * samples or on a routed sub-batch of the same capacity. */

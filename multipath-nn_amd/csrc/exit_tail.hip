@@ -366,14 +366,16 @@ int mpnn_trace_install_tail(void *buf) { return mpnn_trace_install(buf); }
 // workgroups (they loop over the batch already), launched with the router halves idle
 __global__ __launch_bounds__(256) void exit_tail_fwd_big_k(const mpnn_exit_tail_args *__restrict__ tab) {
     const mpnn_exit_tail_args a = tab[blockIdx.x];
-    if (a.h1) router_fwd_big(a);
+    if (a.h1 && a.n > CHUNK) router_fwd_big(a);          // (a record of <= CHUNK samples runs in the LDS-resident kernel only)
 }
 
 extern "C" int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int count, int n_max, void *stream) {
     if (count <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    if (n_max > CHUNK)
+    if (n_max > CHUNK) {
         hipLaunchKernelGGL(exit_tail_fwd_big_k, dim3(count), dim3(256), 0, (hipStream_t)stream, dev_table);
+        MPNN_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(exit_tail_fwd_k, dim3(2 * count), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;
@@ -718,14 +720,16 @@ __global__ __launch_bounds__(256) void exit_tail_bwd_k(const mpnn_exit_tail_bwd_
 
 __global__ __launch_bounds__(256) void exit_tail_bwd_big_k(const mpnn_exit_tail_bwd_args *__restrict__ tab) {
     const mpnn_exit_tail_bwd_args b = tab[blockIdx.x];
-    if (b.f.h1) router_bwd_big(b);
+    if (b.f.h1 && b.f.n > CHUNK) router_bwd_big(b);
 }
 
 extern "C" int mpnn_exit_tail_bwd(const mpnn_exit_tail_bwd_args *dev_table, int count, int n_max, void *stream) {
     if (count <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    if (n_max > CHUNK)
+    if (n_max > CHUNK) {
         hipLaunchKernelGGL(exit_tail_bwd_big_k, dim3(count), dim3(256), 0, (hipStream_t)stream, dev_table);
+        MPNN_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(exit_tail_bwd_k, dim3(2 * count), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;

@@ -1675,6 +1675,10 @@ class Engine:
             self._bind_views(n)
             return
         prog = self.program(mode, n, routed)
+        if train and prog.get('fold') and self._acc_clean and os.environ.get('MPNN_PLAN_DEBUG'):
+            # (debug: a step without a clearing launch relies on the previous step having left these cleared)
+            torch.cuda.synchronize()
+            assert not bool(self.dsum.any()) and not bool(self.dred.any()), 'slot sums not clean at the start of a step'
         if not self.use_graph:
             self._step_eager(prog, train, n)
         else:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes only (rocprofv3 counter collection crashes inside hipGraph replay on this stack: eager launches).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?}
 O=$R/gpurun_out/final
 mkdir -p $O
 B="python3 $R/bench.py --no-graph --steps 30 --warmup 10 --no-cpu-baseline --no-configs --no-dp-structure --eval-batch 512"

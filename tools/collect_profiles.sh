@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/collect_profiles.sh'         (kernel trace + agreement; the PMC passes: tools/collect_pmc.sh)
 # Every step runs under `timeout`: rocprofv3's counter collection was seen to hang inside hipGraphLaunch.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?}
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 timeout 600 python3 $R/bench.py > $O/bench.json 2> $O/bench.err

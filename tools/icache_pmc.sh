@@ -2,7 +2,7 @@
 # Instruction-cache counters per kernel of the training step (eager launches: counter collection does not work inside
 # hipGraph replay on this stack).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?}
 O=$R/gpurun_out/icache
 rm -rf $O; mkdir -p $O
 MPNN_GRAPH=0 timeout 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_WAVES --kernel-trace --output-format csv -d $O -o ic -- python3 $R/tools/quick_step.py 60 > /dev/null 2> $O/err.txt

@@ -2,6 +2,7 @@
 # Budget knobs of the backward launches (weight-gradient share of the resident slots, relative item latencies of
 # the level budget): re-run after changes to the bodies.
 cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
 {
 TAG=base python tools/quick_step.py 300
 for d in 1.6 2.5 3; do TAG=wgdiv_$d MPNN_WG_DIV=$d python tools/quick_step.py 300; done

@@ -2,7 +2,7 @@
 # Step timeline (per-kernel durations inside the replayed graph) of the bench configuration under rocprofv3.
 #   gpurun -- 'bash tools/timeline.sh [name]'   -> gpurun_out/timeline_<name>.txt ; environment knobs pass through
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?}
 N=${1:-cur}
 O=$R/gpurun_out/tl_$N
 rm -rf $O; mkdir -p $O
