@@ -817,11 +817,31 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         if (u == 0) trace_stamp(10);
         lds_barrier();              // LDS-only: the prefetch loads of unit u+2 stay in flight
     };
+#ifndef MPNN_ONE_STEP
+#define MPNN_ONE_STEP 0
+#endif
+#if MPNN_ONE_STEP
+    // ONE copy of the step in the loop (half the loop's code) at the price of a register rotation per unit: the set that
+    // has just received unit u + 2 becomes "the next unit" of the following step (the moves wait for those loads, which
+    // were issued a whole step earlier).
+#pragma nounroll
+    for (int u = 0; u < n_units; ++u) {
+        step(u, xrB, brB, xrA, brA);
+        if (u == 0) trace_stamp(3);
+#pragma unroll
+        for (int k = 0; k < SC * XN; ++k)
+#pragma unroll
+            for (int w = 0; w < XW; ++w) xrB[k][w] = xrA[k][w];
+#pragma unroll
+        for (int k = 0; k < SC * BN; ++k) brB[k] = brA[k];
+    }
+#else
     for (int u = 0; u < n_units; u += 2) {
         step(u, xrB, brB, xrA, brA);
         if (u == 0) trace_stamp(3);
         if (u + 1 < n_units) step(u + 1, xrA, brA, xrB, brB);
     }
+#endif
     trace_stamp(4);
 
     if (EPI == EPI_FWD || EPI == EPI_DGH_BN) {
