@@ -281,3 +281,21 @@ def test_fast_draws_reproduce_the_reference_fixtures():
         rec = _draw_augmentation_fast(n, len(x0), su8, r)
         xb, yb = augmented_batch(x0, y, n, m_sym, r, draws=rec)
         assert np.array_equal(xb, G['case%d_x' % k]) and np.array_equal(yb, G['case%d_y' % k]), k
+
+
+def test_host_only_entry_points_without_a_gpu():
+    """Entry points that are pure host state / validation run without a device: the limits of the any-width exit kernels
+    (mpnn_exit_gen_check) and the compute-unit reservation of the persistent grids (mpnn_set_reserved_cus)."""
+    from lib import _hip
+    lib = _hip.load()
+    ok = lib.mpnn_exit_gen_check
+    assert ok(128, 2048, 100, 32, 24, 3) == 0 and ok(256, 4096, 1024, 256, 256, 4) == 0 and ok(16, 256, 0, 0, 0, 0) == 0
+    assert ok(257, 2048, 10, 16, 16, 2) == _hip.E_SHAPE          # channels
+    assert ok(128, 8192, 10, 16, 16, 2) == _hip.E_SHAPE          # features of the exit's input map
+    assert ok(128, 2048, 1025, 16, 16, 2) == _hip.E_SHAPE        # classes
+    assert ok(128, 2048, 10, 300, 16, 2) == _hip.E_SHAPE and ok(128, 2048, 10, 16, 300, 2) == _hip.E_SHAPE
+    assert ok(128, 2048, 10, 16, 16, 5) == _hip.E_SHAPE and ok(128, 2048, 10, 16, 16, 1) == _hip.E_SHAPE      # sinks
+    assert ok(48, 100, 10, 0, 0, 0) == _hip.E_SHAPE              # K not a multiple of C
+    assert lib.mpnn_set_reserved_cus(-1) == 0                    # query
+    assert lib.mpnn_set_reserved_cus(24) == 0 and lib.mpnn_set_reserved_cus(-1) == 24
+    assert lib.mpnn_set_reserved_cus(0) == 24 and lib.mpnn_set_reserved_cus(-1) == 0
