@@ -8,9 +8,9 @@ ROOT=$(cd ../.. && pwd)
 mkdir -p build_$TAG
 SRCS=$(sed -n 's/^SRCS := //p' Makefile)
 for f in $SRCS; do
-  ( hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -munsafe-fp-atomics -Wno-unused-result \
+  ( hipcc -O3 -std=c++17 -fPIC --offload-arch=${ARCH:-gfx950} -I$ROOT/include -munsafe-fp-atomics -Wno-unused-result \
       -mllvm -amdgpu-kernarg-preload-count=16 "$@" -c $f -o build_$TAG/${f%.hip}.o 2>/dev/null ) &
 done
 wait
-hipcc -shared -fPIC --offload-arch=gfx950 build_$TAG/*.o -o ../libmpnn_hip_$TAG.so
+hipcc -shared -fPIC --offload-arch=${ARCH:-gfx950} build_$TAG/*.o -o ../libmpnn_hip_$TAG.so
 echo built ../libmpnn_hip_$TAG.so
