@@ -1,6 +1,7 @@
 """CPU, world_size 2 over gloo: the data-parallel reducer (lib/_dp.py).  One all-reduce (sum) of the
-flat gradient buffer whose tail carries the per-node TALR statistics; the optimizer's scaling
-(grad/world, statistics/(n*world)) must reproduce the single-process global-batch update."""
+flat gradient buffer that also carries the per-node TALR statistics (at its head in the engine's layout; where
+they sit does not matter to the reducer); the optimizer's scaling (grad/world, statistics/(n*world)) must
+reproduce the single-process global-batch update."""
 import os
 import sys
 
@@ -25,7 +26,8 @@ def _worker(rank, world, port, out):
     n_params, n_nodes, n = 1000, 5, 16
     grads = g.standard_normal(n_params).astype(np.float32)          # per-replica mean-loss gradients
     p_tr = g.random((n_nodes, n)).astype(np.float32)                 # per-replica routing probabilities
-    flat = torch.from_numpy(np.concatenate([grads, np.stack([p_tr.sum(1), (p_tr ** 2).sum(1)], 1).reshape(-1)]))
+    stat = np.stack([p_tr.sum(1), (p_tr ** 2).sum(1)], 1).reshape(-1)
+    flat = torch.from_numpy(np.concatenate([stat, grads]))            # statistics first, as in Engine.G
     _dp.allreduce_sum(flat)
     out[rank] = (grads, p_tr, flat.numpy().copy())
     dist.barrier()
@@ -42,7 +44,7 @@ def test_allreduce_with_talr_tail_matches_global_batch():
     n = out[0][1].shape[1]
     for r in range(world):
         flat = out[r][2]
-        g_sum, stat = flat[:1000], flat[1000:].reshape(-1, 2)
+        stat, g_sum = flat[:10].reshape(-1, 2), flat[10:]
         # optimizer scaling (mpnn_talr_momentum_step): grad_scale = 1/world, inv_n = 1/(n*world)
         assert np.allclose(g_sum / world, grads.mean(0), atol=1e-6)
         assert np.allclose(stat[:, 0] / (n * world), p_tr.mean(1), atol=1e-6)
