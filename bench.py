@@ -329,6 +329,25 @@ def main():
               'ms_p95': float(np.percentile(per, 95)), 'images_per_s_median': n * world / (float(np.median(per)) * 1e-3),
               'what': 'replays after the headline region (rank 0\'s clock), HIP events around chunks of %d steps' % CH}
 
+    # A multi-rank run validates itself: after all the timed steps the replicas must still hold the SAME parameters and
+    # momentum accumulators (every rank applied the same all-reduced gradient), whatever form the step took; the
+    # BatchNorm moving averages are per-replica state by design (each rank normalises its own 128 images) and are
+    # reported, not required to agree.
+    dp_check = None
+    if world > 1:
+        key = [k for k in eng._graphs if k[0] == 'tr' and k[2]] if eng.use_graph else []
+        form = 'eager'
+        if key and isinstance(eng._graphs[key[0]], tuple):
+            form = 'whole' if eng._graphs[key[0]][1] == 'whole' else 'sections'
+        dP, dA, dS = _dp.max_divergence(eng.P), _dp.max_divergence(eng.A), _dp.max_divergence(eng.S)
+        dp_check = {'replicas_identical': dP == 0.0 and dA == 0.0, 'max_abs_param_divergence': dP,
+                    'max_abs_momentum_divergence': dA, 'bn_moving_average_divergence': dS,
+                    'dp_form': form, 'captured_collective_selftest': getattr(eng, 'dp_selftest', None),
+                    'backend': dist.get_backend(), 'steps_before_check': args.warmup + args.steps + 3 + CH * NCH_}
+        single = os.environ.get('MPNN_SINGLE_GPU_VALUE')
+        if single:
+            dp_check['efficiency_vs_single'] = value / (world * float(single))
+
     dp_structure, cfg_table = None, None
     if world == 1 and not args.no_dp_structure and not args.streams:
         try:
@@ -462,6 +481,7 @@ def main():
             'config': {'workload': 'cifar10-ac: ac_chain(k_cpt=0) 8-block actor-routed chain, 32x32x3, 10 classes',
                        'global_batch': n * world, 'per_gpu_batch': n, 'parallelism': 'dp%d' % world, 'rccl_ranks': (dist.get_world_size() if world > 1 else 1),
                        'allreduce': ar,
+                       **(dp_check or {}),
                        'hip_graph': bool(eng.use_graph), 'streams': eng.n_streams if eng.multi_stream else 1},
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
                          'frac': ach / PEAK_F32_MFMA, 'traffic': traffic, 'traffic_source': traffic_src,

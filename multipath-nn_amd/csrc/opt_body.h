@@ -12,10 +12,10 @@ struct OptP {
 __device__ __forceinline__ void opt_node(const OptP &o, int node, int is_router, float &scale, float &pbar) {
     pbar = o.node_stat[node * 2] * o.inv_n;                       // mean p_tr over the batch
     scale = 1.f;
-    if (o.talr) {
-        scale = 1.f / sqrtf(o.node_stat[node * 2 + 1] * o.inv_n);  // 1/sqrt(mean p_tr^2)
-        if (is_router) scale *= o.hyp[MPNN_HYP_ARTR];
-    }
+    if (o.talr) scale = 1.f / sqrtf(o.node_stat[node * 2 + 1] * o.inv_n);   // 1/sqrt(mean p_tr^2)
+    // a router's parameters: alpha_rtr * lr_scale, and lr_scale is 1 without TALR (net_types.py:25-33) -- the factor
+    // does NOT depend on talr.  SRNets have no routers (is_router = 0 for every item).
+    if (is_router) scale *= o.hyp[MPNN_HYP_ARTR];
 }
 
 // one element without a weight pack (BatchNorm gamma / beta in the fused launch): the same arithmetic as opt_seg

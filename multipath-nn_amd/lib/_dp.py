@@ -95,6 +95,19 @@ def sync_state(net):
     return net
 
 
+def max_divergence(t):
+    """max over ranks and elements of |t - rank 0's t| (a float; 0.0 for identical replicas).  Diagnostics of a
+    multi-rank run (bench.py): the replicas' parameters must still agree bit for bit after any number of steps."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0.0
+    staged = t.is_cuda and dist.get_backend() == 'gloo'
+    ref = t.detach().cpu().clone() if staged else t.detach().clone()
+    dist.broadcast(ref, src=0)
+    d = (t.detach().to(ref.device) - ref).abs().max().reshape(1).double()
+    dist.all_reduce(d, op=dist.ReduceOp.MAX)
+    return float(d.item())
+
+
 def quiesce():
     """Call before capturing a hipGraph that contains collectives.  The process group's watchdog thread polls the end
     event of every collective issued OUTSIDE a capture until it has seen it complete (one pass every ~100 ms); an
@@ -122,11 +135,12 @@ def captured_collectives_work():
     all-reduce recorded into a hipGraph and replayed twice must give the sum over the ranks, on every rank.  The
     one-graph form of the data-parallel step (lib/_plan.py) is only used when this passed everywhere; otherwise all
     ranks use one graph per bucket section with the collectives issued from the host."""
-    ok = True
+    import warnings
+    dev = 'cuda:%d' % local_device()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    buf = torch.zeros(1024, device=dev)
+    g = None
     try:
-        dev = 'cuda:%d' % local_device()
-        rank, world = dist.get_rank(), dist.get_world_size()
-        buf = torch.zeros(1024, device=dev)
         src = torch.full((1024,), float(rank + 1), device=dev)
         side = torch.cuda.Stream(device=dev)
         dist.all_reduce(buf.clone(), op=dist.ReduceOp.SUM)        # (communicator set-up outside the capture)
@@ -139,13 +153,24 @@ def captured_collectives_work():
                 h.wait()
                 buf.mul_(2.0)
             torch.cuda.current_stream().wait_stream(side)
+    except Exception as e:                                          # noqa: BLE001 -- any failure means "do not capture"
+        warnings.warn('capturing an RCCL collective failed (%r): the data-parallel step uses section graphs' % (e,))
+        g = None
+    # The ranks agree that EVERY rank captured before ANY rank replays: a rank whose capture threw would otherwise sit in
+    # the eager MIN all-reduce below while the others replay a captured SUM all-reduce -- mismatched collectives, a hang
+    # until the watchdog's timeout, which is the failure this self-test exists to rule out.
+    torch.cuda.synchronize()
+    if not agree(g is not None):
+        return False
+    ok = True
+    try:
+        quiesce()
         for _ in range(2):
             g.replay()
         torch.cuda.synchronize()
         ok = bool(torch.all(buf == float(world * (world + 1))).item())
-    except Exception as e:                                          # noqa: BLE001 -- any failure means "do not capture"
-        import warnings
-        warnings.warn('captured RCCL collectives failed the self-test (%r): the data-parallel step uses section graphs' % (e,))
+    except Exception as e:                                          # noqa: BLE001
+        warnings.warn('replaying a captured RCCL collective failed (%r): the data-parallel step uses section graphs' % (e,))
         ok = False
     return agree(ok)
 
@@ -170,6 +195,7 @@ def attach(net, force=False):
         if _selftest is None:
             _selftest = captured_collectives_work()
         eng.allreduce_capturable = _selftest
+        eng.dp_selftest = bool(_selftest)
     eng._graphs.clear()                        # graphs captured so far folded the optimizer into the step
     for buf in (eng.P, eng.S, eng.A):          # identical replicas to start from
         if buf.is_cuda and dist.get_backend() == 'gloo':

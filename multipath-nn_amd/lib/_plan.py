@@ -69,6 +69,23 @@ class _Node:
     pass
 
 
+class BoundInput:
+    """Feed value for ``net.x0`` / ``net.y`` that means "whatever the step's prologue puts into the engine's own
+    input buffer" (lib/data.py: Dataset.bind_engine -- the on-device batch assembly is launch 0 of the step).  It
+    names the buffer instead of holding a view of it: the buffers are reallocated when a larger batch comes by (the
+    statistics pass at 4 096 images), and a view taken before that would feed the step from an orphaned allocation."""
+
+    def __init__(self, eng, which, n):
+        self.eng, self.which, self.n = eng, which, int(n)
+
+    @property
+    def shape(self):
+        return (self.n,) + tuple(getattr(self.eng, self.which).shape[1:])
+
+    def tensor(self):
+        return getattr(self.eng, self.which)[:self.n]
+
+
 class _Block:
     pass
 
@@ -1418,6 +1435,10 @@ class Engine:
         self._ensure_capacity(n, feed.get(net.mode, net.mode.default) == 'tr')
 
         def put(dst, src):
+            if isinstance(src, BoundInput):
+                if src.eng is not self or self.prologue is None:
+                    raise ValueError('a BoundInput feeds the engine it was bound to, with the prologue installed')
+                return
             if isinstance(src, torch.Tensor):
                 if src.data_ptr() == dst.data_ptr():
                     return
@@ -1780,6 +1801,8 @@ class Engine:
                     gk = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gk, capture_error_mode=CAPTURE_MODE):
                         if k == 0:
+                            if train and self.prologue is not None:    # (the input pipeline: launch 0 of the step in every form)
+                                self.prologue(torch.cuda.current_stream().cuda_stream)
                             self._clear_if_needed(prog, train)
                         self._launch(ops, k)
                     secs.append((gk, bucket))

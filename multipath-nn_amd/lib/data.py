@@ -188,14 +188,21 @@ class Dataset:
     def bind_engine(self, eng, n=128):
         """Make the batch assembly the FIRST launch of the engine's training step (part of its hipGraph): every
         net.train.run then gathers the batch described by the latest stage_training_draws() straight into the
-        engine's input buffers.  Returns the (x0, y) views to put into the feed."""
+        engine's input buffers.  Returns the (x0, y) feed values (markers that name the engine's buffers)."""
+        import torch
+        from ._plan import BoundInput
         if getattr(self, '_x_dev', None) is None:
             self.to_device(str(eng.dev))
         eng._ensure_capacity(n)
-        self.stage_training_draws(n)                     # (allocates the static draw buffer)
-        x_out, y_out = eng.x0[:n], eng.y[:n]
-        eng.set_prologue(lambda stream: self._augment_launch(n, x_out, y_out, stream))
-        return x_out, y_out
+        # the draw buffer and its upload ring, WITHOUT drawing: a draw here would consume a batch of the numpy stream and
+        # offset every later batch against the reference's call sequence (scripts/lib/data.py:24-34)
+        if self._ring is None or self._ring[0][0].shape[0] < n:
+            self._ring = [(torch.zeros((n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING)]
+            self._draw_dev = torch.zeros((n, 4), dtype=torch.int32, device=self._dev)
+        # the engine's buffers are resolved when the launch is issued (eagerly or into a capture; the engine drops its
+        # graphs whenever it reallocates them), never held as views: see _plan.BoundInput
+        eng.set_prologue(lambda stream: self._augment_launch(n, eng.x0[:n], eng.y[:n], stream))
+        return BoundInput(eng, 'x0', n), BoundInput(eng, 'y', n)
 
     def training_batch(self, n=128):
         return batch(self.x0_tr, self.y_tr, n)

@@ -296,7 +296,7 @@ class RefNet:
             for p in params_list_rec(ℓ):
                 scale[id(p)] = s
             for p in params_list_rec(ℓ.router):
-                scale[id(p)] = (ϕ.α_rtr if talr else 1.0) * s
+                scale[id(p)] = ϕ.α_rtr * s      # (α_rtr * lr_scale, lr_scale = 1 without TALR: net_types.py:25-33)
         res['grads'] = {}
         with torch.no_grad():
             for p in net._all_params:

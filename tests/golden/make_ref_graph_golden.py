@@ -33,14 +33,26 @@ CASES = {
     'cr_opt_cls': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9, optimistic=True, use_cls_err=True), tau=0.3, n=3),
     'sr3': dict(ctor='sr_chain', args=(3,), hypers={}, tau=None, n=3),
     # the deepest statically-routed chain (scripts/train-nets:81-88), on CIFAR-shaped and on MNIST-shaped (one channel,
-    # prep-data:35-38) inputs.  (New keys sort AFTER the old ones: a case's seed is its index in sorted(CASES).)
+    # prep-data:35-38) inputs.  (Seeds: `seed_of` below.)
     'sr8': dict(ctor='sr_chain', args=(8,), hypers={}, tau=None, n=3),
     'sr8_mnist': dict(ctor='sr_chain', args=(8,), hypers={}, tau=None, n=3, c0=1),
     # a 3-way switch over two sub-chains, built from the spec's own rcm / reg / pyr (the reference's dr_tree
     # cannot run at this revision: `y_shape` scoping bug, arch_and_hypers.py:99-106)
     'ac_tree3': dict(ctor='small_tree', net='ActorNet', hypers=dict(k_cpt=1.6e-8), tau=0.8, n=4),
     'cr_tree3': dict(ctor='small_tree', net='CriticNet', hypers=dict(k_cpt=8e-9, optimistic=True), tau=0.4, n=4),
+    # the router factor alpha_rtr * lr_scale (net_types.py:25-33) away from 1 -- WITHOUT TALR (lr_scale = 1: the factor
+    # must still apply; rounds 1-4 dropped it in the oracle and in the kernel alike, and no fixture had alpha_rtr != 1),
+    # with TALR, and on a critic net without TALR
+    'ac_notalr_artr2': dict(ctor='ac_chain', hypers=dict(k_cpt=4e-9, talr=False, α_rtr=2.0), tau=1.0, n=3, seed=10),
+    'cr_artr3': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9, α_rtr=3.0), tau=0.5, n=3, seed=11),
+    'cr_notalr_artr': dict(ctor='cr_chain', hypers=dict(k_cpt=2e-9, talr=False, α_rtr=0.5, k_cre=0.01), tau=0.2, n=3, seed=12),
 }
+# seeds of the first ten cases: their index in the sorted key list of the round they were generated in
+_LEGACY = ['ac', 'ac_dyn', 'ac_notalr_nokdec', 'ac_tree3', 'cr', 'cr_opt_cls', 'cr_tree3', 'sr3', 'sr8', 'sr8_mnist']
+
+
+def seed_of(key):
+    return CASES[key].get('seed', _LEGACY.index(key) if key in _LEGACY else None)
 
 
 def small_tree(A, NT, case):
@@ -126,7 +138,8 @@ def main():
     import arch_and_hypers as A
     assert NT.__file__.startswith(REF) and A.__file__.startswith(REF)
     out = {}
-    for seed, (key, case) in enumerate(sorted(CASES.items())):
+    for key, case in sorted(CASES.items()):
+        seed = seed_of(key)
         tf_standin.reset()
         net = make_case(A, NT, case)((32, 32, case.get('c0', 3)), (10,))
         rng = np.random.RandomState(seed)

@@ -284,7 +284,7 @@ def test_bench_two_ranks_functional_on_one_gpu(tmp_path):
     deadlock or a rank-dependent collective shows up here, not on the 8-GPU node."""
     import json
     import subprocess
-    env = dict(os.environ, MPNN_DP_BACKEND='gloo', MPNN_DP_ONE_GPU='1')
+    env = dict(os.environ, MPNN_DP_BACKEND='gloo', MPNN_DP_ONE_GPU='1', MPNN_SINGLE_GPU_VALUE='250000')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '3',
            '--no-cpu-baseline', '--eval-batch', '256']
@@ -294,6 +294,13 @@ def test_bench_two_ranks_functional_on_one_gpu(tmp_path):
     assert line['n_gpus'] == 2 and line['config']['global_batch'] == 256 and line['config']['rccl_ranks'] == 2
     assert set(line['config']['allreduce']) == {'end'}
     assert line['value'] > 0 and line['steady_state']['steps'] == 400
+    # the run validates itself: both replicas hold the same parameters and accumulators after all 412 steps, and the
+    # line says which form of the step ran (gloo: section graphs, no captured-collective self-test)
+    cfg = line['config']
+    assert cfg['replicas_identical'] is True and cfg['max_abs_param_divergence'] == 0.0 and cfg['max_abs_momentum_divergence'] == 0.0
+    assert cfg['dp_form'] == 'sections' and cfg['backend'] == 'gloo' and cfg['captured_collective_selftest'] is None
+    assert cfg['bn_moving_average_divergence'] > 0.0            # (per-replica state: the ranks see different images)
+    assert abs(cfg['efficiency_vs_single'] - line['value'] / 500000) < 1e-9
 
 
 def test_bench_spawns_its_own_ranks(tmp_path):

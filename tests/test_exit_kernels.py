@@ -440,7 +440,8 @@ def test_talr_momentum_step(talr):
             seg += [off + s0, min(2048, cnt - s0), node, rt, int(np.float32(l2).view(np.int32)), s0 if has_eq else -1,
                     0, 0, 0, -1, -1, 0]
         pbar = stat[node, 0] / (n * world)
-        sc = (1 / np.sqrt(stat[node, 1] / (n * world)) * (artr if rt else 1.0)) if talr else 1.0
+        # net_types.py:25-33: lr_scale = 1/sqrt(mean p_tr^2) with TALR, 1 without; routers get alpha_rtr * lr_scale EITHER WAY
+        sc = (1 / np.sqrt(stat[node, 1] / (n * world)) if talr else 1.0) * (artr if rt else 1.0)
         sl = slice(off, off + cnt)
         g = (G[sl].astype(np.float64) / world + 2 * np.float64(np.float32(l2)) * pbar * (P[sl] - (eq if has_eq else 0))) * sc   # net_types.py:24-37 + layer_types.py:52
         want_A[sl] = mu * A[sl] + g

@@ -232,3 +232,55 @@ def test_tree_experiments_run_from_the_cli(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, 'multipath-nn_amd', 'train-adaptive-nets'), 'hybrid-cr-tree-dynkcpt',
                            '--synthetic', '--iters', '2', '--out', out], cwd=str(tmp_path))
     assert os.path.exists(os.path.join(out, 'hybrid-cr-tree-dynkcpt', '0007-stats.npy'))
+
+
+@pytest.mark.parametrize('form', ['one_graph', 'sections', 'eager'])
+def test_bound_input_pipeline_feeds_every_step_in_every_graph_form(form):
+    """Dataset.bind_engine makes mpnn_augment_batch launch 0 of the step.  In EVERY form of the step -- one hipGraph,
+    one graph per gradient-bucket section with host-issued collectives (the data-parallel fallback), eager launches -- a
+    step must train on the batch staged for it (round 4's section-graph form replayed without the gather: every step
+    after the warm-up trained on the first batch), also after the engine reallocated its input buffers for a larger
+    evaluation batch (a statistics pass at 4 096 images between two steps), and binding must not consume numpy draws."""
+    import arch_and_hypers as A
+    from lib.data import Dataset
+    ds = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+    net = A.ac_chain(k_cpt=1.6e-8, seed=5)(ds.x0_shape, ds.y_shape)
+    eng = net.engine()
+    n = 32
+    if form == 'eager':
+        eng.use_graph = False
+    if form == 'sections':
+        calls = []
+
+        def stub(flat):                   # a collective that cannot be captured (gloo / host-issued): world of one
+            calls.append(flat.numel())
+            return None
+        eng.world, eng.allreduce, eng.allreduce_capturable = 1, stub, False
+        eng._graphs.clear()
+    np.random.seed(3)
+    state = np.random.get_state()[1].copy()
+    x0, y = ds.bind_engine(eng, n)
+    assert np.array_equal(np.random.get_state()[1], state), 'bind_engine consumed draws of the global numpy stream'
+    ref = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+    np.random.seed(3)
+    seen = []
+    for t in range(6):
+        ds.stage_training_draws(n)
+        net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.01, net.τ: 1.0})
+        torch.cuda.synchronize()
+        got = eng.x0[:n].cpu().numpy().copy()
+        rng_state = np.random.get_state()
+        np.random.seed(3)                                      # the same draws through the host path, step t
+        for _ in range(t + 1):
+            want, want_y = ref.augmented_training_batch(n)
+        np.random.set_state(rng_state)
+        assert np.abs(got - want).max() <= 1e-6, (form, t)
+        assert np.array_equal(eng.y[:n].cpu().numpy(), want_y)
+        seen.append(got)
+        if t == 3:                                             # a larger evaluation batch: the buffers are reallocated
+            xb = torch.rand(n * 8, *ds.x0_shape, device='cuda')
+            yb = torch.zeros(n * 8, ds.y_shape[0], device='cuda'); yb[:, 0] = 1
+            net.eval({net.x0: xb, net.y: yb})
+    assert all(np.abs(a - b).max() > 0 for a, b in zip(seen, seen[1:]))
+    if form == 'sections':
+        assert len(calls) >= 6 and eng._graphs and all(v[1] != 'whole' for v in eng._graphs.values() if isinstance(v, tuple))

@@ -47,7 +47,7 @@ def test_oracle_matches_the_reference_graph_code(key):
     import lib.net_types as NT
     from oracle.ref_net import RefNet
     case = M.CASES[key]
-    seed = sorted(M.CASES).index(key)
+    seed = M.seed_of(key)
     net = M.make_case(A, NT, case)((32, 32, case.get('c0', 3)), (10,))
     params = ordered(net)
     assert [n for n, _ in params] == list(GOLD['%s/names' % key])        # same parameters, same order
@@ -101,7 +101,7 @@ def test_product_matches_the_reference_graph_code(key):
     import arch_and_hypers as A
     import lib.net_types as NT
     case = M.CASES[key]
-    seed = sorted(M.CASES).index(key)
+    seed = M.seed_of(key)
     net = M.make_case(A, NT, case)((32, 32, case.get('c0', 3)), (10,))
     net.engine()
     params = ordered(net)
