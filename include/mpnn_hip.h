@@ -134,6 +134,13 @@ int mpnn_msconv_fwd(const mpnn_conv_fwd_args *args, void *stream);
  * samples or on a routed sub-batch of the same capacity. */
 int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
                           void *stream);
+/* CO-TRAINING (no reference counterpart in one call: scripts/train-nets:81-88,159-164 trains the nets of an experiment one
+ * after another, each at batch 128 -- one net cannot fill 256 compute units).  The `_rep` / `_multi` entry points run the
+ * SAME launch of `reps` nets of one architecture as ONE grid: `args` / `dev_args` hold reps * count records, net r's at
+ * [r * count, (r + 1) * count) -- identical shapes and modes, every pointer net r's own (its batch, its parameters, its
+ * BatchNorm statistics).  Per net the arithmetic is that of the single-net launch on resident slots / reps. */
+int mpnn_msconv_fwd_group_rep(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
+                              int reps, void *stream);
 
 /* ---- BatchNorm(+ReLU) backward pieces ------------------------------------
  * Backward of `y = relu(gamma * (s - m) / sqrt(v + eps) + beta)` THROUGH the
@@ -239,6 +246,10 @@ int mpnn_msconv_bwd_level_record_size(void);
 int mpnn_msconv_bwd_level_slots(const int *H, const int *W, const int *Cout, int count);
 int mpnn_msconv_bwd_level_prepare(const mpnn_bwd_member *members, int count, void *host_records);
 int mpnn_msconv_bwd_level(const mpnn_bwd_member *members, int count, const void *dev_records, void *stream);
+/* One dependency level of `reps` co-trained nets (see mpnn_msconv_fwd_group_rep): reps * count members / records, net r's
+ * at [r * count, ...); the same shapes and the same workgroup budgets in every net (budget against _slots / reps). */
+int mpnn_msconv_bwd_level_prepare_rep(const mpnn_bwd_member *members, int count, int reps, void *host_records);
+int mpnn_msconv_bwd_level_rep(const mpnn_bwd_member *members, int count, int reps, const void *dev_records, void *stream);
 /* Number of 64-pixel tiles (upper bound of n_split) for a map, or MPNN_E_SHAPE. */
 int mpnn_wgrad_tiles(int n, int H, int W);
 /* dst[i] = sum_{s<n_split} src[s*stride + i].  table: 6 ints per work item:
@@ -473,6 +484,9 @@ typedef struct {
     int n;  int n_total;                 /* n_total: samples the mean is over      */
 } mpnn_route_args;
 int mpnn_route(const mpnn_route_args *args, void *stream);
+/* mpnn_route of `count` co-trained nets with the same tree shape and batch size as one launch (host_table sizes it,
+ * dev_table = the same records in device memory). */
+int mpnn_route_multi(const mpnn_route_args *host_table, const mpnn_route_args *dev_table, int count, void *stream);
 
 /* On-device compaction of the 'ev' sub-batch that reaches a node: indices of
  * samples with p_ev > 0, in order (wave64 ballot + prefix sum), and their
@@ -543,6 +557,17 @@ int mpnn_backward_finish_opt(const float *slabs, const int *slab_table, int n_it
                              float *params, float *accum, float *grads, const float *node_stat,
                              const float *hyp, int talr, float inv_n, float grad_scale, const float *w_eq,
                              float *packs, const int *plain_seg, int n_plain, void *stream);
+
+/* mpnn_backward_finish_opt of `count` co-trained nets as one launch: one record per net (the arguments of the single-net
+ * call), in host memory to size the launch and in device memory for the kernel. */
+typedef struct {
+    const float *slabs;  const int *slab_table;  int n_items;  const int *item_seg;
+    double *sums, *reds;  float *state;  const int *bn_table;  int n_bn;  const int *bn_opt;  int n_img;  double *sums_keep;
+    float *params, *accum, *grads;  const float *node_stat, *hyp;  int talr;  float inv_n, grad_scale;
+    const float *w_eq;  float *packs;  const int *plain_seg;  int n_plain;
+} mpnn_finish_net;
+int mpnn_backward_finish_opt_multi(const mpnn_finish_net *host_table, const mpnn_finish_net *dev_table, int count,
+                                   float decay, void *stream);
 
 /* Workgroups of the mpnn_msconv_bwd_scale kernel (the variant for this shape, with or without a
  * dgrad-vert body) for an H x W x Cout scale that are resident on the

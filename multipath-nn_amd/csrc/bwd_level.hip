@@ -18,7 +18,7 @@
 #include "bwd_bodies.h"
 
 struct BwdRec { BwdScaleP q; int gk, wide, r0, r1; };
-struct BwdLevelQ { int n; int w0[MPNN_BWD_LEVEL_MAX]; };
+struct BwdLevelQ { int n; int w0[MPNN_BWD_LEVEL_MAX]; int reps, wpr; };    // reps > 1: `reps` copies of the level's wpr workgroups, copy r on records tab[r * n ..]
 
 template <int GK, int OT>
 __device__ __forceinline__ void level_wgrad(const BwdRec *__restrict__ r, int l, char *smem) {
@@ -75,7 +75,8 @@ template <int GKMASK, int OTMASK> struct LevelSmemAll {
 template <int GKMASK, int OTMASK>
 __global__ __launch_bounds__(256, (OTMASK & 2) ? 2 : MPNN_OCC_LEVEL) void bwd_level_k(const BwdRec *__restrict__ tab, const BwdLevelQ lq) {
     __shared__ __attribute__((aligned(16))) char smem[LevelSmemAll<GKMASK, OTMASK>::BYTES];
-    const int id = blockIdx.x;
+    int id = blockIdx.x;
+    if (lq.reps > 1) { const int rep = id / lq.wpr; id -= rep * lq.wpr; tab += rep * lq.n; }     // (uniform)
     int m = 0, w0 = 0;
 #pragma unroll
     for (int k = 1; k < MPNN_BWD_LEVEL_MAX; ++k)
@@ -135,10 +136,11 @@ static int level_build(const mpnn_bwd_member *mem, int count, BwdRec *recs, BwdL
     if (!mem || count < 1 || count > MPNN_BWD_LEVEL_MAX) return MPNN_E_ARG;
     gkmask = otmask = total = 0;
     lq.n = count;
+    BwdRec scratch;
     for (int k = 0; k < count; ++k) {
         const mpnn_bwd_member &m = mem[k];
         if (!m.wgrad || m.wgrad->n <= 0) return MPNN_E_ARG;
-        BwdRec &r = recs[k];
+        BwdRec &r = recs ? recs[k] : scratch;
         r = BwdRec{};
         int split = 1;
         const int rc = mpnn_fill_bwd_scale(m.horz, m.vert, m.wgrad, r.q, split);
@@ -172,6 +174,45 @@ extern "C" int mpnn_msconv_bwd_level_prepare(const mpnn_bwd_member *members, int
     BwdLevelQ lq = {};
     int gkmask, otmask, total;
     return level_build(members, count, (BwdRec *)host_records, lq, gkmask, otmask, total);
+}
+
+// The same level for `reps` nets of one architecture in ONE launch (co-training, lib/_co.py): members / records hold
+// reps * count entries, net r's at [r * count, (r + 1) * count) -- identical shapes and workgroup budgets, the buffers of
+// net r.  The caller's budget is per net (mpnn_msconv_bwd_level_slots / reps).
+static int level_build_rep(const mpnn_bwd_member *mem, int count, int reps, BwdRec *recs, BwdLevelQ &lq, int &gkmask, int &otmask, int &total) {
+    if (reps < 1) return MPNN_E_ARG;
+    int rc = level_build(mem, count, recs, lq, gkmask, otmask, total);
+    if (rc) return rc;
+    for (int r = 1; r < reps; ++r) {
+        BwdLevelQ l2 = {};
+        BwdRec tmp[MPNN_BWD_LEVEL_MAX];
+        int g2, o2, t2;
+        if ((rc = level_build(mem + r * count, count, recs ? recs + r * count : tmp, l2, g2, o2, t2))) return rc;
+        if (g2 != gkmask || o2 != otmask || t2 != total) return MPNN_E_ARG;
+        for (int k = 0; k < count; ++k) if (l2.w0[k] != lq.w0[k]) return MPNN_E_ARG;
+    }
+    lq.reps = reps;  lq.wpr = total;
+    return 0;
+}
+
+extern "C" int mpnn_msconv_bwd_level_prepare_rep(const mpnn_bwd_member *members, int count, int reps, void *host_records) {
+    if (!host_records) return MPNN_E_ARG;
+    BwdLevelQ lq = {};
+    int gkmask, otmask, total;
+    return level_build_rep(members, count, reps, (BwdRec *)host_records, lq, gkmask, otmask, total);
+}
+
+extern "C" int mpnn_msconv_bwd_level_rep(const mpnn_bwd_member *members, int count, int reps, const void *dev_records, void *stream) {
+    if (!dev_records) return MPNN_E_ARG;
+    BwdLevelQ lq = {};
+    int gkmask, otmask, total;
+    const int rc = level_build_rep(members, count, reps, nullptr, lq, gkmask, otmask, total);
+    if (rc) return rc;
+    LevelKern kern = level_kernel(gkmask, otmask);
+    if (!kern) return MPNN_E_SHAPE;
+    hipLaunchKernelGGL(kern, dim3(total * reps), dim3(256), 0, (hipStream_t)stream, (const BwdRec *)dev_records, lq);
+    MPNN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int mpnn_msconv_bwd_level(const mpnn_bwd_member *members, int count, const void *dev_records, void *stream) {

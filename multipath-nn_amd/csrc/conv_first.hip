@@ -29,8 +29,18 @@ struct FirstP {
 
 struct FirstTile { int n0, y0, x0; };
 
-template <bool STATS, bool POOL>
-__global__ __launch_bounds__(256) void fwd_first_k(const FirstP p) {
+// REP (co-trained nets, mpnn_msconv_fwd_group_rep): the grid is copies of `wpr` workgroups, copy r runs the first conv of
+// net r -- its record tab[r], the geometry of p0.
+template <bool STATS, bool POOL, bool REP = false>
+__global__ __launch_bounds__(256) void fwd_first_k(const FirstP p0, const mpnn_conv_fwd_args *__restrict__ tab = nullptr, const int wpr = 0) {
+    FirstP p = p0;
+    int bid = blockIdx.x, gdim = gridDim.x;
+    if constexpr (REP) {
+        const int rep = bid / wpr;
+        bid -= rep * wpr;  gdim = wpr;
+        const mpnn_conv_fwd_args *a = tab + rep;
+        p.x = a->a.x; p.w = a->wa_pack; p.bias = a->bias; p.out = a->out; p.pool_out = a->pool_out; p.out_sum = a->out_sum;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
@@ -61,10 +71,10 @@ __global__ __launch_bounds__(256) void fwd_first_k(const FirstP p) {
     // write one compact window of the output, which the memory side likes better than a private stream per wave
     // (123 against 132 us at 4 096 images).  The walk is incremental (column, row, image carries): no division
     // in the loop.
-    const bool xa = p.xcd != 0 && (p.n & 31) == 0 && (gridDim.x & 7) == 0;
-    const int xcd_id = blockIdx.x & 7;
-    const int jw = xa ? (int)(blockIdx.x >> 3) * 4 + wid : (int)blockIdx.x * 4 + wid;
-    const int nw = xa ? (int)(gridDim.x >> 3) * 4 : (int)gridDim.x * 4;
+    const bool xa = p.xcd != 0 && (p.n & 31) == 0 && (gdim & 7) == 0;
+    const int xcd_id = bid & 7;
+    const int jw = xa ? (int)(bid >> 3) * 4 + wid : (int)bid * 4 + wid;
+    const int nw = xa ? (int)(gdim >> 3) * 4 : (int)gdim * 4;
     const int jn = xa ? (p.n_tiles >> 3) : p.n_tiles;
     const int c0 = jw, c1 = jn, cd = nw;
     const int ty_n = H >> 2;
@@ -202,15 +212,24 @@ __global__ __launch_bounds__(256) void fwd_first_k(const FirstP p) {
             double a1 = 0.0, a2 = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { a1 += red[w][tid][0]; a2 += red[w][tid][1]; }
-            double *slot = p.out_sum + (size_t)(blockIdx.x % p.nslot) * 2 * 16;
+            double *slot = p.out_sum + (size_t)(bid % p.nslot) * 2 * 16;
             atomicAdd(slot + tid, a1);
             atomicAdd(slot + 16 + tid, a2);
         }
     }
 }
 
+static int first_conv_launch(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, hipStream_t st);
+
 // Takes the launch if the record is the first conv of a net (see the top of the file); 0 = launched, 1 = not mine.
-int mpnn_first_conv_launch(const mpnn_conv_fwd_args *a, hipStream_t st) {
+int mpnn_first_conv_launch(const mpnn_conv_fwd_args *a, hipStream_t st) { return first_conv_launch(a, nullptr, 1, st); }
+// ... of `reps` nets at once: a = net 0's record (the others have its shapes: checked by the caller), dev_args = the
+// reps records in device memory.
+int mpnn_first_conv_launch_rep(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, hipStream_t st) {
+    return first_conv_launch(a, dev_args, reps, st);
+}
+
+static int first_conv_launch(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, hipStream_t st) {
     static const int on = [] { const char *e = getenv("MPNN_FIRST_CONV"); return e ? atoi(e) : 1; }();
     if (!on || a->idx || a->cnt || a->v || a->Cout != 16 || a->a.C < 1 || a->a.C > 3 || a->a.shift != 0 ||
         a->a.mode != MPNN_ACT_IDENTITY) return 1;
@@ -223,13 +242,17 @@ int mpnn_first_conv_launch(const mpnn_conv_fwd_args *a, hipStream_t st) {
     p.n_tiles = a->n * (a->W >> 4) * (a->H >> 2);
     p.xcd = xcd_env();
     const bool stats = a->out_sum != nullptr, pool = a->pool_out != nullptr;
-    void (*kern)(const FirstP) = stats ? (pool ? fwd_first_k<true, true> : fwd_first_k<true, false>)
-                                       : (pool ? fwd_first_k<false, true> : fwd_first_k<false, false>);
-    long wgs = resident_slots((const void *)kern, 0);
+    typedef void (*FirstKern)(const FirstP, const mpnn_conv_fwd_args *, const int);
+    FirstKern kern = reps > 1 ? (stats ? (pool ? fwd_first_k<true, true, true> : fwd_first_k<true, false, true>)
+                                       : (pool ? fwd_first_k<false, true, true> : fwd_first_k<false, false, true>))
+                              : (stats ? (pool ? fwd_first_k<true, true> : fwd_first_k<true, false>)
+                                       : (pool ? fwd_first_k<false, true> : fwd_first_k<false, false>));
+    long wgs = resident_slots((const void *)kern, 0) / reps;
     const long need = (p.n_tiles + 3) / 4;
     if (wgs > need) wgs = need;
+    if (wgs < 1) wgs = 1;
     const int grid = xcd_round((int)wgs);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(kern, dim3(grid * reps), dim3(256), 0, st, p, dev_args, grid);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

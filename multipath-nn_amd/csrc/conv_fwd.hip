@@ -20,7 +20,9 @@ extern "C" int mpnn_msconv_fwd(const mpnn_conv_fwd_args *a, void *stream) {
 // Rows of the grid are dealt to the members; each member runs the body of its own geometry.
 // The members' serial latency chains overlap instead of queueing as separate launches.
 // ---------------------------------------------------------------------------
-struct FwdGroupP { int gk[4], small[4], gy[4], gx[4], y0[4], w0[4], rh[4]; int n; int xcd; };   // w0 = first linear workgroup of a member; gk 3 = strip body, rh rows per strip
+struct FwdGroupP { int gk[4], small[4], gy[4], gx[4], y0[4], w0[4], rh[4]; int n; int xcd; int reps, wpr; };   // w0 = first linear workgroup of a member; gk 3 = strip body, rh rows per strip
+// reps > 1 (mpnn_msconv_fwd_group_rep: co-trained nets of one architecture): the grid is `reps` copies of the group's
+// wpr workgroups, copy r runs the records tab[r * n .. r * n + n) -- same geometry, the buffers of net r.
 
 __host__ __device__ static inline int fill_fwd(const mpnn_conv_fwd_args *a, ConvP &p) {
     if (!a || !a->a.x || !a->wa_pack || !a->out || !a->bias) return MPNN_E_ARG;
@@ -53,7 +55,8 @@ __global__ __launch_bounds__(256, WIDE ? 2 : (SMALL ? 3 : MPNN_OCC)) void fwd_gr
     extern __shared__ __attribute__((aligned(16))) char smem[];   // sized by the host for the members present
     // 1-D grid with exactly the workgroups that have work (a 2-D grid padded to the widest member
     // launches workgroups that exit at once, and they were seen to delay the residency of real ones)
-    const int id = blockIdx.x;
+    int id = blockIdx.x;
+    if (q.reps > 1) { const int rep = id / q.wpr; id -= rep * q.wpr; tab += rep * q.n; }     // (uniform)
     int m = 0, w0 = 0, gx = q.gx[0], kind = q.gk[0] * 2 + q.small[0];
 #pragma unroll
     for (int k = 1; k < 4; ++k)
@@ -96,8 +99,35 @@ __global__ __launch_bounds__(512) void fwd_ks_k(const mpnn_conv_fwd_args *__rest
     conv_body<GK, 1, 1, 4, 1, false, EPI_FWD, 2, true>(p, bx, yy, gx, smem);
 }
 
+int mpnn_first_conv_launch_rep(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, hipStream_t st);
+
+static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count, int reps, void *stream);
+
 extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
                                      void *stream) {
+    return fwd_group_launch(args, dev_args, count, 1, stream);
+}
+
+// The same group for `reps` nets of one architecture in ONE launch (co-training, lib/_co.py): args / dev_args hold
+// reps * count records, net r's at [r * count, (r + 1) * count) -- identical shapes and modes, the buffers of net r.
+// The resident slots are shared between the nets; every net gets the grid the group would get on slots / reps.
+extern "C" int mpnn_msconv_fwd_group_rep(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
+                                         int reps, void *stream) {
+    if (reps < 1) return MPNN_E_ARG;
+    if (count <= 0) return 0;
+    if (!args || count > 4) return MPNN_E_ARG;
+    for (int r = 1; r < reps; ++r)
+        for (int k = 0; k < count; ++k) {
+            const mpnn_conv_fwd_args &a = args[k], &b = args[r * count + k];
+            if (a.n != b.n || a.H != b.H || a.W != b.W || a.Cout != b.Cout || a.a.C != b.a.C || a.a.mode != b.a.mode ||
+                a.a.shift != b.a.shift || (a.v != nullptr) != (b.v != nullptr) || a.Cv != b.Cv || a.out_nslot != b.out_nslot ||
+                (a.pool_out != nullptr) != (b.pool_out != nullptr) || (a.out_sum != nullptr) != (b.out_sum != nullptr) ||
+                a.idx || b.idx || a.cnt || b.cnt) return MPNN_E_ARG;
+        }
+    return fwd_group_launch(args, dev_args, count, reps, stream);
+}
+
+static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count, int reps, void *stream) {
     if (count <= 0) return 0;
     if (!args || !dev_args || count > 4) return MPNN_E_ARG;
     FwdGroupP q = {};
@@ -133,7 +163,8 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         rows += q.gy[k];
     }
     // the first conv of a net (image -> 16 channels, no operand V): its own wave-per-tile kernel (conv_first.hip)
-    if (count == 1 && mpnn_first_conv_launch(&args[0], (hipStream_t)stream) == 0) return 0;
+    if (count == 1 && reps == 1 && mpnn_first_conv_launch(&args[0], (hipStream_t)stream) == 0) return 0;
+    if (count == 1 && reps > 1 && mpnn_first_conv_launch_rep(&args[0], dev_args, reps, (hipStream_t)stream) == 0) return 0;
     // Share the resident workgroup slots between the members in proportion to their work, so that
     // every member is resident from the start.
     const int bytes[5] = {ConvSmem<0, 4, 16>::BYTES, ConvSmem<1, 4, 16>::BYTES, ConvSmem<2, 4, 16>::BYTES, 2048, strip_lds_bytes(MPNN_STRIP_KMAX)};
@@ -144,7 +175,8 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
     static const int ks_env = [] { const char *e = getenv("MPNN_FWD_KSPLIT"); return e ? atoi(e) : 1; }();
     // (training launches only: in the evaluation path the body of a conv depends on its shapes and its sample
     // capacity alone, so routed and dense evaluation of a batch agree bit for bit)
-    if (ks_env && !any_idx && hp[0].a.mode == MPNN_ACT_BN_BATCH && count == 1 && q.gk[0] != 0 && q.gk[0] < 3 && !q.small[0] && (hp[0].a.C % 32) == 0 && (hp[0].Cv % 32) == 0 &&
+    // (one net only: with several nets in the launch there are workgroups enough for every SIMD)
+    if (ks_env && reps == 1 && !any_idx && hp[0].a.mode == MPNN_ACT_BN_BATCH && count == 1 && q.gk[0] != 0 && q.gk[0] < 3 && !q.small[0] && (hp[0].a.C % 32) == 0 && (hp[0].Cv % 32) == 0 &&
         hp[0].a.C + hp[0].Cv >= 64) {
         const int gy = q.gy[0];
         int gx = hp[0].n_tiles;
@@ -173,7 +205,8 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
         wide ? (any_idx ? fwd_group_k<false, true, true> : fwd_group_k<false, false, true>) :
         any_idx ? (any_small ? fwd_group_k<true, true> : fwd_group_k<false, true>)
                 : (any_small ? fwd_group_k<true, false> : fwd_group_k<false, false>);
-    const long slots = resident_slots((const void *)kern, lds);
+    long slots = resident_slots((const void *)kern, lds) / reps;
+    if (slots < 1) slots = 1;
     // work of a member = tile-rows x units per tile (16-channel chunks of both operands)
     long total = 0, work[4];
     for (int k = 0; k < count; ++k) {
@@ -203,7 +236,8 @@ extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_
     int n_wg = 0;
     for (int k = 0; k < count; ++k) { q.w0[k] = n_wg; n_wg += q.gx[k] * q.gy[k]; }
     (void)gxm; (void)rows;
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, (hipStream_t)stream, dev_args, q);
+    q.reps = reps;  q.wpr = n_wg;
+    hipLaunchKernelGGL(kern, dim3(n_wg * reps), dim3(256), lds, (hipStream_t)stream, dev_args, q);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

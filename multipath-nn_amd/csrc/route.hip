@@ -49,8 +49,9 @@ __device__ __forceinline__ int4 uniform4(int4 v) {   // a record is the same in 
                      __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
 }
 
+// blk = workgroup index within the net's launch (RB samples each)
 template <int RB>
-__global__ __launch_bounds__(RT_THREADS) void route_k(const mpnn_route_args a) {
+__device__ __forceinline__ void route_body(const mpnn_route_args &a, const int blk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = a.n, NN = a.n_nodes, MS = a.max_sinks;
     trace_stamp(0); trace_note(6, 14);
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(RT_THREADS) void route_k(const mpnn_route_args a) {
     int4 *REC = (int4 *)(ARG + a.n_switches * RB);     // node records by rank   [NN + 1]  (16-byte aligned: RB % 4 == 0)
     float *OPS = (float *)(REC + NN + 1);         // node ops                 [NN]
     int *SWN = (int *)(OPS + NN);                 // sinks of each switch     [n_switches]
-    const int s0 = blockIdx.x * RB;
+    const int s0 = blk * RB;
     const int wave = threadIdx.x >> 6;
     constexpr int BT = RT_THREADS - 64;            // threads of the input burst; the last wave packs the records meanwhile
     if (wave < RT_WAVES - 1) {
@@ -348,6 +349,17 @@ __global__ __launch_bounds__(RT_THREADS) void route_k(const mpnn_route_args a) {
     trace_stamp(5);
 }
 
+template <int RB>
+__global__ __launch_bounds__(RT_THREADS) void route_k(const mpnn_route_args a) { route_body<RB>(a, blockIdx.x); }
+
+// Several nets of one tree shape in one launch (co-training, lib/_co.py): wpn workgroups per net, net r's record tab[r].
+template <int RB>
+__global__ __launch_bounds__(RT_THREADS) void route_multi_k(const mpnn_route_args *__restrict__ tab, const int wpn) {
+    const int net = blockIdx.x / wpn;
+    const mpnn_route_args a = tab[net];            // (by value: every field's scalar load in the entry block)
+    route_body<RB>(a, blockIdx.x - net * wpn);
+}
+
 int mpnn_trace_install_route(void *buf) { return mpnn_trace_install(buf); }
 
 extern "C" int mpnn_route(const mpnn_route_args *args, void *stream) {
@@ -369,6 +381,40 @@ extern "C" int mpnn_route(const mpnn_route_args *args, void *stream) {
     if (per * 64 + fix <= cap)      hipLaunchKernelGGL(route_k<64>, dim3((n + 63) / 64), dim3(RT_THREADS), per * 64 + fix, st, *args);
     else if (per * 32 + fix <= cap) hipLaunchKernelGGL(route_k<32>, dim3((n + 31) / 32), dim3(RT_THREADS), per * 32 + fix, st, *args);
     else if (per * 16 + fix <= cap) hipLaunchKernelGGL(route_k<16>, dim3((n + 15) / 16), dim3(RT_THREADS), per * 16 + fix, st, *args);
+    else return MPNN_E_SHAPE;
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+// mpnn_route for `count` nets with the same tree shape and batch size (host_table: the records, to size the launch;
+// dev_table: the same records in device memory).
+extern "C" int mpnn_route_multi(const mpnn_route_args *host_table, const mpnn_route_args *dev_table, int count, void *stream) {
+    if (count <= 0) return 0;
+    if (!host_table || !dev_table) return MPNN_E_ARG;
+    const mpnn_route_args *args = host_table;
+    for (int k = 0; k < count; ++k) {
+        const mpnn_route_args &b = host_table[k];
+        if (!b.nodes || !b.p_tr || !b.p_ev) return MPNN_E_ARG;
+        if (b.n != args->n || b.n_nodes != args->n_nodes || b.n_switches != args->n_switches || b.n_leaves != args->n_leaves ||
+            b.max_sinks != args->max_sinks) return MPNN_E_ARG;
+    }
+    if (args->n_nodes > MPNN_MAX_NODES || args->max_sinks > MPNN_MAX_SINKS) return MPNN_E_SHAPE;
+    if (args->n <= 0) return 0;
+    const size_t per = (size_t)(4 * args->n_nodes + 2 * args->n_switches * args->max_sinks + args->n_switches + 2 * args->n_leaves) * 4;
+    const size_t fix = (size_t)(args->n_nodes * 5 + 8 + args->n_switches) * 4;
+    const size_t cap = 160 * 1024;
+    const hipStream_t st = (hipStream_t)stream;
+    const int n = args->n;
+    static bool raised = false;
+    if (!raised) {
+        hipFuncSetAttribute((const void *)route_multi_k<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        hipFuncSetAttribute((const void *)route_multi_k<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        hipFuncSetAttribute((const void *)route_multi_k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap);
+        raised = true;
+    }
+    if (per * 64 + fix <= cap)      { const int w = (n + 63) / 64; hipLaunchKernelGGL(route_multi_k<64>, dim3(w * count), dim3(RT_THREADS), per * 64 + fix, st, dev_table, w); }
+    else if (per * 32 + fix <= cap) { const int w = (n + 31) / 32; hipLaunchKernelGGL(route_multi_k<32>, dim3(w * count), dim3(RT_THREADS), per * 32 + fix, st, dev_table, w); }
+    else if (per * 16 + fix <= cap) { const int w = (n + 15) / 16; hipLaunchKernelGGL(route_multi_k<16>, dim3(w * count), dim3(RT_THREADS), per * 16 + fix, st, dev_table, w); }
     else return MPNN_E_SHAPE;
     MPNN_LAUNCH_CHECK();
     return 0;

@@ -352,16 +352,15 @@ extern "C" int mpnn_backward_finish(const float *slabs, float *grads, const int 
 //   [.., + n_plain)           an optimizer work item whose gradient is already final in `grads` (exit parameters,
 //                             tensors whose weight gradient was written without slabs)
 // Same arithmetic, element for element, as the two launches it replaces.
-__global__ __launch_bounds__(256) void finish_opt_k(const float *__restrict__ slabs, const int *__restrict__ slab_table,
-                                                    int n_items, const int *__restrict__ item_seg,
-                                                    double *__restrict__ sums, double *__restrict__ reds,
-                                                    float *__restrict__ state, const int *__restrict__ bn_table, int n_bn,
-                                                    const int *__restrict__ bn_opt, float decay, int n_img,
-                                                    double *__restrict__ sums_keep, const OptP o,
-                                                    const int *__restrict__ plain_seg) {
+__device__ __forceinline__ void finish_opt_body(const int b, const float *__restrict__ slabs, const int *__restrict__ slab_table,
+                                                int n_items, const int *__restrict__ item_seg,
+                                                double *__restrict__ sums, double *__restrict__ reds,
+                                                float *__restrict__ state, const int *__restrict__ bn_table, int n_bn,
+                                                const int *__restrict__ bn_opt, float decay, int n_img,
+                                                double *__restrict__ sums_keep, const OptP &o,
+                                                const int *__restrict__ plain_seg) {
     __shared__ float wl[2048];
     __shared__ float gl[MPNN_SLAB_ITEM];
-    const int b = blockIdx.x;
     if (b < n_items) {
         slab_item(slabs, const_cast<float *>(o.grads), slab_table + b * 6, gl);
         __syncthreads();
@@ -382,6 +381,28 @@ __global__ __launch_bounds__(256) void finish_opt_k(const float *__restrict__ sl
     }
 }
 
+__global__ __launch_bounds__(256) void finish_opt_k(const float *__restrict__ slabs, const int *__restrict__ slab_table,
+                                                    int n_items, const int *__restrict__ item_seg,
+                                                    double *__restrict__ sums, double *__restrict__ reds,
+                                                    float *__restrict__ state, const int *__restrict__ bn_table, int n_bn,
+                                                    const int *__restrict__ bn_opt, float decay, int n_img,
+                                                    double *__restrict__ sums_keep, const OptP o,
+                                                    const int *__restrict__ plain_seg) {
+    finish_opt_body(blockIdx.x, slabs, slab_table, n_items, item_seg, sums, reds, state, bn_table, n_bn, bn_opt, decay, n_img,
+                    sums_keep, o, plain_seg);
+}
+
+// Several nets in one launch (co-training, lib/_co.py): wpn workgroups per net (the largest net's count; the others'
+// surplus workgroups exit), net r's arguments in the device record tab[r].
+__global__ __launch_bounds__(256) void finish_opt_multi_k(const mpnn_finish_net *__restrict__ tab, const int wpn, const float decay) {
+    const int net = blockIdx.x / wpn, b = blockIdx.x - net * wpn;
+    const mpnn_finish_net f = tab[net];             // (by value: every field's scalar load in the entry block)
+    if (b >= f.n_items + f.n_bn + f.n_plain) return;
+    const OptP o = {f.params, f.accum, f.grads, f.node_stat, f.hyp, f.talr, f.inv_n, f.grad_scale, f.w_eq, f.packs};
+    finish_opt_body(b, f.slabs, f.slab_table, f.n_items, f.item_seg, f.sums, f.reds, f.state, f.bn_table, f.n_bn, f.bn_opt,
+                    decay, f.n_img, f.sums_keep, o, f.plain_seg);
+}
+
 extern "C" int mpnn_backward_finish_opt(const float *slabs, const int *slab_table, int n_items, const int *item_seg,
                                         double *sums, double *reds, float *state, const int *bn_table, int n_bn,
                                         const int *bn_opt, float decay, int n_img, double *sums_keep,
@@ -395,6 +416,25 @@ extern "C" int mpnn_backward_finish_opt(const float *slabs, const int *slab_tabl
     const OptP o = {params, accum, grads, node_stat, hyp, talr, inv_n, grad_scale, w_eq, packs};
     hipLaunchKernelGGL(finish_opt_k, dim3(n_items + n_bn + n_plain), dim3(256), 0, (hipStream_t)stream, slabs, slab_table,
                        n_items, item_seg, sums, reds, state, bn_table, n_bn, bn_opt, decay, n_img, sums_keep, o, plain_seg);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mpnn_backward_finish_opt_multi(const mpnn_finish_net *host_table, const mpnn_finish_net *dev_table, int count,
+                                              float decay, void *stream) {
+    if (count <= 0) return 0;
+    if (!host_table || !dev_table) return MPNN_E_ARG;
+    int wpn = 0;
+    for (int k = 0; k < count; ++k) {
+        const mpnn_finish_net &f = host_table[k];
+        if (f.n_items < 0 || f.n_bn < 0 || f.n_plain < 0) return MPNN_E_ARG;
+        if ((f.n_items && (!f.slabs || !f.slab_table || !f.item_seg)) || (f.n_bn && (!f.bn_table || !f.bn_opt)) ||
+            (f.n_plain && !f.plain_seg) || !f.params || !f.accum || !f.grads || !f.node_stat || !f.hyp) return MPNN_E_ARG;
+        const int w = f.n_items + f.n_bn + f.n_plain;
+        if (w > wpn) wpn = w;
+    }
+    if (wpn == 0) return 0;
+    hipLaunchKernelGGL(finish_opt_multi_k, dim3(wpn * count), dim3(256), 0, (hipStream_t)stream, dev_table, wpn, decay);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

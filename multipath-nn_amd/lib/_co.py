@@ -1,0 +1,186 @@
+"""Co-training: the nets of one experiment advance TOGETHER, one launch per layer for all of them.
+
+The reference trains the nets of an experiment one after another, each at batch 128 (scripts/train-nets:81-88,159-164:
+eight `ac_chain(k_cpt=k)` of one architecture).  One net x 128 images cannot fill 256 compute units: three quarters of
+every launch of its step are ramp (dispatch, coefficient tables, first tile), which is why the single-net step sits at
+0.20 of the fp32 MFMA peak while the same kernels reach 0.50 at 4 096 images.  The batch-wide BatchNorm
+statistics put a grid-wide dependency between consecutive layers, so the depth of a step cannot shrink -- but its WIDTH
+can: K nets of one architecture have the same launch list, and launch j of every net is independent of launch j of the
+others.
+
+``CoTrainer(nets)`` keeps one ``Engine`` per net -- its own parameters, momentum, gradients, BatchNorm statistics,
+activations and batch of 128: reference semantics per net, untouched -- and builds ONE program whose launch j is launch j
+of all K nets: the table-driven kernels take the concatenated records (`mpnn_msconv_fwd_group_rep`,
+`mpnn_msconv_bwd_level_rep`, `mpnn_route_multi`, `mpnn_backward_finish_opt_multi`; the exit-path kernels already take any
+number of records).  The dependency depth stays 33 launches; the work per launch grows K-fold.  The program replays as
+one hipGraph.
+
+What changes per net against training it alone: the planner budgets every net's workgroups against resident slots / K,
+so the pixel split of the weight gradients (the slabs) differs and the conv gradients agree with the solo step to fp32
+summation order, not bit for bit (tests/test_cotrain.py holds them to the whole-net tolerances and to the oracle's).
+"""
+import ctypes as C
+
+import torch
+
+from lib import _hip
+from lib._plan import CAPTURE_MODE
+
+
+class CoTrainer:
+    def __init__(self, nets):
+        if len(nets) < 1:
+            raise ValueError('CoTrainer needs at least one net')
+        self.nets = list(nets)
+        self.engs = [net.engine() for net in self.nets]
+        e0 = self.engs[0]
+        for e in self.engs:
+            if type(e).__name__ != 'Engine':
+                raise NotImplementedError('co-training covers the multiscale chain / tree engine (lib/_plan.py)')
+            if e.allreduce is not None or e.multi_stream or e.generic_exits or not e.fuse_opt or not e.bwd_levels or not e.group_fwd:
+                raise NotImplementedError('co-training runs the single-process, single-stream, fused-optimizer schedule '
+                                          'with the tuned exit kernels')
+            if e.dev != e0.dev:
+                raise ValueError('co-trained nets live on one device')
+        self.lib, self.dev = e0.lib, e0.dev
+        self.K = len(self.nets)
+        self.use_graph = e0.use_graph
+        self._progs, self._graphs, self._keep = {}, {}, []
+
+    # ------------------------------------------------------------------ the merged program
+    def _program(self, n):
+        if n in self._progs:
+            return self._progs[n]
+        K, lib, keep = self.K, self.lib, self._keep
+        progs = []
+        for e in self.engs:
+            e.co_share = K
+            progs.append(e.program('tr', n))
+        skip = ('fork', 'join')
+        lists = [[op for op in list(p['fwd']) + list(p['bwd']) if op.what not in skip] for p in progs]
+        sig = [[(op.what, op.tag) for op in ops] for ops in lists]
+        if any(s != sig[0] for s in sig[1:]) or any(bool(p.get('fold')) != bool(progs[0].get('fold')) for p in progs) or \
+                not all(p.get('fused_opt') for p in progs):
+            raise NotImplementedError('co-trained nets must have the same architecture (identical launch lists)')
+
+        def launch_of(fn, what, flops, tag, *args):
+            def launch(st):
+                _hip.check(fn(*args, st), what)
+            launch.what, launch.flops, launch.tag, launch.args = what, flops, tag, args
+            return launch
+
+        def table(records):
+            t = _hip.to_device_table(records, self.dev)
+            keep.append(t)
+            return t
+
+        merged = []
+        for j, ops in enumerate(zip(*lists)):
+            o0 = ops[0]
+            what, tag, flops = o0.what, o0.tag, sum(o.flops for o in ops)
+            if what == 'fwd_group':
+                cnt = o0.args[2]
+                arr = (_hip.ConvFwdArgs * (cnt * K))()
+                for r, o in enumerate(ops):
+                    for k in range(cnt):
+                        arr[r * cnt + k] = o.args[0][k]
+                dev = table(list(arr))
+                keep.append(arr)
+                merged.append(launch_of(lib.mpnn_msconv_fwd_group_rep, what, flops, tag, arr, dev.data_ptr(), cnt, K))
+            elif what in ('lin_fwd', 'exit_tail_fwd', 'exit_tail_bwd', 'lin_bwd'):
+                recs = [r for o in ops for r in o.host]
+                dev = table(recs)
+                merged.append(launch_of(o0.fn, what, flops, tag, dev.data_ptr(), len(recs), *o0.args[2:]))
+            elif what == 'route':
+                arr = (_hip.RouteArgs * K)(*[o.host for o in ops])
+                dev = table(list(arr))
+                keep.append(arr)
+                merged.append(launch_of(lib.mpnn_route_multi, what, flops, tag, arr, dev.data_ptr(), K))
+            elif what == 'bwd_scale':
+                if o0.fn is not lib.mpnn_msconv_bwd_level:
+                    raise NotImplementedError('co-training: a backward launch is not in its table-driven form')
+                cnt = o0.args[1]
+                mem = (_hip.BwdMember * (cnt * K))()
+                for r, o in enumerate(ops):
+                    for k in range(cnt):
+                        mem[r * cnt + k] = o.args[0][k]
+                rec_bytes = lib.mpnn_msconv_bwd_level_record_size()
+                host = (C.c_char * (rec_bytes * cnt * K))()
+                _hip.check(lib.mpnn_msconv_bwd_level_prepare_rep(mem, cnt, K, C.cast(host, C.c_void_p)), 'bwd_level records (co-training)')
+                dev = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.dev)
+                keep += [mem, dev]
+                merged.append(launch_of(lib.mpnn_msconv_bwd_level_rep, what, flops, tag, mem, cnt, K, dev.data_ptr()))
+            elif what == 'backward_finish':
+                arr = (_hip.FinishNet * K)(*[p['finish_net'] for p in progs])
+                dev = table(list(arr))
+                keep.append(arr)
+                merged.append(launch_of(lib.mpnn_backward_finish_opt_multi, what, flops, tag, arr, dev.data_ptr(), K,
+                                        float(self.engs[0].bn_decay)))
+            else:
+                raise NotImplementedError('co-training: launch %r has no multi-net form' % what)
+        prog = dict(ops=merged, n=n, fold=bool(progs[0].get('fold')))
+        self._progs[n] = prog
+        return prog
+
+    # ------------------------------------------------------------------ running
+    def _eager(self, prog):
+        st = torch.cuda.current_stream().cuda_stream
+        for e in self.engs:
+            if e.prologue is not None:
+                e.prologue(st)
+            if not (prog['fold'] and e._acc_clean):
+                e._begin(True)
+            e._acc_clean = False
+        for op in prog['ops']:
+            op(st)
+        for e in self.engs:
+            e._acc_clean = prog['fold']
+
+    def run(self, feeds):
+        """One training step of every net: feeds[i] is net i's feed (as for ``net.train.run``)."""
+        if len(feeds) != self.K:
+            raise ValueError('one feed per co-trained net')
+        ns = set()
+        for e, net, feed in zip(self.engs, self.nets, feeds):
+            n, mode = e._stage(feed)
+            if mode != 'tr':
+                raise ValueError("co-training needs net.mode: 'tr' in every feed")
+            ns.add(n)
+            if not e._packs_fresh:
+                e._pack()
+                e._packs_fresh = True
+        if len(ns) != 1:
+            raise ValueError('co-trained nets step on batches of one size')
+        n = ns.pop()
+        prog = self._program(n)
+        g = self._graphs.get(n) if self.use_graph else None
+        if not self.use_graph or g is None:
+            self._eager(prog)                              # (first call: loads the code objects)
+            if self.use_graph:
+                self._graphs[n] = 'warm'
+        else:
+            if g == 'warm':
+                torch.cuda.synchronize()
+                for e in self.engs:                        # (captured without clearing launches)
+                    if prog['fold'] and not e._acc_clean:
+                        e._begin(True)
+                        e._acc_clean = True
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                    self._eager(prog)
+                self._graphs[n] = g
+            for e in self.engs:
+                if prog['fold'] and not e._acc_clean:      # something outside run() left the accumulators dirty
+                    e._begin(True)
+                e._acc_clean = False
+            g.replay()
+            for e in self.engs:
+                e._acc_clean = prog['fold']
+        for e in self.engs:
+            e.last_n, e.last_mode, e._last_fold = n, 'tr', prog['fold']
+            e._bind_views(n)
+
+    def invalidate(self):
+        """Drop the merged programs and graphs (an engine reallocated its buffers: a larger batch came by)."""
+        self._progs.clear()
+        self._graphs.clear()

@@ -140,11 +140,23 @@ class RouteArgs(C.Structure):
                 ('node_stat', P), ('loss', P), ('n', C.c_int), ('n_total', C.c_int)]
 
 
+class FinishNet(C.Structure):
+    _fields_ = [('slabs', P), ('slab_table', P), ('n_items', C.c_int), ('item_seg', P),
+                ('sums', P), ('reds', P), ('state', P), ('bn_table', P), ('n_bn', C.c_int), ('bn_opt', P), ('n_img', C.c_int),
+                ('sums_keep', P), ('params', P), ('accum', P), ('grads', P), ('node_stat', P), ('hyp', P), ('talr', C.c_int),
+                ('inv_n', C.c_float), ('grad_scale', C.c_float), ('w_eq', P), ('packs', P), ('plain_seg', P), ('n_plain', C.c_int)]
+
+
 _SIGS = {
     'mpnn_pack_weights': [P, P, P, C.c_int, P],
     'mpnn_step_begin': [P, P, P, C.c_int, P, C.c_long, P],
     'mpnn_msconv_fwd': [C.POINTER(ConvFwdArgs), P],
     'mpnn_msconv_fwd_group': [C.POINTER(ConvFwdArgs), P, C.c_int, P],
+    'mpnn_msconv_fwd_group_rep': [C.POINTER(ConvFwdArgs), P, C.c_int, C.c_int, P],
+    'mpnn_msconv_bwd_level_prepare_rep': [C.POINTER(BwdMember), C.c_int, C.c_int, P],
+    'mpnn_msconv_bwd_level_rep': [C.POINTER(BwdMember), C.c_int, C.c_int, P, P],
+    'mpnn_route_multi': [C.POINTER(RouteArgs), P, C.c_int, P],
+    'mpnn_backward_finish_opt_multi': [C.POINTER(FinishNet), P, C.c_int, C.c_float, P],
     'mpnn_debug_set_trace': [P],
     'mpnn_backward_finish': [P, P, P, C.c_int, P, P, P, P, C.c_int, C.c_float, C.c_int, P, P],
     'mpnn_augment_batch': [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P],

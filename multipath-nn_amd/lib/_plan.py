@@ -131,6 +131,10 @@ class Engine:
         self.prologue = None             # callable(stream): first launch of every training step (the input pipeline)
         # single process: the launch that ends the backward pass also applies the update (mpnn_backward_finish_opt)
         self.fuse_opt = bool(int(os.environ.get('MPNN_FUSE_OPT', '1')))
+        # co-training (lib/_co.py): this net shares every launch of its training step with co_share - 1 other nets of the
+        # same architecture -- the planner budgets workgroups against resident slots / co_share and every backward
+        # launch takes the table-driven (level) form, whose records the co-trainer concatenates over the nets
+        self.co_share = 1
         self._keep = []
         self._progs = {}
         self._graphs = {}
@@ -646,8 +650,16 @@ class Engine:
                     else:
                         rest.append(m)
                 pend = rest
-                bud = self._level_budget(grp, n) if len(grp) > 1 else None
-                if bud is None:
+                bud = self._level_budget(grp, n) if (len(grp) > 1 or self.co_share > 1) else None
+                if bud is None and self.co_share > 1 and len(grp) > 1:
+                    # (the members do not fit slots / co_share together: one table-driven launch each)
+                    buds = [self._level_budget([m], n) for m in grp]
+                    if any(b is None for b in buds):
+                        raise NotImplementedError('co-training %d nets: a backward launch does not fit the resident slots' % self.co_share)
+                    groups += [[(m, b[0])] for m, b in zip(grp, buds)]
+                elif bud is None and self.co_share > 1:
+                    raise NotImplementedError('co-training %d nets: a backward launch does not fit the resident slots' % self.co_share)
+                elif bud is None:
                     groups += [[(m, None)] for m in grp]
                 else:
                     groups.append(list(zip(grp, bud)))
@@ -671,6 +683,7 @@ class Engine:
         slots = lib.mpnn_msconv_bwd_level_slots(H, W, Co, len(grp))
         if slots <= 0:
             return None
+        slots //= self.co_share
         bodies = []                                          # (member, kind, rows, tiles, latency per item)
         for k, (kb, b, i) in enumerate(grp):
             tiles = lib.mpnn_wgrad_tiles(n, b.H[i], b.W[i])
@@ -765,7 +778,7 @@ class Engine:
             raise NotImplementedError('data-parallel training runs on the single-stream schedule (MPNN_STREAMS=0)')
         dp = mode == 'tr' and self.allreduce is not None
         reserve = self.dp_reserve_cus if (dp and len(self.dp_buckets) > 1) else 0
-        key = (mode, n, self.multi_stream, self.group_fwd, routed, dp, self.bwd_levels, self.fold_clear, reserve, self.fuse_opt)
+        key = (mode, n, self.multi_stream, self.group_fwd, routed, dp, self.bwd_levels, self.fold_clear, reserve, self.fuse_opt, self.co_share)
         if key in self._progs:
             return self._progs[key]
         self._ensure_capacity(n, mode == 'tr')
@@ -783,12 +796,12 @@ class Engine:
 
         cur_reserve = [0]                     # compute units the launches being built leave free (see below: trunk backward)
 
-        def call(fn, what, *args, flops=0.0, tag='', stream=0, waits=(), records=None):
+        def call(fn, what, *args, flops=0.0, tag='', stream=0, waits=(), records=None, host=None):
             def launch(st):
                 _hip.check(fn(*args, st), what)
             launch.what, launch.flops, launch.tag = what, float(flops), tag
             launch.stream, launch.waits, launch.records = stream, tuple(waits), records
-            launch.args = args
+            launch.args, launch.fn, launch.host = args, fn, host        # (host: the launch's records in host memory, for lib/_co.py)
             launch.reserve = cur_reserve[0]
             return launch
 
@@ -962,14 +975,14 @@ class Engine:
             fwd.append(call(lib.mpnn_exit_tail_fwd_gen, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n))
         elif n_exit:
             if n <= 512:
-                fwd.append(call(lib.mpnn_lin_fwd_ks, 'lin_fwd', t_lf.data_ptr(), n_exit, n, kmax))
+                fwd.append(call(lib.mpnn_lin_fwd_ks, 'lin_fwd', t_lf.data_ptr(), n_exit, n, kmax, host=lin_f))
             else:
-                fwd.append(call(lib.mpnn_lin_fwd, 'lin_fwd', t_lf.data_ptr(), n_exit, n))
-            fwd.append(call(lib.mpnn_exit_tail_fwd, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n))
+                fwd.append(call(lib.mpnn_lin_fwd, 'lin_fwd', t_lf.data_ptr(), n_exit, n, host=lin_f))
+            fwd.append(call(lib.mpnn_exit_tail_fwd, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n, host=tail_f))
 
         # ---- route ----
         ra = self._route_args(n, mode, self.loss)
-        fwd.append(call(lib.mpnn_route, 'route', C.byref(ra)))
+        fwd.append(call(lib.mpnn_route, 'route', C.byref(ra), host=ra))
 
         prog = dict(fwd=fwd, bwd=bwd, n=n, mode=mode, fold=fold)
         self._progs[key] = prog
@@ -983,8 +996,8 @@ class Engine:
             bwd.append(call(lib.mpnn_exit_tail_bwd_gen, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
             bwd.append(call(lib.mpnn_lin_bwd_gen, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
         elif n_exit:
-            bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
-            bwd.append(call(lib.mpnn_lin_bwd_rs if n <= 512 else lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
+            bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n, host=tail_b))
+            bwd.append(call(lib.mpnn_lin_bwd_rs if n <= 512 else lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax, host=lin_b))
         if dp and 'exit' in self.dp_buckets:
             bwd.append(marker('bucket', 'exit'))       # head + router gradients are final: their all-reduce starts here
         # From here to the end of the backward pass a bucket's all-reduce runs beside the launches: their persistent
@@ -1219,6 +1232,15 @@ class Engine:
                 t_plain = torch.from_numpy(np.concatenate(plain) if plain else np.zeros(_hip.SEG_INTS, np.int32)).to(self.dev)
                 keep += [t_seg, t_bno, t_plain]
                 talr = 1 if (self.net._net_kind != 'sr' and getattr(self.net.hypers, 'talr', False)) else 0
+                fin = _hip.FinishNet()
+                fin.slabs, fin.slab_table, fin.n_items, fin.item_seg = slab.data_ptr(), tab.data_ptr(), n_items, t_seg.data_ptr()
+                fin.sums, fin.reds, fin.state = self.dsum.data_ptr(), self.dred.data_ptr(), self.S.data_ptr()
+                fin.bn_table, fin.n_bn, fin.bn_opt, fin.n_img, fin.sums_keep = self.bn_table.data_ptr(), self.n_bn, t_bno.data_ptr(), n, keep_ptr
+                fin.params, fin.accum, fin.grads = self.P.data_ptr(), self.A.data_ptr(), self.G.data_ptr()
+                fin.node_stat, fin.hyp, fin.talr, fin.inv_n, fin.grad_scale = self.node_stat.data_ptr(), self.hyp.data_ptr(), talr, 1.0 / n, 1.0
+                fin.w_eq, fin.packs = (self.w_eq.data_ptr() if self.w_eq is not None else None), self.packs.data_ptr()
+                fin.plain_seg, fin.n_plain = t_plain.data_ptr(), len(plain)
+                prog['finish_net'] = fin                   # (the same arguments as one record: lib/_co.py)
                 bwd.append(call(lib.mpnn_backward_finish_opt, 'backward_finish', slab.data_ptr(), tab.data_ptr(), n_items,
                                 t_seg.data_ptr(), self.dsum.data_ptr(), self.dred.data_ptr(), self.S.data_ptr(),
                                 self.bn_table.data_ptr(), self.n_bn, t_bno.data_ptr(), self.bn_decay, n, keep_ptr,

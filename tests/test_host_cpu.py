@@ -39,7 +39,8 @@ def test_ctypes_structs_match_the_c_layout():
              ('mpnn_lin_bwd_args', _hip.LinBwdArgs), ('mpnn_exit_tail_args', _hip.ExitTailArgs),
              ('mpnn_exit_tail_bwd_args', _hip.ExitTailBwdArgs), ('mpnn_route_args', _hip.RouteArgs),
              ('mpnn_exit_ev_args', _hip.ExitEvArgs), ('mpnn_conv_nhwc_fwd_args', _hip.ConvNhwcFwdArgs),
-             ('mpnn_conv_nhwc_dgrad_args', _hip.ConvNhwcDgradArgs), ('mpnn_conv_nhwc_wgrad_args', _hip.ConvNhwcWgradArgs)]
+             ('mpnn_conv_nhwc_dgrad_args', _hip.ConvNhwcDgradArgs), ('mpnn_conv_nhwc_wgrad_args', _hip.ConvNhwcWgradArgs),
+             ('mpnn_finish_net', _hip.FinishNet)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mpnn_hip.h"', 'int main(void){']
     for cname, cls in pairs:
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))

@@ -74,7 +74,7 @@ def rel(a, b):
     return np.abs(a - b).max() / (1e-12 + np.abs(b).max())
 
 
-def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL, n_cls=10):
+def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL, n_cls=10, stepper=None):
     """Teacher-forced: before every step the oracle is re-synchronised from the product's
     parameters, momentum accumulators and BatchNorm state, so each step checks one
     forward + backward + TALR/momentum update from IDENTICAL state.  (A free-running
@@ -88,6 +88,9 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL, n_cls=1
         perturb_routers(net)
     ref = RefNet(net)
     lr = 0.05
+    # stepper(net) -> callable(feed): how a training step of THIS net is run (default: net.train.run; the co-training
+    # tests step it together with other nets, tests/test_cotrain.py)
+    train_step = net.train.run if stepper is None else stepper(net)
     worst = {'grad': 0.0, 'update': 0.0}
     flips_total = decisions_total = 0
     for t in range(steps):
@@ -107,7 +110,7 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL, n_cls=1
         # the engine's G holds the DATA gradient; the L2 term 2*k_l2*mean(p_tr)*w is folded into
         # mpnn_talr_momentum_step, so add it here from the pre-step weights before comparing
         before = {id(p): p.data.clone() for p in net._all_params}
-        net.train.run(feed)
+        train_step(feed)
         torch.cuda.synchronize()
         from oracle.decisions import from_product
         # UNFORCED float64 forward first (the oracle still holds the pre-step parameters): the device's own
