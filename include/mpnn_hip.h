@@ -140,7 +140,9 @@ int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_ar
  * [r * count, (r + 1) * count) -- identical shapes and modes, every pointer net r's own (its batch, its parameters, its
  * BatchNorm statistics).  Per net the arithmetic is that of the single-net launch on resident slots / reps. */
 int mpnn_msconv_fwd_group_rep(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
-                              int reps, void *stream);
+                              int reps, int share, void *stream);
+/* (share: every net's grid is sized for resident slots / share; <= 0 means reps.  reps = 1 with share = K launches ONE net
+ * with exactly the grid it has inside a joint launch of K.) */
 
 /* ---- BatchNorm(+ReLU) backward pieces ------------------------------------
  * Backward of `y = relu(gamma * (s - m) / sqrt(v + eps) + beta)` THROUGH the

@@ -219,17 +219,17 @@ __global__ __launch_bounds__(256) void fwd_first_k(const FirstP p0, const mpnn_c
     }
 }
 
-static int first_conv_launch(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, hipStream_t st);
+static int first_conv_launch(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, int share, hipStream_t st);
 
 // Takes the launch if the record is the first conv of a net (see the top of the file); 0 = launched, 1 = not mine.
-int mpnn_first_conv_launch(const mpnn_conv_fwd_args *a, hipStream_t st) { return first_conv_launch(a, nullptr, 1, st); }
+int mpnn_first_conv_launch(const mpnn_conv_fwd_args *a, hipStream_t st) { return first_conv_launch(a, nullptr, 1, 1, st); }
 // ... of `reps` nets at once: a = net 0's record (the others have its shapes: checked by the caller), dev_args = the
-// reps records in device memory.
-int mpnn_first_conv_launch_rep(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, hipStream_t st) {
-    return first_conv_launch(a, dev_args, reps, st);
+// reps records in device memory; every net's grid is sized for resident slots / share.
+int mpnn_first_conv_launch_rep(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, int share, hipStream_t st) {
+    return first_conv_launch(a, dev_args, reps, share, st);
 }
 
-static int first_conv_launch(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, hipStream_t st) {
+static int first_conv_launch(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, int share, hipStream_t st) {
     static const int on = [] { const char *e = getenv("MPNN_FIRST_CONV"); return e ? atoi(e) : 1; }();
     if (!on || a->idx || a->cnt || a->v || a->Cout != 16 || a->a.C < 1 || a->a.C > 3 || a->a.shift != 0 ||
         a->a.mode != MPNN_ACT_IDENTITY) return 1;
@@ -247,7 +247,7 @@ static int first_conv_launch(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_ar
                                        : (pool ? fwd_first_k<false, true, true> : fwd_first_k<false, false, true>))
                               : (stats ? (pool ? fwd_first_k<true, true> : fwd_first_k<true, false>)
                                        : (pool ? fwd_first_k<false, true> : fwd_first_k<false, false>));
-    long wgs = resident_slots((const void *)kern, 0) / reps;
+    long wgs = resident_slots((const void *)kern, 0) / share;
     const long need = (p.n_tiles + 3) / 4;
     if (wgs > need) wgs = need;
     if (wgs < 1) wgs = 1;

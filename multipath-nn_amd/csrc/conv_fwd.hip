@@ -99,21 +99,24 @@ __global__ __launch_bounds__(512) void fwd_ks_k(const mpnn_conv_fwd_args *__rest
     conv_body<GK, 1, 1, 4, 1, false, EPI_FWD, 2, true>(p, bx, yy, gx, smem);
 }
 
-int mpnn_first_conv_launch_rep(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, hipStream_t st);
+int mpnn_first_conv_launch_rep(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, int share, hipStream_t st);
 
-static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count, int reps, void *stream);
+static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count, int reps, int share, void *stream);
 
 extern "C" int mpnn_msconv_fwd_group(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
                                      void *stream) {
-    return fwd_group_launch(args, dev_args, count, 1, stream);
+    return fwd_group_launch(args, dev_args, count, 1, 1, stream);
 }
 
 // The same group for `reps` nets of one architecture in ONE launch (co-training, lib/_co.py): args / dev_args hold
 // reps * count records, net r's at [r * count, (r + 1) * count) -- identical shapes and modes, the buffers of net r.
-// The resident slots are shared between the nets; every net gets the grid the group would get on slots / reps.
+// The resident slots are shared between the nets; every net gets the grid the group would get on slots / share
+// (share <= 0: reps.  reps = 1 with share = K is the launch of ONE of K nets that take turns with the same grids --
+// the same per-workgroup tile runs, i.e. the same fp32 partial sums of the BatchNorm statistics, as in the joint launch).
 extern "C" int mpnn_msconv_fwd_group_rep(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count,
-                                         int reps, void *stream) {
+                                         int reps, int share, void *stream) {
     if (reps < 1) return MPNN_E_ARG;
+    if (share <= 0) share = reps;
     if (count <= 0) return 0;
     if (!args || count > 4) return MPNN_E_ARG;
     for (int r = 1; r < reps; ++r)
@@ -124,10 +127,10 @@ extern "C" int mpnn_msconv_fwd_group_rep(const mpnn_conv_fwd_args *args, const m
                 (a.pool_out != nullptr) != (b.pool_out != nullptr) || (a.out_sum != nullptr) != (b.out_sum != nullptr) ||
                 a.idx || b.idx || a.cnt || b.cnt) return MPNN_E_ARG;
         }
-    return fwd_group_launch(args, dev_args, count, reps, stream);
+    return fwd_group_launch(args, dev_args, count, reps, share, stream);
 }
 
-static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count, int reps, void *stream) {
+static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_args *dev_args, int count, int reps, int share, void *stream) {
     if (count <= 0) return 0;
     if (!args || !dev_args || count > 4) return MPNN_E_ARG;
     FwdGroupP q = {};
@@ -163,8 +166,8 @@ static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_
         rows += q.gy[k];
     }
     // the first conv of a net (image -> 16 channels, no operand V): its own wave-per-tile kernel (conv_first.hip)
-    if (count == 1 && reps == 1 && mpnn_first_conv_launch(&args[0], (hipStream_t)stream) == 0) return 0;
-    if (count == 1 && reps > 1 && mpnn_first_conv_launch_rep(&args[0], dev_args, reps, (hipStream_t)stream) == 0) return 0;
+    if (count == 1 && reps == 1 && share == 1 && mpnn_first_conv_launch(&args[0], (hipStream_t)stream) == 0) return 0;
+    if (count == 1 && (reps > 1 || share > 1) && mpnn_first_conv_launch_rep(&args[0], dev_args, reps, share, (hipStream_t)stream) == 0) return 0;
     // Share the resident workgroup slots between the members in proportion to their work, so that
     // every member is resident from the start.
     const int bytes[5] = {ConvSmem<0, 4, 16>::BYTES, ConvSmem<1, 4, 16>::BYTES, ConvSmem<2, 4, 16>::BYTES, 2048, strip_lds_bytes(MPNN_STRIP_KMAX)};
@@ -172,11 +175,12 @@ static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_
     for (int k = 0; k < count; ++k) if (bytes[q.gk[k]] > lds) lds = bytes[q.gk[k]];
     // a single deep member on a small map: 128-256 workgroups of 4 waves would leave every SIMD with one
     // wave and nothing to overlap -> K-split body (two thread groups per workgroup, 32-channel units)
-    static const int ks_env = [] { const char *e = getenv("MPNN_FWD_KSPLIT"); return e ? atoi(e) : 1; }();
+    // (read at every launch -- launches are issued once per captured graph --, so a test can switch it per engine)
+    const int ks_env = [] { const char *e = getenv("MPNN_FWD_KSPLIT"); return e ? atoi(e) : 1; }();
     // (training launches only: in the evaluation path the body of a conv depends on its shapes and its sample
     // capacity alone, so routed and dense evaluation of a batch agree bit for bit)
     // (one net only: with several nets in the launch there are workgroups enough for every SIMD)
-    if (ks_env && reps == 1 && !any_idx && hp[0].a.mode == MPNN_ACT_BN_BATCH && count == 1 && q.gk[0] != 0 && q.gk[0] < 3 && !q.small[0] && (hp[0].a.C % 32) == 0 && (hp[0].Cv % 32) == 0 &&
+    if (ks_env && reps == 1 && share == 1 && !any_idx && hp[0].a.mode == MPNN_ACT_BN_BATCH && count == 1 && q.gk[0] != 0 && q.gk[0] < 3 && !q.small[0] && (hp[0].a.C % 32) == 0 && (hp[0].Cv % 32) == 0 &&
         hp[0].a.C + hp[0].Cv >= 64) {
         const int gy = q.gy[0];
         int gx = hp[0].n_tiles;
@@ -205,7 +209,7 @@ static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_
         wide ? (any_idx ? fwd_group_k<false, true, true> : fwd_group_k<false, false, true>) :
         any_idx ? (any_small ? fwd_group_k<true, true> : fwd_group_k<false, true>)
                 : (any_small ? fwd_group_k<true, false> : fwd_group_k<false, false>);
-    long slots = resident_slots((const void *)kern, lds) / reps;
+    long slots = resident_slots((const void *)kern, lds) / share;
     if (slots < 1) slots = 1;
     // work of a member = tile-rows x units per tile (16-channel chunks of both operands)
     long total = 0, work[4];

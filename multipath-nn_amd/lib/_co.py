@@ -45,17 +45,24 @@ class CoTrainer:
         self.lib, self.dev = e0.lib, e0.dev
         self.K = len(self.nets)
         self.use_graph = e0.use_graph
-        self._progs, self._graphs, self._keep = {}, {}, []
+        self._progs, self._graphs, self._keep, self._gens = {}, {}, [], None
 
     # ------------------------------------------------------------------ the merged program
     def _program(self, n):
+        gens = tuple(e._gen for e in self.engs)
+        if self._progs and self._gens != gens:             # an engine reallocated its buffers (a larger batch came by)
+            self.invalidate()
         if n in self._progs:
             return self._progs[n]
         K, lib, keep = self.K, self.lib, self._keep
         progs = []
         for e in self.engs:
-            e.co_share = K
-            progs.append(e.program('tr', n))
+            e.co_share = K                                 # (a planner setting of THIS program only: the net's solo programs keep 1)
+            try:
+                progs.append(e.program('tr', n))
+            finally:
+                e.co_share = 1
+        self._gens = tuple(e._gen for e in self.engs)
         skip = ('fork', 'join')
         lists = [[op for op in list(p['fwd']) + list(p['bwd']) if op.what not in skip] for p in progs]
         sig = [[(op.what, op.tag) for op in ops] for ops in lists]
@@ -78,7 +85,9 @@ class CoTrainer:
         for j, ops in enumerate(zip(*lists)):
             o0 = ops[0]
             what, tag, flops = o0.what, o0.tag, sum(o.flops for o in ops)
-            if what == 'fwd_group':
+            if K == 1:
+                merged.append(o0)                          # (a group of one: the net's own launches)
+            elif what == 'fwd_group':
                 cnt = o0.args[2]
                 arr = (_hip.ConvFwdArgs * (cnt * K))()
                 for r, o in enumerate(ops):
@@ -86,7 +95,7 @@ class CoTrainer:
                         arr[r * cnt + k] = o.args[0][k]
                 dev = table(list(arr))
                 keep.append(arr)
-                merged.append(launch_of(lib.mpnn_msconv_fwd_group_rep, what, flops, tag, arr, dev.data_ptr(), cnt, K))
+                merged.append(launch_of(lib.mpnn_msconv_fwd_group_rep, what, flops, tag, arr, dev.data_ptr(), cnt, K, K))
             elif what in ('lin_fwd', 'exit_tail_fwd', 'exit_tail_bwd', 'lin_bwd'):
                 recs = [r for o in ops for r in o.host]
                 dev = table(recs)

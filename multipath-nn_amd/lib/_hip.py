@@ -152,7 +152,7 @@ _SIGS = {
     'mpnn_step_begin': [P, P, P, C.c_int, P, C.c_long, P],
     'mpnn_msconv_fwd': [C.POINTER(ConvFwdArgs), P],
     'mpnn_msconv_fwd_group': [C.POINTER(ConvFwdArgs), P, C.c_int, P],
-    'mpnn_msconv_fwd_group_rep': [C.POINTER(ConvFwdArgs), P, C.c_int, C.c_int, P],
+    'mpnn_msconv_fwd_group_rep': [C.POINTER(ConvFwdArgs), P, C.c_int, C.c_int, C.c_int, P],
     'mpnn_msconv_bwd_level_prepare_rep': [C.POINTER(BwdMember), C.c_int, C.c_int, P],
     'mpnn_msconv_bwd_level_rep': [C.POINTER(BwdMember), C.c_int, C.c_int, P, P],
     'mpnn_route_multi': [C.POINTER(RouteArgs), P, C.c_int, P],

@@ -503,6 +503,7 @@ class Engine:
             self.n_max = n
             self._progs.clear()
             self._graphs.clear()
+            self._gen = getattr(self, '_gen', 0) + 1       # (buffer generation: lib/_co.py rebuilds its merged program)
             self.n_max_bwd = 0
             h, w, c0 = self.x0_shape
             self.x0 = z(n, h, w, c0)
@@ -537,6 +538,7 @@ class Engine:
                 b.ev_cnt = self.ev_cnt[k:k + 1]
         if train and n > self.n_max_bwd:
             self.n_max_bwd = n
+            self._gen = getattr(self, '_gen', 0) + 1
             self._progs = {k: v for k, v in self._progs.items() if k[0] != 'tr'}
             self._graphs = {k: v for k, v in self._graphs.items() if k[0] != 'tr'}
             for b in self.blocks:
@@ -865,6 +867,11 @@ class Engine:
                         fwd_args(b, i, a)
                     dev_arr = _hip.to_device_table(list(arr), self.dev)
                     keep += [arr, dev_arr]
+                    if self.co_share > 1:
+                        # (one net of a co-trained group stepping by itself: the grids it has inside the joint launches)
+                        fwd.append(call(lib.mpnn_msconv_fwd_group_rep, 'fwd_group', arr, dev_arr.data_ptr(), len(grp), 1, self.co_share,
+                                        flops=sum(fl_f(b, i) for b, i in grp), tag=' | '.join(tag_f(b, i) for b, i in grp)))
+                        continue
                     fwd.append(call(lib.mpnn_msconv_fwd_group, 'fwd_group', arr, dev_arr.data_ptr(), len(grp),
                                     flops=sum(fl_f(b, i) for b, i in grp),
                                     tag=' | '.join(tag_f(b, i) for b, i in grp)))

@@ -139,36 +139,48 @@ class Dataset:
         self._y_ts_dev = torch.from_numpy(np.ascontiguousarray(self.y_ts, dtype=np.float32)).to(device)
         self._sym_u8 = np.ascontiguousarray(_sym_of_sources(self.y_tr, self.m_sym), dtype=np.uint8)
         self._all_sym = bool(self._sym_u8.all())
-        self._ring, self._slot, self._draw_dev = None, -1, None
+        self._bufs = {}
         return self
 
-    def stage_training_draws(self, n=128, r_shift=4):
-        """Draw one batch's augmentation records -- (j, flip, du, dv) per sample, the reference's numpy.random call
-        sequence (scripts/lib/data.py:24-34) -- and queue their upload into the static device buffer the augmentation
-        launch reads.  Asynchronous: a ring of pinned host buffers, each reused only after the event behind its last
-        copy has completed (under hipGraph replay the host runs several steps ahead of the stream)."""
+    def _draw_buffers(self, n, key=None):
+        """The static device record buffer + its ring of pinned upload buffers for one consumer (key None: the dataset's
+        own; an engine bound with bind_engine has its own set, so that several engines -- the nets of a co-trained
+        group -- each read the batch staged for THEM)."""
         import torch
         from . import _hip
         if getattr(self, '_x_dev', None) is None:
             raise _hip.HipError('Dataset.to_device() first: the augmentation kernel gathers from device memory')
-        if self._ring is None or self._ring[0][0].shape[0] < n:
-            self._ring = [(torch.zeros((n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING)]
-            self._draw_dev = torch.zeros((n, 4), dtype=torch.int32, device=self._dev)
-        k = self._slot = (self._slot + 1) % self.RING
-        buf, ev = self._ring[k]
+        bufs = self.__dict__.setdefault('_bufs', {})
+        b = bufs.get(key)
+        if b is None or b['ring'][0][0].shape[0] < n:
+            b = bufs[key] = dict(ring=[(torch.zeros((n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING)],
+                                 slot=-1, dev=torch.zeros((n, 4), dtype=torch.int32, device=self._dev))
+        return b
+
+    def stage_training_draws(self, n=128, r_shift=4, eng=None):
+        """Draw one batch's augmentation records -- (j, flip, du, dv) per sample, the reference's numpy.random call
+        sequence (scripts/lib/data.py:24-34) -- and queue their upload into the static device buffer the augmentation
+        launch reads (eng: the buffer of that bound engine).  Asynchronous: a ring of pinned host buffers, each reused only
+        after the event behind its last copy has completed (under hipGraph replay the host runs several steps ahead of the
+        stream)."""
+        import torch
+        b = self._draw_buffers(n, None if eng is None else id(eng))
+        k = b['slot'] = (b['slot'] + 1) % self.RING
+        buf, ev = b['ring'][k]
         if ev is not None:
             ev.synchronize()
         _draw_augmentation_fast(n, len(self.x0_tr), self._sym_u8, r_shift, out=buf.numpy()[:n], all_sym=self._all_sym)
-        self._draw_dev[:n].copy_(buf[:n], non_blocking=True)
+        b['dev'][:n].copy_(buf[:n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        self._ring[k] = (buf, ev)
-        return self._draw_dev
+        b['ring'][k] = (buf, ev)
+        return b['dev']
 
-    def _augment_launch(self, n, x_out, y_out, stream):
+    def _augment_launch(self, n, x_out, y_out, stream, draws=None):
         from . import _hip
         h, w, c = self.x0_tr.shape[1:]
-        _hip.check(_hip.load().mpnn_augment_batch(self._x_dev.data_ptr(), self._y_dev.data_ptr(), self._draw_dev.data_ptr(),
+        draws = self._draw_buffers(n)['dev'] if draws is None else draws
+        _hip.check(_hip.load().mpnn_augment_batch(self._x_dev.data_ptr(), self._y_dev.data_ptr(), draws.data_ptr(),
                                                   x_out.data_ptr(), y_out.data_ptr(), n, h, w, c, self.y_tr.shape[1], stream),
                    'augment_batch')
 
@@ -189,19 +201,17 @@ class Dataset:
         """Make the batch assembly the FIRST launch of the engine's training step (part of its hipGraph): every
         net.train.run then gathers the batch described by the latest stage_training_draws() straight into the
         engine's input buffers.  Returns the (x0, y) feed values (markers that name the engine's buffers)."""
-        import torch
         from ._plan import BoundInput
         if getattr(self, '_x_dev', None) is None:
             self.to_device(str(eng.dev))
         eng._ensure_capacity(n)
-        # the draw buffer and its upload ring, WITHOUT drawing: a draw here would consume a batch of the numpy stream and
-        # offset every later batch against the reference's call sequence (scripts/lib/data.py:24-34)
-        if self._ring is None or self._ring[0][0].shape[0] < n:
-            self._ring = [(torch.zeros((n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING)]
-            self._draw_dev = torch.zeros((n, 4), dtype=torch.int32, device=self._dev)
+        # the engine's own draw buffer and upload ring, allocated WITHOUT drawing: a draw here would consume a batch of the
+        # numpy stream and offset every later batch against the reference's call sequence (scripts/lib/data.py:24-34).
+        # Stage every step's records with stage_training_draws(n, eng=eng).
+        draws = self._draw_buffers(n, id(eng))['dev']
         # the engine's buffers are resolved when the launch is issued (eagerly or into a capture; the engine drops its
         # graphs whenever it reallocates them), never held as views: see _plan.BoundInput
-        eng.set_prologue(lambda stream: self._augment_launch(n, eng.x0[:n], eng.y[:n], stream))
+        eng.set_prologue(lambda stream: self._augment_launch(n, eng.x0[:n], eng.y[:n], stream, draws))
         return BoundInput(eng, 'x0', n), BoundInput(eng, 'y', n)
 
     def training_batch(self, n=128):

@@ -31,9 +31,13 @@ def _copy_state(src, dst):
 
 @pytest.mark.parametrize('kind,K,n', [('ac', 3, 32), ('cr', 2, 16), ('ac', 8, 128), ('sr', 3, 16)])
 def test_cotrained_step_equals_the_solo_step(kind, K, n):
-    """Every net of a co-trained group takes the step it would take alone from the same state: routing, costs and exit
-    gradients bit for bit (the same kernels on the same records), conv weight gradients to fp32 summation order (the
-    planner gives each net's weight-gradient launch 1/K of the slots, so the pixel split -- the slab count -- differs)."""
+    """Every net of a co-trained group takes the step it would take alone from the same state.  "Alone" with the planner
+    setting of the co-trained program (`Engine.co_share = K`: every launch gets the grid it has inside the joint launch
+    -- resident slots / K), so that the comparison is about the LAUNCH GROUPING and nothing else: the grids fix which
+    tiles a workgroup sums before its fp64 atomic (the BatchNorm statistics' fp32 partial sums), the pixel split of the
+    weight gradients (the slab count) and the forward body of the deep 4x4 convs (the K-split body, which a lone net
+    uses where a launch has too few workgroups, adds two partial sums per output).  Then everything agrees to the last
+    bits (hard decisions exactly; sums that meet in fp64 atomics to 1e-5 of the tensor's scale)."""
     import arch_and_hypers as A
     from lib._co import CoTrainer
     ks = A.k_cpts
@@ -41,6 +45,8 @@ def test_cotrained_step_equals_the_solo_step(kind, K, n):
     co_nets = _nets([mk(i) for i in range(K)])
     solo = _nets([mk(i) for i in range(K)])
     co = CoTrainer(co_nets)
+    for b in solo:
+        b.engine().co_share = K
     for t in range(4):                                        # eager, capture + replay, replays
         feeds_co, feeds_so = [], []
         for i, (a, b) in enumerate(zip(co_nets, solo)):
@@ -55,21 +61,20 @@ def test_cotrained_step_equals_the_solo_step(kind, K, n):
         for b, f in zip(solo, feeds_so):
             b.train.run(f)
         torch.cuda.synchronize()
+        close = lambda u, v: torch.allclose(u, v, rtol=1e-5, atol=1e-9)
         for i, (a, b) in enumerate(zip(co_nets, solo)):
             ea, eb = a.engine(), b.engine()
             for la, lb in zip(a.layers, b.layers):
-                assert torch.equal(la.p_tr, lb.p_tr) and torch.equal(la.p_ev, lb.p_ev), (t, i, la.name)
-            assert torch.equal(ea.loss, eb.loss) or kind == 'sr'
+                assert close(la.p_tr, lb.p_tr) and torch.equal(la.p_ev, lb.p_ev), (t, i, la.name)
+            assert close(ea.loss, eb.loss)
             for pa, pb in zip(ea.trainable, eb.trainable):
-                ga, gb = pa.grad.cpu().numpy().astype(np.float64), pb.grad.cpu().numpy().astype(np.float64)
-                assert np.abs(ga - gb).max() <= 2e-5 * np.abs(gb).max() + 1e-7, (t, i, pa.owner.name, pa.name)
-            da = (ea.P - before[i]).cpu().numpy().astype(np.float64)
-            db = (eb.P - before[i]).cpu().numpy().astype(np.float64)
+                ga, gb = pa.grad.double(), pb.grad.double()
+                assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()) + 1e-12, (t, i, pa.owner.name, pa.name)
+            da, db = (ea.P - before[i]).double(), (eb.P - before[i]).double()
             for pa in ea.trainable:
                 sl = slice(pa.offset, pa.offset + pa.size)
-                assert np.abs(da[sl] - db[sl]).max() <= 1e-4 * np.abs(db[sl]).max() + 1e-7, (t, i, pa.owner.name, pa.name)
-            assert torch.allclose(ea.S, eb.S, rtol=1e-5, atol=1e-7), (t, i, 'BatchNorm moving averages')
-            assert torch.equal(ea.A[:ea.stat_pad], eb.A[:eb.stat_pad])
+                assert float((da[sl] - db[sl]).abs().max()) <= 1e-5 * float(db[sl].abs().max()) + 1e-12, (t, i, pa.owner.name, pa.name)
+            assert torch.allclose(ea.S, eb.S, rtol=1e-6, atol=1e-9), (t, i, 'BatchNorm moving averages')
     # the weight packs the fused optimizer keeps current == a fresh packing of the parameters
     for a in co_nets:
         e = a.engine()
@@ -107,3 +112,62 @@ def test_cotrained_net_matches_the_oracle(kind, K, n):
             co.run(feeds)
         return step
     run_case(mk(k_cpt=1.6e-8), n, lambda net, t: {net.τ: tau(t * 5000)}, steps=3 if n <= 16 else 2, stepper=stepper)
+
+
+def test_train_nets_cli_co_train(tmp_path):
+    """train-nets --co-train 3: three nets of the experiment advance together through the input pipeline (each net its own
+    draws and its own on-device batch assembly as launch 0..2 of the joint graph), log and checkpoint like the serial loop,
+    and a statistics pass at 512 images between two steps (the engines' own evaluation programs) does not disturb the
+    joint program."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'nets')
+    cmd = [sys.executable, os.path.join(root, 'multipath-nn_amd', 'train-nets'), 'cifar10-ac', '--synthetic', '--iters', '6',
+           '--log-every', '3', '--nets', '0', '2', '5', '--co-train', '3', '--stats-batch', '512', '--out', out]
+    subprocess.check_call(cmd, cwd=str(tmp_path))
+    base = os.path.join(out, 'cifar10-ac')
+    for i in (0, 2, 5):
+        for f in ('%.4i.npy', '%.4i-stats.npy', '%.4i-log.txt', '%.4i-stats/00000003.npy', '%.4i-stats/00000006.npy'):
+            assert os.path.exists(os.path.join(base, f % i)), f % i
+        desc = np.load(os.path.join(base, '%.4i-stats.npy' % i), allow_pickle=True)[()]
+        assert desc['type'] == 'ActorNet' and 0 <= desc['stats_ts']['acc'] <= 1
+
+
+def test_cotrained_pipeline_feeds_each_net_its_own_batches():
+    """Co-trained nets bound to one Dataset: every net trains on the batch staged for IT (its own record buffer), the draws
+    come from the one numpy stream in net order, step after step -- also after a larger evaluation batch reallocated one
+    engine's input buffers between two steps (the joint program is rebuilt)."""
+    import arch_and_hypers as A
+    from lib._co import CoTrainer
+    from lib.data import Dataset
+    ds = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+    ref = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+    nets = _nets([A.ac_chain(k_cpt=k) for k in (0.0, 1e-9, 4e-9)])
+    engs = [net.engine() for net in nets]
+    n = 32
+    bound = [ds.bind_engine(e, n) for e in engs]
+    co = CoTrainer(nets)
+    np.random.seed(11)
+    want = []
+    state0 = np.random.get_state()
+    for t in range(5):
+        for k in range(3):
+            want.append(ref.augmented_training_batch(n))
+    np.random.set_state(state0)
+    for t in range(5):
+        feeds = []
+        for net, e, (x0, y) in zip(nets, engs, bound):
+            ds.stage_training_draws(n, eng=e)
+            feeds.append({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.01, net.τ: 1.0})
+        co.run(feeds)
+        torch.cuda.synchronize()
+        for k, e in enumerate(engs):
+            wx, wy = want[3 * t + k]
+            assert np.abs(e.x0[:n].cpu().numpy() - wx).max() <= 1e-6, (t, k)
+            assert np.array_equal(e.y[:n].cpu().numpy(), wy), (t, k)
+        if t == 2:
+            xb = torch.rand(n * 8, *ds.x0_shape, device='cuda')
+            yb = torch.zeros(n * 8, ds.y_shape[0], device='cuda'); yb[:, 0] = 1
+            nets[1].eval({nets[1].x0: xb, nets[1].y: yb})

@@ -265,7 +265,7 @@ def test_bound_input_pipeline_feeds_every_step_in_every_graph_form(form):
     np.random.seed(3)
     seen = []
     for t in range(6):
-        ds.stage_training_draws(n)
+        ds.stage_training_draws(n, eng=eng)
         net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.01, net.τ: 1.0})
         torch.cuda.synchronize()
         got = eng.x0[:n].cpu().numpy().copy()

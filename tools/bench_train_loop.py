@@ -47,7 +47,7 @@ x0, y = ds.bind_engine(eng, N)
 
 
 def bound(t):
-    ds.stage_training_draws(N)
+    ds.stage_training_draws(N, eng=eng)
     net.train.run(feed(x0, y, t))
 full = timed(bound, 'pipeline as train-nets runs it (draws + async upload; augmentation inside the step graph)')
 print('pipeline / resident: %.3f' % (full / base))
