@@ -223,6 +223,38 @@ def time_configs(dev, n, reps=200):
     return out
 
 
+def time_experiment(dev, n, single_ms, reps=100):
+    """The reference trains the 8 nets of an experiment -- ac_chain(k_cpt=k), k in k_cpts, scripts/train-nets:81-88 -- one
+    after another, each at batch 128 (:159-164).  Here the same 8 nets, each with its own batch, BatchNorm statistics and
+    parameters, advance TOGETHER: one hipGraph whose launch j is launch j of every net (lib/_co.py; `train-nets --co-train 8`).
+    Aggregate images/s of the 8 co-trained nets beside the serial rate (the single-net headline): the dependency depth
+    of a step stays 33 launches, the work per launch grows 8-fold."""
+    import arch_and_hypers as A
+    from lib._co import CoTrainer
+    nets, feeds = [], []
+    g = torch.Generator().manual_seed(99)
+    for i, k in enumerate(A.k_cpts):
+        net = A.ac_chain(k_cpt=k, seed=1234 + i)((32, 32, 3), (10,))
+        net.to(dev)
+        eng = net.engine()
+        eng._ensure_capacity(n, train=True)
+        eng.x0[:n].copy_(torch.rand((n, 32, 32, 3), generator=g).to(dev))
+        eng.y[:n].copy_(torch.nn.functional.one_hot(torch.randint(0, 10, (n,), generator=g), 10).float().to(dev))
+        nets.append(net)
+        feeds.append({net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr', net.λ_lrn: A.λ_lrn(0), net.τ: A.τ_ds(0)})
+    co = CoTrainer(nets)
+    for _ in range(5):
+        co.run(feeds)
+    torch.cuda.synchronize()
+    ms = time_replays(lambda: co.run(feeds), reps)
+    K = len(nets)
+    return {'nets': K, 'what': 'cifar10-ac experiment: ac_chain(k_cpt=k) for the 8 k_cpts, batch %d each, co-trained (one hipGraph, '
+                               'launch j = launch j of all nets)' % n,
+            'images_per_s': K * n / (ms * 1e-3), 'ms_per_joint_step': ms, 'ms_per_net_step': ms / K,
+            'images_per_s_serial': n / (single_ms * 1e-3), 'speedup_vs_serial': K * single_ms / ms,
+            'step_frac_of_mfma_roofline': K * n / (ms * 1e-3) * F_TRAIN / 1e12 / PEAK_F32_MFMA}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -235,6 +267,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-batch', type=int, default=4096, help='batch of the routed / dense evaluation measurement')
     ap.add_argument('--no-configs', action='store_true', help='skip the SURVEY 8(d) config table (extra.configs)')
+    ap.add_argument('--no-experiment', action='store_true', help='skip the co-trained experiment (extra.experiment)')
     ap.add_argument('--no-dp-structure', action='store_true', help='skip the 1-rank RCCL structure measurement (dp_structure)')
     args = ap.parse_args()
 
@@ -360,6 +393,12 @@ def main():
             dp_structure['corunner'] = {'error': repr(e)}
     if rank == 0 and world == 1 and not args.no_configs:
         cfg_table = time_configs(dev, n)
+    experiment = None
+    if rank == 0 and world == 1 and not args.no_experiment and not args.streams and not args.no_graph:
+        try:
+            experiment = time_experiment(dev, n, steady['ms_median'])
+        except Exception as e:
+            experiment = {'error': repr(e)}
 
     out = None
     if rank == 0:
@@ -492,7 +531,7 @@ def main():
             'conv_kernels': {'tflops': conv_fl / (conv_ms * 1e-3) / 1e12, 'sum_ms': conv_ms,
                              'all_launches_sum_ms': total_ms, 'n_launches': len(ops)},
             'routed_flops_per_s': value * 2 * moc, 'moc': moc, 'eval': ev, 'steady_state': steady,
-            'dp_structure': dp_structure, 'extra': {'configs': cfg_table},
+            'dp_structure': dp_structure, 'extra': {'configs': cfg_table, 'experiment': experiment},
             'roofline_forward' if other == 'fwd_group' else 'roofline_backward': roof_other,
             'launch_floor': {'kernels_per_step': n_launch, 'us_per_step': floor_us, 'us_per_kernel': floor_us / n_launch,
                              'what': 'hipGraph of that many EMPTY kernels (one wave, returns at once)'},

@@ -73,7 +73,8 @@ def test_cotrained_step_equals_the_solo_step(kind, K, n):
             da, db = (ea.P - before[i]).double(), (eb.P - before[i]).double()
             for pa in ea.trainable:
                 sl = slice(pa.offset, pa.offset + pa.size)
-                assert float((da[sl] - db[sl]).abs().max()) <= 1e-5 * float(db[sl].abs().max()) + 1e-12, (t, i, pa.owner.name, pa.name)
+                ulp = 1.2e-7 * float(ea.P[sl].abs().max())          # (the update is a difference of fp32 parameter values)
+                assert float((da[sl] - db[sl]).abs().max()) <= 1e-5 * float(db[sl].abs().max()) + ulp, (t, i, pa.owner.name, pa.name)
             assert torch.allclose(ea.S, eb.S, rtol=1e-6, atol=1e-9), (t, i, 'BatchNorm moving averages')
     # the weight packs the fused optimizer keeps current == a fresh packing of the parameters
     for a in co_nets:
