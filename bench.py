@@ -262,6 +262,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=128, help='per-GPU batch (arch_and_hypers.py:35)')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--steps-per-graph', type=int, default=4,
+                    help='training steps per hipGraph replay (Engine.run_steps; 1: one graph per step).  A step is a step: '
+                         '--steps still counts single training steps')
     ap.add_argument('--streams', action='store_true',
                     help='multi-stream DAG schedule (measured slower under hipGraph: cross-stream edges cost more than the overlap gains)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -312,12 +315,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 3)):      # >= 3: eager, capture, first replay
+    # K training steps per hipGraph replay (single process; under data parallelism one graph per step): the ~8.6 us the
+    # GPU idles between two replays of a one-step graph are paid once per K steps.  `steps` counts training steps.
+    spg = max(1, min(args.steps_per_graph, eng.STEPS_MAX)) if (world == 1 and eng.use_graph and not args.streams) else 1
+
+    def run_steps(k):
+        done = 0
+        while spg > 1 and k - done >= spg:
+            net.train.run_steps([feed] * spg)
+            done += spg
+        for _ in range(k - done):
+            net.train.run(feed)
+
+    for _ in range(3):                         # eager, capture, first replay of the one-step graph
         net.train.run(feed)
+    if spg > 1:
+        for _ in range(3):                     # (warm-up, capture, first replay of the K-step graph)
+            net.train.run_steps([feed] * spg)
+    run_steps(max(args.warmup, 3))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        net.train.run(feed)
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -349,17 +367,17 @@ def main():
     st_ = torch.cuda.current_stream()
     CH, NCH_ = 10, 40                                         # (an event per replay would break the back-to-back queue)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(NCH_ + 1)]
-    for _ in range(3):
-        net.train.run(feed)
+    CH = CH if spg == 1 else (CH + spg - 1) // spg * spg      # (whole K-step replays per chunk)
+    run_steps(3 * spg)
     evs[0].record(st_)
     for k in range(NCH_):
-        for _ in range(CH):
-            net.train.run(feed)
+        run_steps(CH)
         evs[k + 1].record(st_)
     barrier()
     per = np.array([evs[k].elapsed_time(evs[k + 1]) / CH for k in range(NCH_)])
     steady = {'steps': CH * NCH_, 'ms_median': float(np.median(per)), 'ms_mean': float(per.mean()),
               'ms_p95': float(np.percentile(per, 95)), 'images_per_s_median': n * world / (float(np.median(per)) * 1e-3),
+              'steps_per_graph': spg,
               'what': 'replays after the headline region (rank 0\'s clock), HIP events around chunks of %d steps' % CH}
 
     # A multi-rank run validates itself: after all the timed steps the replicas must still hold the SAME parameters and
@@ -521,7 +539,7 @@ def main():
                        'global_batch': n * world, 'per_gpu_batch': n, 'parallelism': 'dp%d' % world, 'rccl_ranks': (dist.get_world_size() if world > 1 else 1),
                        'allreduce': ar,
                        **(dp_check or {}),
-                       'hip_graph': bool(eng.use_graph), 'streams': eng.n_streams if eng.multi_stream else 1},
+                       'hip_graph': bool(eng.use_graph), 'steps_per_graph': spg, 'streams': eng.n_streams if eng.multi_stream else 1},
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
                          'frac': ach / PEAK_F32_MFMA, 'traffic': traffic, 'traffic_source': traffic_src,
                          'traffic_stale': traffic_stale,

@@ -378,6 +378,10 @@ typedef struct {
      * [R2, n_sinks], h2 [n, R2], bn_save [2 R + 2 R2] = m1, rstd1, m2, rstd2.  The tuned kernels need R2 == R <= 16
      * and n_cls <= 16; the any-width forms below (mpnn_*_gen) take anything up to mpnn_exit_gen_check's limits. */
     int R2;
+    /* Optional (K training steps in ONE hipGraph, lib/_plan.py:run_steps): this record's head workgroup copies the
+     * MPNN_HYP_N schedule values hyp_src[0 .. MPNN_HYP_N) to hyp_dst -- the buffer mpnn_route and the optimizer of THIS
+     * step read -- so that step j of the graph runs with the values staged in slot j, without a launch of its own. */
+    const float *hyp_src;  float *hyp_dst;
 } mpnn_exit_tail_args;
 int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int count, int n_max,
                        void *stream);

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_gen_k(const mpnn_exit_tail_
     if (blockIdx.x == 0 && n_rec0) {            // (the accumulators mpnn_route adds to: see mpnn_exit_tail_args)
         for (int i = tid; i < a.n_clear_f; i += 256) a.clear_f[i] = 0.f;
         for (int i = tid; i < a.n_clear_d; i += 256) a.clear_d[i] = 0.0;
+        if (a.hyp_src && tid < MPNN_HYP_N) a.hyp_dst[tid] = a.hyp_src[tid];
     }
     if (a.z) for (int r = tid; r < n; r += 256) gen_head_fwd(a, r);
     if (!a.h1) return;

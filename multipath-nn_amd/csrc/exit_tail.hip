@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
         // (optional) the accumulators mpnn_route adds to: cleared here, one launch ahead of it
         if (a.clear_f) for (int k = tid; k < a.n_clear_f; k += 256) a.clear_f[k] = 0.f;
         if (a.clear_d) for (int k = tid; k < a.n_clear_d; k += 256) a.clear_d[k] = 0.0;
+        if (a.hyp_src && tid < MPNN_HYP_N) a.hyp_dst[tid] = a.hyp_src[tid];     // (this step's schedule values: see the header)
         // ---- the head: Softmax + CrossEntropyError, one sample per thread ----
         if (!a.z) return;
         const int nc = a.n_cls;

@@ -96,7 +96,8 @@ class ExitTailArgs(C.Structure):
                 ('g2', P), ('b2', P), ('m2', P), ('v2', P), ('w3', P), ('bias3', P),
                 ('h2', P), ('r', P), ('r_stride', C.c_int), ('bn_save', P),
                 ('bn_eps', C.c_float), ('bn_decay', C.c_float), ('mode', C.c_int), ('n', C.c_int),
-                ('clear_f', P), ('n_clear_f', C.c_int), ('clear_d', P), ('n_clear_d', C.c_int), ('R2', C.c_int)]
+                ('clear_f', P), ('n_clear_f', C.c_int), ('clear_d', P), ('n_clear_d', C.c_int), ('R2', C.c_int),
+                ('hyp_src', P), ('hyp_dst', P)]
 
 
 class ExitTailBwdArgs(C.Structure):

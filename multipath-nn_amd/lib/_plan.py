@@ -129,6 +129,7 @@ class Engine:
         self.dp_bucket_opt = bool(int(os.environ.get('MPNN_DP_BUCKET_OPT', '0')))
         self._opt_stream = None
         self.prologue = None             # callable(stream): first launch of every training step (the input pipeline)
+        self.prologue_slot = None        # callable(stream, j): the same for step j of a K-step graph (run_steps)
         # single process: the launch that ends the backward pass also applies the update (mpnn_backward_finish_opt)
         self.fuse_opt = bool(int(os.environ.get('MPNN_FUSE_OPT', '1')))
         # co-training (lib/_co.py): this net shares every launch of its training step with co_share - 1 other nets of the
@@ -540,7 +541,7 @@ class Engine:
             self.n_max_bwd = n
             self._gen = getattr(self, '_gen', 0) + 1
             self._progs = {k: v for k, v in self._progs.items() if k[0] != 'tr'}
-            self._graphs = {k: v for k, v in self._graphs.items() if k[0] != 'tr'}
+            self._graphs = {k: v for k, v in self._graphs.items() if k[0] not in ('tr', 'trK')}
             for b in self.blocks:
                 b.dzg = [z(n, b.H[i], b.W[i], b.C[i]) for i in range(b.L)]
                 if b.has_exit:
@@ -562,9 +563,13 @@ class Engine:
                     m_avg=bn.m_avg.data, v_avg=bn.v_avg.data, eps=float(b.bns[i].hypers.ϵ),
                     nslot=self._nslot(b, i))
 
-    def _act_of_input(self, b, i, n, mode):
+    def _act_of_input(self, b, i, n, mode, fwd=False):
         """mpnn_act of the block's input at scale i."""
         if b.in_map is None:
+            if fwd and getattr(self, 'rgbx_probe', False) and b.in_shift[i] > 0:
+                # TIMING PROBE (tools/rgbx_probe.py; results are only right while x4 holds the strided picks of x0): the
+                # pyramid scale as a dense 4-channel map (RGBX, X = 0) -- aligned float4 pixels, no address shift
+                return _hip.act(self.x4[b.in_shift[i]], 4, _hip.ACT_IDENTITY, 0)
             return _hip.act(self.x0, self.x0_shape[2], _hip.ACT_IDENTITY, b.in_shift[i])
         pb, j = b.parent, b.in_map[i]
         return _hip.act(pb.s[j], pb.C[j], mode, 0, self._bn(pb, j), n * pb.H[j] * pb.W[j])
@@ -830,7 +835,7 @@ class Engine:
 
         def fwd_args(b, i, a):
             cp = b.conv.params
-            a.a = self._act_of_input(b, i, n, act_mode)
+            a.a = self._act_of_input(b, i, n, act_mode, fwd=True)
             if i > 0:
                 a.v, a.Cv = b.sp[i - 1].data_ptr(), b.C[i - 1]
                 a.wv_pack = self.packs[b.pack['w_vert_%i' % (i - 1)][0]:].data_ptr()
@@ -979,7 +984,7 @@ class Engine:
         keep += [t_lf, t_lb, t_tf, t_tb]
         if n_exit and self.generic_exits:
             fwd.append(call(lib.mpnn_lin_fwd_gen, 'lin_fwd', t_lf.data_ptr(), n_exit, n))
-            fwd.append(call(lib.mpnn_exit_tail_fwd_gen, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n))
+            fwd.append(call(lib.mpnn_exit_tail_fwd_gen, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n, host=tail_f))
         elif n_exit:
             if n <= 512:
                 fwd.append(call(lib.mpnn_lin_fwd_ks, 'lin_fwd', t_lf.data_ptr(), n_exit, n, kmax, host=lin_f))
@@ -1477,23 +1482,7 @@ class Engine:
                           non_blocking=True)
         put(self.x0[:n], x0)
         put(self.y[:n], feed[net.y])
-        ϕ = net.hypers
-        get = lambda name, default: feed.get(_attr(net, name), _attr(ϕ, name, default))
-        h = self._hyp_stage
-        h[_hip.HYP_LR] = float(get('λ_lrn', 0.0))
-        h[_hip.HYP_MU] = float(get('μ_lrn', 0.0))
-        h[_hip.HYP_TAU] = float(get('τ', 1.0))
-        h[_hip.HYP_EPS] = float(get('ϵ', 0.0))
-        h[_hip.HYP_KDEC] = float(_attr(ϕ, 'k_dec', 0.0))
-        h[_hip.HYP_KCRE] = float(_attr(ϕ, 'k_cre', 0.0))
-        h[_hip.HYP_ARTR] = float(_attr(ϕ, 'α_rtr', 1.0))
-        if getattr(ϕ, 'dyn_k_cpt', False):
-            k = feed[net.k_cpt]
-            k = np.broadcast_to(np.asarray(k, np.float32).reshape(-1), (n,)) if not isinstance(k, torch.Tensor) else k.expand(n)
-            put(self.k_cpt[:n], k)
-            h[_hip.HYP_KCPT] = 0.0
-        else:
-            h[_hip.HYP_KCPT] = float(getattr(ϕ, 'k_cpt', 0.0))
+        h = self._hyp_values(feed, n, put)
         if self._hyp_sent is None or not torch.equal(h, self._hyp_sent):
             # Upload through a ring of pinned buffers: the copy is asynchronous and, under hipGraph
             # replay, the host runs many steps ahead of the stream -- rewriting ONE staging buffer in place
@@ -1510,6 +1499,31 @@ class Engine:
             self._hyp_ring[k] = (buf, ev)
             self._hyp_sent = h.clone()
         return n, feed.get(net.mode, net.mode.default)
+
+    def _hyp_values(self, feed, n, put=None):
+        """The MPNN_HYP_N schedule / hyper-parameter values of one step (self._hyp_stage, a host tensor); put: stages the
+        per-sample k_cpt vector of a dyn_k_cpt net."""
+        net = self.net
+        ϕ = net.hypers
+        get = lambda name, default: feed.get(_attr(net, name), _attr(ϕ, name, default))
+        h = self._hyp_stage
+        h[_hip.HYP_LR] = float(get('λ_lrn', 0.0))
+        h[_hip.HYP_MU] = float(get('μ_lrn', 0.0))
+        h[_hip.HYP_TAU] = float(get('τ', 1.0))
+        h[_hip.HYP_EPS] = float(get('ϵ', 0.0))
+        h[_hip.HYP_KDEC] = float(_attr(ϕ, 'k_dec', 0.0))
+        h[_hip.HYP_KCRE] = float(_attr(ϕ, 'k_cre', 0.0))
+        h[_hip.HYP_ARTR] = float(_attr(ϕ, 'α_rtr', 1.0))
+        if getattr(ϕ, 'dyn_k_cpt', False):
+            if put is None:
+                raise NotImplementedError('per-sample k_cpt: one step per call')
+            k = feed[net.k_cpt]
+            k = np.broadcast_to(np.asarray(k, np.float32).reshape(-1), (n,)) if not isinstance(k, torch.Tensor) else k.expand(n)
+            put(self.k_cpt[:n], k)
+            h[_hip.HYP_KCPT] = 0.0
+        else:
+            h[_hip.HYP_KCPT] = float(getattr(ϕ, 'k_cpt', 0.0))
+        return h
 
     def _launch(self, ops, sec=0):
         """Run a program section.  Sequential order is a valid topological order; with
@@ -1738,6 +1752,108 @@ class Engine:
             self._last_fold = bool(prog.get('fold'))
         self._bind_views(n)
 
+    STEPS_MAX = 8                       # most training steps in one hipGraph (run_steps)
+
+    def run_steps(self, feeds):
+        """K training steps as ONE hipGraph replay (K = len(feeds) <= STEPS_MAX; same results as K calls of run()).
+
+        Between two replays of the one-step graph the GPU idles ~8.6 us (profiles/r04_final_step_timeline.txt: host /
+        runtime, not kernel time); K steps in one graph pay that once.  What changes from step to step is data, not
+        structure: the schedule values (learning rate, temperature) are staged for all K steps at once in a device
+        ring and copied into the buffer the step's kernels read by the head workgroup of the step's own
+        mpnn_exit_tail_fwd (mpnn_exit_tail_args.hyp_src: no launch of its own); with the input pipeline bound
+        (Dataset.bind_engine) launch 0 of step j gathers the batch staged in record slot j.  Without it every feed
+        must name the engine's resident input buffers (the same batch K times: the benchmark).  Falls back to K
+        single-step calls where the one-graph form does not apply (data parallel, eager, per-sample k_cpt)."""
+        net, K = self.net, len(feeds)
+        ok = (1 < K <= self.STEPS_MAX and self.use_graph and self.allreduce is None and not self.multi_stream
+              and not getattr(net.hypers, 'dyn_k_cpt', False))
+        if ok:
+            xs = [f[net.x0] for f in feeds]
+            bound = all(isinstance(x, BoundInput) for x in xs)
+            same = all(isinstance(x, torch.Tensor) and x.data_ptr() == xs[0].data_ptr() and x.shape == xs[0].shape for x in xs) and \
+                isinstance(xs[0], torch.Tensor) and xs[0].data_ptr() == self.x0.data_ptr() and \
+                all(isinstance(f[net.y], torch.Tensor) and f[net.y].data_ptr() == self.y.data_ptr() for f in feeds)
+            ok = (bound and self.prologue_slot is not None) or (same and self.prologue is None)
+            ok = ok and all(f.get(net.mode, net.mode.default) == 'tr' for f in feeds)
+        if not ok:
+            for f in feeds:
+                self.run(f, True)
+            return
+        n = int(xs[0].shape[0])
+        key = ('trK', n, K, self.bwd_levels, self.fold_clear)
+        g = self._graphs.get(key)
+        if g is None:
+            for f in feeds:                                     # (first call: the single-step path warms everything up)
+                self.run(f, True)
+            self._graphs[key] = 'warm'
+            return
+        prog = self.program('tr', n)
+        if not (prog.get('fold') and prog.get('fused_opt')):
+            for f in feeds:
+                self.run(f, True)
+            return
+        if len(self._event_keep) > 4096:
+            torch.cuda.synchronize()
+            self._event_keep.clear()
+        # the K steps' schedule values: one asynchronous upload through a ring of pinned buffers
+        if not hasattr(self, '_hypk'):
+            self._hypk = torch.zeros(self.STEPS_MAX, _hip.HYP_N, device=self.dev)
+            self._hypk_ring = [(torch.zeros(self.STEPS_MAX, _hip.HYP_N).pin_memory(), None) for _ in range(8)]
+            self._hypk_slot = -1
+        r = self._hypk_slot = (self._hypk_slot + 1) % len(self._hypk_ring)
+        buf, ev = self._hypk_ring[r]
+        if ev is not None:
+            ev.synchronize()
+        for j, f in enumerate(feeds):
+            buf[j].copy_(self._hyp_values(f, n))
+        self._hypk[:K].copy_(buf[:K], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._hypk_ring[r] = (buf, ev)
+        self._hyp_sent = None                                   # (the graph rewrites self.hyp on the device)
+        if not self._packs_fresh:
+            self._pack()
+            self._packs_fresh = True
+        if g == 'warm':
+            torch.cuda.synchronize()
+            if not self._acc_clean:
+                self._begin(True)
+                self._acc_clean = True
+            ops = [op for op in list(prog['fwd']) + list(prog['bwd']) if op.what not in ('fork', 'join')]
+            tails = [op for op in ops if op.what == 'exit_tail_fwd']
+            assert len(tails) == 1 and tails[0].host
+            tabs = []
+            for j in range(K):
+                recs = []
+                for k, rec in enumerate(tails[0].host):
+                    c = type(rec)()
+                    C.memmove(C.byref(c), C.byref(rec), C.sizeof(rec))
+                    if k == 0:
+                        c.hyp_src, c.hyp_dst = self._hypk[j].data_ptr(), self.hyp.data_ptr()
+                    recs.append(c)
+                tabs.append(_hip.to_device_table(recs, self.dev))
+            self._keep += tabs
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                st = torch.cuda.current_stream().cuda_stream
+                for j in range(K):
+                    if self.prologue_slot is not None:
+                        self.prologue_slot(st, j)
+                    for op in ops:
+                        if op.what == 'exit_tail_fwd':
+                            _hip.check(op.fn(tabs[j].data_ptr(), *op.args[1:], st), 'exit_tail_fwd')
+                        else:
+                            op(st)
+            self._graphs[key] = g
+        if not self._acc_clean:                                 # something outside run() left the accumulators dirty
+            self._begin(True)
+        self._acc_clean = False
+        g.replay()
+        self._acc_clean = True
+        self.last_n, self.last_mode, self._last_fold = n, 'tr', True
+        self._bind_views(n)
+
     def _step_eager(self, prog, train, n):
         """One step as eager launches (also what a whole-step hipGraph captures): everything up to the optimizer, then
         the optimizer -- unless the data-parallel step already applied every bucket behind its all-reduce."""
@@ -1745,11 +1861,12 @@ class Engine:
         if train and not prog.get('fused_opt') and not (self.allreduce is not None and self._bucket_opt_on()):
             self._opt(n)
 
-    def set_prologue(self, fn):
+    def set_prologue(self, fn, fn_slot=None):
         """fn(stream) becomes the first launch of every training step -- lib/data.py installs the on-device batch
-        assembly (mpnn_augment_batch) here, so that it is replayed with the step's hipGraph."""
-        self.prologue = fn
-        self._graphs = {k: v for k, v in self._graphs.items() if k[0] != 'tr'}
+        assembly (mpnn_augment_batch) here, so that it is replayed with the step's hipGraph.  fn_slot(stream, j): the
+        same for step j of a K-step graph (run_steps), reading the records staged in slot j."""
+        self.prologue, self.prologue_slot = fn, fn_slot
+        self._graphs = {k: v for k, v in self._graphs.items() if k[0] not in ('tr', 'trK')}
 
     def mark_dirty(self):
         """Tell the engine that something outside run() launched program ops or wrote the step's accumulators (slot

@@ -129,6 +129,7 @@ class Dataset:
     # a ring of pinned buffers and one gather launch -- which, once bind_engine() has installed it, is part of the
     # training step's hipGraph.
     RING = 8
+    SLOTS = 8           # record slots per consumer: Engine.STEPS_MAX training steps in one hipGraph
 
     def to_device(self, device='cuda:0'):
         import torch
@@ -153,33 +154,34 @@ class Dataset:
         bufs = self.__dict__.setdefault('_bufs', {})
         b = bufs.get(key)
         if b is None or b['ring'][0][0].shape[0] < n:
-            b = bufs[key] = dict(ring=[(torch.zeros((n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING)],
-                                 slot=-1, dev=torch.zeros((n, 4), dtype=torch.int32, device=self._dev))
+            # dev: SLOTS record buffers -- slot j feeds step j of a K-step graph (Engine.run_steps), slot 0 the one-step graph
+            b = bufs[key] = dict(ring=[(torch.zeros((n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING * self.SLOTS)],
+                                 slot=-1, dev=torch.zeros((self.SLOTS, n, 4), dtype=torch.int32, device=self._dev))
         return b
 
-    def stage_training_draws(self, n=128, r_shift=4, eng=None):
+    def stage_training_draws(self, n=128, r_shift=4, eng=None, slot=0):
         """Draw one batch's augmentation records -- (j, flip, du, dv) per sample, the reference's numpy.random call
         sequence (scripts/lib/data.py:24-34) -- and queue their upload into the static device buffer the augmentation
-        launch reads (eng: the buffer of that bound engine).  Asynchronous: a ring of pinned host buffers, each reused only
+        launch reads (eng: the buffer of that bound engine; slot: for step `slot` of a K-step graph).  Asynchronous: a ring of pinned host buffers, each reused only
         after the event behind its last copy has completed (under hipGraph replay the host runs several steps ahead of the
         stream)."""
         import torch
         b = self._draw_buffers(n, None if eng is None else id(eng))
-        k = b['slot'] = (b['slot'] + 1) % self.RING
+        k = b['slot'] = (b['slot'] + 1) % len(b['ring'])
         buf, ev = b['ring'][k]
         if ev is not None:
             ev.synchronize()
         _draw_augmentation_fast(n, len(self.x0_tr), self._sym_u8, r_shift, out=buf.numpy()[:n], all_sym=self._all_sym)
-        b['dev'][:n].copy_(buf[:n], non_blocking=True)
+        b['dev'][slot, :n].copy_(buf[:n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         b['ring'][k] = (buf, ev)
-        return b['dev']
+        return b['dev'][slot]
 
     def _augment_launch(self, n, x_out, y_out, stream, draws=None):
         from . import _hip
         h, w, c = self.x0_tr.shape[1:]
-        draws = self._draw_buffers(n)['dev'] if draws is None else draws
+        draws = self._draw_buffers(n)['dev'][0] if draws is None else draws
         _hip.check(_hip.load().mpnn_augment_batch(self._x_dev.data_ptr(), self._y_dev.data_ptr(), draws.data_ptr(),
                                                   x_out.data_ptr(), y_out.data_ptr(), n, h, w, c, self.y_tr.shape[1], stream),
                    'augment_batch')
@@ -211,7 +213,8 @@ class Dataset:
         draws = self._draw_buffers(n, id(eng))['dev']
         # the engine's buffers are resolved when the launch is issued (eagerly or into a capture; the engine drops its
         # graphs whenever it reallocates them), never held as views: see _plan.BoundInput
-        eng.set_prologue(lambda stream: self._augment_launch(n, eng.x0[:n], eng.y[:n], stream, draws))
+        eng.set_prologue(lambda stream: self._augment_launch(n, eng.x0[:n], eng.y[:n], stream, draws[0]),
+                         lambda stream, j: self._augment_launch(n, eng.x0[:n], eng.y[:n], stream, draws[j]))
         return BoundInput(eng, 'x0', n), BoundInput(eng, 'y', n)
 
     def training_batch(self, n=128):

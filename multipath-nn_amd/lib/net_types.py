@@ -60,6 +60,15 @@ class _TrainOp:
     def run(self, feed):
         return self._net._run_train(feed)
 
+    def run_steps(self, feeds):
+        """len(feeds) consecutive training steps, replayed as ONE hipGraph where the engine can (Engine.run_steps);
+        the same results as calling run() on each feed in turn."""
+        eng = self._net.engine()
+        if hasattr(eng, 'run_steps'):
+            return eng.run_steps(list(feeds))
+        for f in feeds:                                   # (the single-scale Conv engine: step by step)
+            eng.run(f, train=True)
+
 ################################################################################
 # Root Network Class  (reference: net_types.py:43-79)
 ################################################################################

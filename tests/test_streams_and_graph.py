@@ -190,3 +190,78 @@ def test_backward_dependency_levels():
     # ONE step (later steps amplify rounding chaotically); the weight-gradient split differs between the two
     # schedules, so the slab sums round differently: agreement to fp32 rounding of the update, not bit for bit
     assert float((out[0] - out[1]).abs().max()) <= 2e-6 * float(out[1].abs().max())
+
+
+@pytest.mark.parametrize('kind', ['ac', 'cr', 'sr'])
+def test_k_steps_in_one_graph_equal_k_single_steps(kind):
+    """Engine.run_steps: K training steps as ONE hipGraph replay -- the schedule values of step j (learning rate,
+    temperature: different in every step here) reach the step through the device ring and the head workgroup of its
+    mpnn_exit_tail_fwd -- against K single-step replays from the same state: the same launches on the same data, so the
+    parameters agree to the last bits of the fp64-atomic statistics (1e-6), call after call (warm-up, capture, replays)."""
+    import arch_and_hypers as A
+    mk = {'ac': lambda: A.ac_chain(k_cpt=1.6e-8, seed=7), 'cr': lambda: A.cr_chain(k_cpt=8e-9, seed=7), 'sr': lambda: A.sr_chain(8)}[kind]
+    nets = [mk()((32, 32, 3), (10,)) for _ in range(2)]
+    for net in nets:
+        net.engine().init_params(77)
+    n, K = 32, 4
+    rng = np.random.default_rng(3)
+    x0 = torch.from_numpy(rng.random((n, 32, 32, 3)).astype(np.float32)).cuda()
+    y = torch.from_numpy(np.eye(10, dtype=np.float32)[rng.integers(0, 10, n)]).cuda()
+    engs = [net.engine() for net in nets]
+    for e in engs:
+        e._ensure_capacity(n)
+        e.x0[:n].copy_(x0); e.y[:n].copy_(y)
+
+    def feed(net, t):
+        e = net.engine()
+        f = {net.x0: e.x0[:n], net.y: e.y[:n], net.mode: 'tr', net.λ_lrn: 0.05 / (1 + 0.3 * t)}
+        if kind != 'sr':
+            f[net.τ] = 1.0 / (1 + 0.1 * t)
+        return f
+    a, b = nets
+    rel = lambda u, v: float((u - v).abs().max() / v.abs().max())
+    for call in range(4):
+        ts = range(call * K, (call + 1) * K)
+        a.train.run_steps([feed(a, t) for t in ts])
+        for t in ts:
+            b.train.run(feed(b, t))
+        torch.cuda.synchronize()
+        assert rel(engs[0].P, engs[1].P) <= 1e-6 and rel(engs[0].A, engs[1].A) <= 1e-6 and rel(engs[0].S, engs[1].S) <= 1e-6, (call,)
+        for la, lb in zip(a.layers, b.layers):
+            assert torch.equal(la.p_ev, lb.p_ev) and torch.allclose(la.p_tr, lb.p_tr, rtol=1e-5, atol=1e-8)
+    assert any(k[0] == 'trK' and not isinstance(v, str) for k, v in engs[0]._graphs.items())    # (the one-graph form did run)
+    # a single step after K-step replays picks up its own schedule values again
+    a.train.run(feed(a, 99)); b.train.run(feed(b, 99))
+    torch.cuda.synchronize()
+    assert rel(engs[0].P, engs[1].P) <= 1e-6
+
+
+def test_k_steps_in_one_graph_with_the_input_pipeline():
+    """run_steps with Dataset.bind_engine: launch 0 of step j gathers the batch staged in record slot j -- the same
+    batches, in the same order, from the same numpy stream as step-by-step training."""
+    import arch_and_hypers as A
+    from lib.data import Dataset
+    n, K = 32, 4
+    outs = []
+    for mode in ('single', 'steps'):
+        ds = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+        net = A.ac_chain(k_cpt=1.6e-8, seed=5)(ds.x0_shape, ds.y_shape)
+        eng = net.engine()
+        x0, y = ds.bind_engine(eng, n)
+        np.random.seed(21)
+        f = lambda t: {net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.02 / (1 + t), net.τ: 1.0}
+        for call in range(3):
+            if mode == 'single':
+                for j in range(K):
+                    ds.stage_training_draws(n, eng=eng)
+                    net.train.run(f(call * K + j))
+            else:
+                for j in range(K):
+                    ds.stage_training_draws(n, eng=eng, slot=j)
+                net.train.run_steps([f(call * K + j) for j in range(K)])
+        torch.cuda.synchronize()
+        outs.append((eng.P.clone(), eng.x0[:n].clone(), np.random.get_state()[1].copy()))
+    rel = lambda u, v: float((u - v).abs().max() / v.abs().max())
+    assert torch.equal(outs[0][1], outs[1][1])                       # the last batch is the same batch
+    assert np.array_equal(outs[0][2], outs[1][2])                    # ... and the numpy stream stands at the same place
+    assert rel(outs[0][0], outs[1][0]) <= 1e-6
