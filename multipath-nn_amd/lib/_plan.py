@@ -1776,23 +1776,29 @@ class Engine:
                 all(isinstance(f[net.y], torch.Tensor) and f[net.y].data_ptr() == self.y.data_ptr() for f in feeds)
             ok = (bound and self.prologue_slot is not None) or (same and self.prologue is None)
             ok = ok and all(f.get(net.mode, net.mode.default) == 'tr' for f in feeds)
+        def one_by_one():
+            # step by step; with the input pipeline bound, step j must gather from record slot j (the caller staged K slots)
+            slots = self.prologue_slot is not None and all(isinstance(f[net.x0], BoundInput) for f in feeds)
+            keep_p, keep_g = self.prologue, self.use_graph
+            try:
+                for j, f in enumerate(feeds):
+                    if slots:
+                        self.prologue, self.use_graph = (lambda st, j=j: self.prologue_slot(st, j)), False
+                    self.run(f, True)
+            finally:
+                self.prologue, self.use_graph = keep_p, keep_g
         if not ok:
-            for f in feeds:
-                self.run(f, True)
-            return
+            return one_by_one()
         n = int(xs[0].shape[0])
         key = ('trK', n, K, self.bwd_levels, self.fold_clear)
         g = self._graphs.get(key)
         if g is None:
-            for f in feeds:                                     # (first call: the single-step path warms everything up)
-                self.run(f, True)
+            one_by_one()                                        # (first call: the single-step path loads the code objects)
             self._graphs[key] = 'warm'
             return
         prog = self.program('tr', n)
         if not (prog.get('fold') and prog.get('fused_opt')):
-            for f in feeds:
-                self.run(f, True)
-            return
+            return one_by_one()
         if len(self._event_keep) > 4096:
             torch.cuda.synchronize()
             self._event_keep.clear()
