@@ -1782,7 +1782,7 @@ class Engine:
             keep_p, keep_g = self.prologue, self.use_graph
             try:
                 for j, f in enumerate(feeds):
-                    if slots:
+                    if slots and j > 0:         # (slot 0 is what the one-step graph reads: step 0 takes the usual path)
                         self.prologue, self.use_graph = (lambda st, j=j: self.prologue_slot(st, j)), False
                     self.run(f, True)
             finally:
