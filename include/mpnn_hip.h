@@ -393,6 +393,7 @@ typedef struct {
     float *dz;                           /* [n,n_cls] dL/dz (head logits)          */
     float *dh1;                          /* [n,R] dL/dh1                           */
     float *dg1, *db1, *dw2, *dbias2, *dg2, *db2, *dw3, *dbias3;   /* written      */
+    float *dh2;                          /* [n,R2] scratch (mpnn_exit_tail_bwd_gen: dL/dh2; the tuned kernel ignores it) */
 } mpnn_exit_tail_bwd_args;
 int mpnn_exit_tail_bwd(const mpnn_exit_tail_bwd_args *dev_table, int count, int n_max,
                        void *stream);

@@ -103,7 +103,7 @@ class ExitTailArgs(C.Structure):
 class ExitTailBwdArgs(C.Structure):
     _fields_ = [('f', ExitTailArgs), ('w_cerr', P), ('dr', P), ('dz', P), ('dh1', P),
                 ('dg1', P), ('db1', P), ('dw2', P), ('dbias2', P), ('dg2', P), ('db2', P),
-                ('dw3', P), ('dbias3', P)]
+                ('dw3', P), ('dbias3', P), ('dh2', P)]
 
 
 class ExitEvArgs(C.Structure):

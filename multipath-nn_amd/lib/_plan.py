@@ -549,6 +549,7 @@ class Engine:
                     b.dzh = z(n, self.n_cls) if b.head is not None else None
                     if b.router is not None:
                         b.dh1 = z(n, b.R)
+                        b.dh2 = z(n, b.R2) if self.generic_exits else None     # (scratch of mpnn_exit_tail_bwd_gen)
 
     # ------------------------------------------------------------------ programs
     @staticmethod
@@ -966,6 +967,8 @@ class Engine:
                 tf.bn_eps, tf.bn_decay = float(bn1.hypers.ϵ), float(bn1.hypers.d)
                 tb.dr = self.dr[sw * n * MS:].data_ptr()
                 tb.dh1 = b.dh1.data_ptr()
+                if mode == 'tr' and getattr(b, 'dh2', None) is not None:
+                    tb.dh2 = b.dh2.data_ptr()
                 tb.dg1, tb.db1 = bn1.params.γ.grad.data_ptr(), bn1.params.β.grad.data_ptr()
                 tb.dw2, tb.dbias2 = l2.params.w.grad.data_ptr(), l2.params.b.grad.data_ptr()
                 tb.dg2, tb.db2 = bn2.params.γ.grad.data_ptr(), bn2.params.β.grad.data_ptr()
