@@ -427,6 +427,8 @@ typedef struct {
     const int *idx;  const int *cnt;  int n;           /* this node's sample list / capacity */
     int *child_idx[MPNN_MAX_SINKS];  int *child_cnt[MPNN_MAX_SINKS];
     int R2;                              /* width of the second hidden layer (0: R); see mpnn_exit_tail_args */
+    float *z, *h1;                       /* scratch of mpnn_exit_ev_gen: [n, n_cls] head logits, [n, R] first router map
+                                          * (rows by IMAGE; the tuned mpnn_exit_ev keeps both in LDS and ignores them) */
 } mpnn_exit_ev_args;
 int mpnn_exit_ev(const mpnn_exit_ev_args *dev_table, int count, int n_max, void *stream);
 int mpnn_exit_ev_check(const mpnn_exit_ev_args *host_record);

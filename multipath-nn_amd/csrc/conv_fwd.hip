@@ -147,13 +147,14 @@ static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_
         q.small[k] = p.a.C <= 4;
         if (!q.small[k] && (p.a.C & 3)) return MPNN_E_SHAPE;
         static const int strip_env = [] { const char *e = getenv("MPNN_STRIP"); return e ? atoi(e) : 512; }();     // minimum batch, 0 = off
-        // (evaluation batches only: at the training batch a strip per wave leaves the chip half empty -- 14.7 against 13.3 us)
+        // (evaluation batches only: at the training batch a strip per wave leaves the chip half empty -- 14.7 against 13.3 us;
+        // co-trained nets count together: `share` nets of n images each fill the chip like one batch of share * n)
         const int kch = (p.a.C >> 4) + (args[k].v ? (p.Cv >> 4) : 0);                  // 16-channel chunks of input
-        if (strip_env && p.n >= strip_env && q.small[k] && args[k].v && (p.Cv % 16) == 0 && 1 + (p.Cv >> 4) <= MPNN_STRIP_KMAX &&
+        if (strip_env && (long)p.n * share >= strip_env && q.small[k] && args[k].v && (p.Cv % 16) == 0 && 1 + (p.Cv >> 4) <= MPNN_STRIP_KMAX &&
             p.a.mode == MPNN_ACT_IDENTITY && p.W >= 16 && (p.W % 16) == 0 && (p.H % 4) == 0 && (!args[k].pool_out || !(p.H & 1))) {
             q.gk[k] = 4;  p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W);                    // image + V: the strip body's SMA form
         } else
-        if (strip_env && p.n >= strip_env && p.W >= 16 && (p.W % 16) == 0 && (p.H % 4) == 0 && (p.a.C % 16) == 0 && p.a.C >= 16 &&
+        if (strip_env && (long)p.n * share >= strip_env && p.W >= 16 && (p.W % 16) == 0 && (p.H % 4) == 0 && (p.a.C % 16) == 0 && p.a.C >= 16 &&
             (!args[k].v || (p.Cv % 16) == 0) && kch <= MPNN_STRIP_KMAX && (!args[k].pool_out || !(p.H & 1))) {
             q.gk[k] = kch == 1 ? 3 : 4;  p.n_tiles = conv_grid_x<0>(p.n, p.H, p.W);        // (64-pixel tiles: the unit of the work shares)
         } else

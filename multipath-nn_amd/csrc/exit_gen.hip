@@ -56,26 +56,19 @@ __device__ __forceinline__ void phase_barrier() {          // the phase's global
 // grid (16-row tiles, 16-column tiles of both sets, records); the four waves split K (LF_UN 16-feature blocks per trip, all
 // their loads issued before the first MFMA), partial tiles meet in LDS.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lin_fwd_gen_k(const mpnn_lin_fwd_args *__restrict__ tab) {
-    const mpnn_lin_fwd_args &a = tab[blockIdx.z];
-    const int n0 = blockIdx.x * 16;
-    if (n0 >= a.n) return;
-    const int M0 = a.w[0] ? a.M[0] : 0, M1 = a.w[1] ? a.M[1] : 0;
-    const int T0 = (M0 + 15) >> 4, T1 = (M1 + 15) >> 4;
-    int ct = blockIdx.y;
-    if (ct >= T0 + T1) return;
-    const int s = ct >= T0 ? 1 : 0;
-    if (s) ct -= T0;
-    const int M = s ? M1 : M0, c0 = ct * 16;
-    const float *__restrict__ w = a.w[s];
-    __shared__ float cA[GEN_C * 3];
-    __shared__ float red[4 * 256];
+// One (16-row, 16-column) output tile: rows = sample slots n0 .. n0 + 15 of `n`; slot -> image through idx (routed
+// evaluation) or the identity; outputs, k_cpt and the input rows are indexed by IMAGE.
+__device__ __forceinline__ void gen_lin_tile(const mpnn_act &act, int HW, int n, const int *__restrict__ idx, int n0,
+                                             const float *__restrict__ w, const float *__restrict__ bias, int M, int c0,
+                                             bool extra, float alpha, const float *__restrict__ kcpt, float *__restrict__ y,
+                                             float *cA, float *red) {
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15, wid = tid >> 6;
-    const int C = a.a.C, K = a.HW * C;
-    gen_table(a.a, cA);
-    const int row = n0 + li;
-    const bool valid = row < a.n;
-    const float *xrow = a.a.x + (size_t)(valid ? row : 0) * K;
+    const int C = act.C, K = HW * C;
+    gen_table(act, cA);
+    const int slot = n0 + li;
+    const bool valid = slot < n;
+    const int img = valid ? (idx ? idx[slot] : slot) : 0;
+    const float *xrow = act.x + (size_t)img * K;
     const int col = c0 + li;
     const bool cv = col < M;
     const int colc = cv ? col : 0;
@@ -100,7 +93,7 @@ __global__ __launch_bounds__(256) void lin_fwd_gen_k(const mpnn_lin_fwd_args *__
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool on = k0 + j < K;
-                const float xa = (on && valid) ? gen_act(a.a, cA, xv[u][j], c) : 0.f;
+                const float xa = (on && valid) ? gen_act(act, cA, xv[u][j], c) : 0.f;
                 const float xb = (on && cv) ? bv[u][j] : 0.f;
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xb, acc, 0, 0, 0);
                 c = c + 1 < C ? c + 1 : 0;
@@ -113,14 +106,31 @@ __global__ __launch_bounds__(256) void lin_fwd_gen_k(const mpnn_lin_fwd_args *__
     __syncthreads();
     {   // D layout: element e = lane * 4 + r -> row 4 (lane / 16) + r, column lane % 16
         const int e = tid, l = e >> 2, r = e & 3;
-        const int orow = n0 + (l >> 4) * 4 + r, ocol = c0 + (l & 15);
-        if (orow < a.n && ocol < M) {
-            float v = a.b[s][ocol];
+        const int oslot = n0 + (l >> 4) * 4 + r, ocol = c0 + (l & 15);
+        if (oslot < n && ocol < M) {
+            const int oimg = idx ? idx[oslot] : oslot;
+            float v = bias[ocol];
             v += ((red[e] + red[256 + e]) + (red[512 + e] + red[768 + e]));
-            if (a.extra_col[s]) v += a.alpha_cpt * a.k_cpt[orow] * w[(size_t)K * M + ocol];
-            a.y[s][(size_t)orow * M + ocol] = v;
+            if (extra) v += alpha * kcpt[oimg] * w[(size_t)K * M + ocol];
+            y[(size_t)oimg * M + ocol] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void lin_fwd_gen_k(const mpnn_lin_fwd_args *__restrict__ tab) {
+    const mpnn_lin_fwd_args &a = tab[blockIdx.z];
+    const int n0 = blockIdx.x * 16;
+    if (n0 >= a.n) return;
+    const int M0 = a.w[0] ? a.M[0] : 0, M1 = a.w[1] ? a.M[1] : 0;
+    const int T0 = (M0 + 15) >> 4, T1 = (M1 + 15) >> 4;
+    int ct = blockIdx.y;
+    if (ct >= T0 + T1) return;
+    const int s = ct >= T0 ? 1 : 0;
+    if (s) ct -= T0;
+    __shared__ float cA[GEN_C * 3];
+    __shared__ float red[4 * 256];
+    gen_lin_tile(a.a, a.HW, a.n, nullptr, n0, a.w[s], a.b[s], s ? M1 : M0, ct * 16, a.extra_col[s] != 0, a.alpha_cpt, a.k_cpt,
+                 a.y[s], cA, red);
 }
 
 // ---------------------------------------------------------------------------
@@ -562,82 +572,111 @@ __global__ __launch_bounds__(TT) void exit_tail_bwd_gen_k(const mpnn_exit_tail_b
 }
 
 // ---------------------------------------------------------------------------
-// evaluation: 8 samples per workgroup end to end (see mpnn_exit_ev)
+// evaluation (mpnn_exit_ev_gen; moving-average BatchNorms: every sample on its own).  Two launches:
+//   ev_lin_gen_k   the two affine maps over the exit's features on MFMA tiles (gen_lin_tile), on the record's sample
+//                  list (idx / device-side cnt), into the record's scratch maps z [n, n_cls] and h1 [n, R] (by image);
+//   ev_tail_gen_k  64 samples per workgroup, HT threads per sample: the router tail through LDS rows, the head's softmax /
+//                  cross-entropy / arg-max, and the children's sample lists -- ONE reservation (atomic) per workgroup
+//                  and sink, then every sample writes itself at base + its rank within the workgroup.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void exit_ev_gen_k(const mpnn_exit_ev_args *__restrict__ tab) {
+__global__ __launch_bounds__(256) void ev_lin_gen_k(const mpnn_exit_ev_args *__restrict__ tab) {
+    const mpnn_exit_ev_args &a = tab[blockIdx.z];
+    int n = a.n;
+    if (a.cnt) { const int c = *a.cnt; n = c < n ? c : n; }
+    const int n0 = blockIdx.x * 16;
+    if (n0 >= n) return;
+    const int M0 = a.w_head ? a.n_cls : 0, M1 = a.w1 ? a.R : 0;
+    const int T0 = (M0 + 15) >> 4, T1 = (M1 + 15) >> 4;
+    int ct = blockIdx.y;
+    if (ct >= T0 + T1) return;
+    const int s = ct >= T0 ? 1 : 0;
+    if (s) ct -= T0;
+    __shared__ float cA[GEN_C * 3];
+    __shared__ float red[4 * 256];
+    if (s) gen_lin_tile(a.a, a.HW, n, a.idx, n0, a.w1, a.b1, M1, ct * 16, a.extra_col != 0, a.alpha_cpt, a.k_cpt, a.h1, cA, red);
+    else   gen_lin_tile(a.a, a.HW, n, a.idx, n0, a.w_head, a.b_head, M0, ct * 16, false, 0.f, nullptr, a.z, cA, red);
+}
+
+#define EV_SPW 64            // samples per workgroup of the tail
+__global__ __launch_bounds__(256) void ev_tail_gen_k(const mpnn_exit_ev_args *__restrict__ tab) {
     const mpnn_exit_ev_args &a = tab[blockIdx.y];
     int n = a.n;
     if (a.cnt) { const int c = *a.cnt; n = c < n ? c : n; }
-    const int s0 = blockIdx.x * 8;
+    const int s0 = blockIdx.x * EV_SPW;
     if (s0 >= n) return;
-    __shared__ float cA[GEN_C * 3];
-    __shared__ float zs[8 * 1024], hs[8 * GEN_R], a1s[8 * GEN_R], a2s[8 * GEN_R];
-    __shared__ int img_s[8];
-    const int tid = threadIdx.x, K = a.HW * a.a.C, C = a.a.C;
+    __shared__ float aL[16 * GEN_R], bL[16 * GEN_R];
+    __shared__ int arg_s[EV_SPW], img_s[EV_SPW], base_s[MPNN_MAX_SINKS];
+    const int tid = threadIdx.x, sl = tid / HT, part = tid % HT;
     const int nc = a.w_head ? a.n_cls : 0, R = a.w1 ? a.R : 0, R2 = a.w1 ? (a.R2 > 0 ? a.R2 : a.R) : 0, S = a.w1 ? a.n_sinks : 0;
-    gen_table(a.a, cA);
-    if (tid < 8) img_s[tid] = s0 + tid < n ? (a.idx ? a.idx[s0 + tid] : s0 + tid) : -1;
+    if (tid < EV_SPW) { arg_s[tid] = -1; img_s[tid] = -1; }
     __syncthreads();
-    const int Mt = nc + R;
-    for (int e = tid; e < 8 * Mt; e += 256) {
-        const int sm = e / Mt, c = e - sm * Mt, img = img_s[sm];
-        if (img < 0) continue;
-        const float *x = a.a.x + (size_t)img * K;
-        const bool head = c < nc;
-        const int cc = head ? c : c - nc, M = head ? nc : R;
-        const float *w = head ? a.w_head : a.w1;
-        float acc = 0.f;
-        for (int k = 0; k < K; ++k) acc += gen_act(a.a, cA, x[k], k % C) * w[(size_t)k * M + cc];
-        if (head) zs[sm * 1024 + cc] = acc + a.b_head[cc];
-        else {
-            acc += a.b1[cc];
-            if (a.extra_col) acc += a.alpha_cpt * a.k_cpt[img] * a.w1[(size_t)K * R + cc];
-            hs[sm * GEN_R + cc] = acc;
+    for (int it = 0; it < EV_SPW / 16; ++it) {
+        const int slot = s0 + it * 16 + sl;
+        const bool ok = slot < n;
+        const int img = ok ? (a.idx ? a.idx[slot] : slot) : 0;
+        if (R) {
+            for (int c = part; c < R; c += HT)
+                aL[sl * R + c] = fmaxf(a.g1[c] * (a.h1[(size_t)img * R + c] - a.m1[c]) * rsqrtf(a.v1[c] + a.bn_eps) + a.be1[c], 0.f);
+            __syncthreads();
+            for (int j = part; j < R2; j += HT) {
+                float h = a.bias2[j];
+                for (int c = 0; c < R; ++c) h += aL[sl * R + c] * a.w2[c * R2 + j];
+                bL[sl * R2 + j] = fmaxf(a.g2[j] * (h - a.m2[j]) * rsqrtf(a.v2[j] + a.bn_eps) + a.be2[j], 0.f);
+            }
+            __syncthreads();
+            if (part == 0 && ok) {
+                int arg = 0; float rmax = 0.f;
+                for (int s = 0; s < S; ++s) {
+                    float r = a.bias3[s];
+                    for (int j = 0; j < R2; ++j) r += bL[sl * R2 + j] * a.w3[j * S + s];
+                    a.r[(size_t)img * a.r_stride + s] = r;
+                    if (s == 0 || r > rmax) { rmax = r; arg = s; }             // first index on ties (tf.argmax)
+                }
+                arg_s[it * 16 + sl] = arg; img_s[it * 16 + sl] = img;
+            }
         }
-    }
-    __syncthreads();
-    for (int e = tid; e < 8 * R; e += 256) {
-        const int sm = e / R, c = e - sm * R;
-        a1s[sm * GEN_R + c] = fmaxf(a.g1[c] * (hs[sm * GEN_R + c] - a.m1[c]) * rsqrtf(a.v1[c] + a.bn_eps) + a.be1[c], 0.f);
-    }
-    __syncthreads();
-    for (int e = tid; e < 8 * R2; e += 256) {
-        const int sm = e / R2, j = e - sm * R2;
-        float h = a.bias2[j];
-        for (int c = 0; c < R; ++c) h += a1s[sm * GEN_R + c] * a.w2[c * R2 + j];
-        a2s[sm * GEN_R + j] = fmaxf(a.g2[j] * (h - a.m2[j]) * rsqrtf(a.v2[j] + a.bn_eps) + a.be2[j], 0.f);
-    }
-    __syncthreads();
-    if (tid >= 8 || img_s[tid] < 0) return;
-    const int img = img_s[tid];
-    if (nc) {
-        const float *z = zs + tid * 1024, *y = a.y + (size_t)img * nc;
-        float mx = z[0];
-        for (int k = 1; k < nc; ++k) mx = fmaxf(mx, z[k]);
-        float sum = 0.f;
-        for (int k = 0; k < nc; ++k) sum += expf(z[k] - mx);
-        const float inv = 1.f / sum;
-        float ce = 0.f, pmax = 0.f, ymax = 0.f; int ap = 0, ay = 0;
-        for (int k = 0; k < nc; ++k) {
-            const float pk = expf(z[k] - mx) * inv, yk = y[k];
-            ce -= yk * logf(a.eps_ce / (float)nc + (1.f - a.eps_ce) * pk);
-            if (k == 0 || pk > pmax) { pmax = pk; ap = k; }
-            if (k == 0 || yk > ymax) { ymax = yk; ay = k; }
+        if (nc) {            // the head: HT threads per sample (as gen_head_fwd, by image)
+            const float *z = a.z + (size_t)img * nc, *y = a.y + (size_t)img * nc;
+            float mx = -3.0e38f;
+            for (int k = part; k < nc; k += HT) mx = fmaxf(mx, z[k]);
+            mx = quad_max(mx);
+            float sum = 0.f;
+            for (int k = part; k < nc; k += HT) sum += expf(z[k] - mx);
+            sum = quad_sum(sum);
+            const float inv = 1.f / sum;
+            float ce = 0.f, pmax = -1.f, ymax = -3.0e38f; int ap = nc, ay = nc;
+            for (int k = part; k < nc; k += HT) {
+                const float pk = expf(z[k] - mx) * inv, yk = y[k];
+                ce -= yk * logf(a.eps_ce / (float)nc + (1.f - a.eps_ce) * pk);
+                if (pk > pmax) { pmax = pk; ap = k; }
+                if (yk > ymax) { ymax = yk; ay = k; }
+            }
+            ce = quad_sum(ce);
+#pragma unroll
+            for (int m = 1; m < HT; m <<= 1) {
+                const float p2 = __shfl_xor(pmax, m), y2 = __shfl_xor(ymax, m);
+                const int ap2 = __shfl_xor(ap, m), ay2 = __shfl_xor(ay, m);
+                if (p2 > pmax || (p2 == pmax && ap2 < ap)) { pmax = p2; ap = ap2; }
+                if (y2 > ymax || (y2 == ymax && ay2 < ay)) { ymax = y2; ay = ay2; }
+            }
+            if (ok && part == 0) { a.c_err[img] = ce; a.d_cor[img] = ap == ay ? 1.f : 0.f; }
         }
-        a.c_err[img] = ce;
-        a.d_cor[img] = ap == ay ? 1.f : 0.f;
+        __syncthreads();
     }
-    if (S) {
-        int arg = 0; float rmax = 0.f;
-        for (int s = 0; s < S; ++s) {
-            float r = a.bias3[s];
-            for (int j = 0; j < R2; ++j) r += a2s[tid * GEN_R + j] * a.w3[j * S + s];
-            a.r[(size_t)img * a.r_stride + s] = r;
-            if (s == 0 || r > rmax) { rmax = r; arg = s; }             // first index on ties (tf.argmax)
-        }
-        if (a.child_idx[arg]) {
-            const int pos = atomicAdd(a.child_cnt[arg], 1);
-            if (pos < a.n) a.child_idx[arg][pos] = img;
+    if (!S) return;
+    // the children's lists: one reservation per (workgroup, sink), ranks within the workgroup in slot order
+    if (tid < MPNN_MAX_SINKS) {
+        int cnt = 0;
+        for (int k = 0; k < EV_SPW; ++k) cnt += arg_s[k] == tid ? 1 : 0;
+        base_s[tid] = (cnt > 0 && tid < S && a.child_idx[tid]) ? atomicAdd(a.child_cnt[tid], cnt) : -1;
+    }
+    __syncthreads();
+    if (tid < EV_SPW && arg_s[tid] >= 0) {
+        const int arg = arg_s[tid], base = base_s[arg];
+        if (base >= 0) {
+            int rank = 0;
+            for (int k = 0; k < tid; ++k) rank += arg_s[k] == arg ? 1 : 0;
+            if (base + rank < a.n) a.child_idx[arg][base + rank] = img_s[tid];
         }
     }
 }
@@ -684,7 +723,9 @@ extern "C" int mpnn_exit_tail_bwd_gen(const mpnn_exit_tail_bwd_args *dev_table, 
 extern "C" int mpnn_exit_ev_gen(const mpnn_exit_ev_args *dev_table, int count, int n_max, void *stream) {
     if (count <= 0 || n_max <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    hipLaunchKernelGGL(exit_ev_gen_k, dim3((n_max + 7) / 8, count), dim3(256), 0, (hipStream_t)stream, dev_table);
+    hipLaunchKernelGGL(ev_lin_gen_k, dim3((n_max + 15) / 16, g_gen_tiles, count), dim3(256), 0, (hipStream_t)stream, dev_table);
+    MPNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ev_tail_gen_k, dim3((n_max + EV_SPW - 1) / EV_SPW, count), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;
 }

@@ -115,7 +115,7 @@ class ExitEvArgs(C.Structure):
                 ('g2', P), ('be2', P), ('m2', P), ('v2', P), ('w3', P), ('bias3', P),
                 ('bn_eps', C.c_float), ('r', P), ('r_stride', C.c_int),
                 ('idx', P), ('cnt', P), ('n', C.c_int),
-                ('child_idx', P * 4), ('child_cnt', P * 4), ('R2', C.c_int)]
+                ('child_idx', P * 4), ('child_cnt', P * 4), ('R2', C.c_int), ('z', P), ('h1', P)]
 
 
 class ConvNhwcFwdArgs(C.Structure):

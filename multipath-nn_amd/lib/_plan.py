@@ -1400,6 +1400,9 @@ class Engine:
                             e.child_idx[i], e.child_cnt[i] = sb.ev_idx.data_ptr(), sb.ev_cnt.data_ptr()
             if b.ev_list is not None:
                 e.idx, e.cnt = b.ev_list[0].data_ptr(), b.ev_list[1].data_ptr()
+            if self.generic_exits:                       # (scratch maps of mpnn_exit_ev_gen)
+                e.z = b.z.data_ptr() if b.head is not None else None
+                e.h1 = b.h1.data_ptr() if b.router is not None else None
             if not self.generic_exits:
                 _hip.check(lib.mpnn_exit_ev_check(C.byref(e)), 'exit_ev record')
             recs[id(b)] = e

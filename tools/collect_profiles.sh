@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:?}
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 timeout 600 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-configs --no-dp-structure > $O/bench_under_rocprof.json 2> $O/kt.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-configs --no-dp-structure --no-experiment > $O/bench_under_rocprof.json 2> $O/kt.err
 cd $R
 python tools/analyze_trace.py $O/kt > $O/step_timeline.txt
 cp $O/kt/*kernel_stats.csv $O/kernel_stats.csv
