@@ -292,7 +292,7 @@ def test_host_only_entry_points_without_a_gpu():
     ok = lib.mpnn_exit_gen_check
     assert ok(128, 2048, 100, 32, 24, 3) == 0 and ok(256, 4096, 1024, 256, 256, 4) == 0 and ok(16, 256, 0, 0, 0, 0) == 0
     assert ok(257, 2048, 10, 16, 16, 2) == _hip.E_SHAPE          # channels
-    assert ok(128, 8192, 10, 16, 16, 2) == _hip.E_SHAPE          # features of the exit's input map
+    assert ok(128, 8192, 10, 16, 16, 2) == 0 and ok(128, 131072, 10, 16, 16, 2) == _hip.E_SHAPE      # features of the exit's input map
     assert ok(128, 2048, 1025, 16, 16, 2) == _hip.E_SHAPE        # classes
     assert ok(128, 2048, 10, 300, 16, 2) == _hip.E_SHAPE and ok(128, 2048, 10, 16, 300, 2) == _hip.E_SHAPE
     assert ok(128, 2048, 10, 16, 16, 5) == _hip.E_SHAPE and ok(128, 2048, 10, 16, 16, 1) == _hip.E_SHAPE      # sinks
