@@ -546,6 +546,11 @@ int mpnn_talr_momentum_step(float *params, float *accum, const float *grads,
 int mpnn_augment_batch(const float *x_src, const float *y_src, const int *draw,
                        float *x_out, float *y_out, int n, int H, int W, int C, int n_cls,
                        void *stream);
+/* The batches of `count` consumers (co-trained nets) from one dataset in ONE launch: consumer r's record buffer and
+ * destinations in dev_table[r] (device memory), n images each. */
+typedef struct { const int *draw;  float *x_out;  float *y_out; } mpnn_augment_dst;
+int mpnn_augment_batch_multi(const float *x_src, const float *y_src, const mpnn_augment_dst *dev_table, int count,
+                             int n, int H, int W, int C, int n_cls, void *stream);
 
 /* mpnn_slab_reduce and mpnn_bn_finalize in ONE launch (same arguments and semantics; the two are
  * independent of each other and both end the backward pass). */

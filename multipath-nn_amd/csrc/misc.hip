@@ -304,10 +304,10 @@ extern "C" int mpnn_compact_by_branch(const float *p_ev, int n, int *idx_out, in
 // dataset stays resident in HBM.  One workgroup per output image: fp64 per-channel mean through
 // LDS, then the gather.  C <= 4.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void augment_k(const float *__restrict__ x_src, const float *__restrict__ y_src,
-                                                 const int *__restrict__ draw, float *__restrict__ x_out,
-                                                 float *__restrict__ y_out, int H, int W, int C, int n_cls) {
-    const int i = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void augment_body(const int i, const float *__restrict__ x_src, const float *__restrict__ y_src,
+                                             const int *__restrict__ draw, float *__restrict__ x_out,
+                                             float *__restrict__ y_out, int H, int W, int C, int n_cls) {
+    const int tid = threadIdx.x;
     const int j = draw[i * 4], flip = draw[i * 4 + 1], du = draw[i * 4 + 2], dv = draw[i * 4 + 3];
     const float *a = x_src + (size_t)j * H * W * C;
     __shared__ double part[256][4];
@@ -338,6 +338,31 @@ __global__ __launch_bounds__(256) void augment_k(const float *__restrict__ x_src
     }
     if (y_src && y_out)
         for (int k = tid; k < n_cls; k += 256) y_out[(size_t)i * n_cls + k] = y_src[(size_t)j * n_cls + k];
+}
+
+__global__ __launch_bounds__(256) void augment_k(const float *__restrict__ x_src, const float *__restrict__ y_src,
+                                                 const int *__restrict__ draw, float *__restrict__ x_out,
+                                                 float *__restrict__ y_out, int H, int W, int C, int n_cls) {
+    augment_body(blockIdx.x, x_src, y_src, draw, x_out, y_out, H, W, C, n_cls);
+}
+
+// the batches of `count` consumers (co-trained nets, lib/_co.py) from one dataset in one launch: consumer r's record
+// buffer and destinations in dst[r], n images each
+__global__ __launch_bounds__(256) void augment_multi_k(const float *__restrict__ x_src, const float *__restrict__ y_src,
+                                                       const mpnn_augment_dst *__restrict__ dst, int n, int H, int W, int C,
+                                                       int n_cls) {
+    const int r = blockIdx.x / n;
+    const mpnn_augment_dst d = dst[r];
+    augment_body(blockIdx.x - r * n, x_src, y_src, d.draw, d.x_out, d.y_out, H, W, C, n_cls);
+}
+
+extern "C" int mpnn_augment_batch_multi(const float *x_src, const float *y_src, const mpnn_augment_dst *dev_table, int count,
+                                        int n, int H, int W, int C, int n_cls, void *stream) {
+    if (n <= 0 || count <= 0) return 0;
+    if (!x_src || !dev_table || C < 1 || C > 4 || H < 1 || W < 1) return MPNN_E_ARG;
+    hipLaunchKernelGGL(augment_multi_k, dim3(n * count), dim3(256), 0, (hipStream_t)stream, x_src, y_src, dev_table, n, H, W, C, n_cls);
+    MPNN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int mpnn_augment_batch(const float *x_src, const float *y_src, const int *draw, float *x_out, float *y_out,

@@ -44,8 +44,21 @@ class CoTrainer:
                 raise ValueError('co-trained nets live on one device')
         self.lib, self.dev = e0.lib, e0.dev
         self.K = len(self.nets)
+        # the nets' schedule / hyper-parameter values side by side in ONE device buffer: one upload per joint step instead of
+        # one per net (the learning rate changes every step).  The engines' own `hyp` become rows of it; programs that
+        # baked the old pointers in are dropped.
+        self.hyp_all = torch.zeros(self.K, _hip.HYP_N, device=self.dev)
+        for k, e in enumerate(self.engs):
+            self.hyp_all[k].copy_(e.hyp)
+            e.hyp = self.hyp_all[k]
+            e._hyp_sent = None
+            e._progs.clear()
+            e._graphs.clear()
+        self._hyp_ring = [(torch.zeros(self.K, _hip.HYP_N).pin_memory(), None) for _ in range(8)]
+        self._hyp_slot, self._hyp_sent, self._hyp_epochs = -1, None, None
         self.use_graph = e0.use_graph
         self._progs, self._graphs, self._keep, self._gens = {}, {}, [], None
+        self.prologue = None             # callable(stream): ONE launch that assembles every net's batch (Dataset.bind_cotrainer)
 
     # ------------------------------------------------------------------ the merged program
     def _program(self, n):
@@ -134,8 +147,10 @@ class CoTrainer:
     # ------------------------------------------------------------------ running
     def _eager(self, prog):
         st = torch.cuda.current_stream().cuda_stream
+        if self.prologue is not None:
+            self.prologue(st)
         for e in self.engs:
-            if e.prologue is not None:
+            if self.prologue is None and e.prologue is not None:
                 e.prologue(st)
             if not (prog['fold'] and e._acc_clean):
                 e._begin(True)
@@ -150,14 +165,29 @@ class CoTrainer:
         if len(feeds) != self.K:
             raise ValueError('one feed per co-trained net')
         ns = set()
-        for e, net, feed in zip(self.engs, self.nets, feeds):
-            n, mode = e._stage(feed)
+        hs = torch.empty(self.K, _hip.HYP_N)
+        for k, (e, net, feed) in enumerate(zip(self.engs, self.nets, feeds)):
+            n, mode = e._stage(feed, upload_hyp=False)
+            hs[k].copy_(e._hyp_stage)
             if mode != 'tr':
                 raise ValueError("co-training needs net.mode: 'tr' in every feed")
             ns.add(n)
             if not e._packs_fresh:
                 e._pack()
                 e._packs_fresh = True
+        epochs = tuple(getattr(e, '_hyp_epoch', 0) for e in self.engs)      # (a net that stepped alone rewrote its row)
+        if self._hyp_sent is None or epochs != self._hyp_epochs or not torch.equal(hs, self._hyp_sent):
+            self._hyp_epochs = epochs
+            r = self._hyp_slot = (self._hyp_slot + 1) % len(self._hyp_ring)
+            buf, ev = self._hyp_ring[r]
+            if ev is not None:
+                ev.synchronize()
+            buf.copy_(hs)
+            self.hyp_all.copy_(buf, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._hyp_ring[r] = (buf, ev)
+            self._hyp_sent = hs
         if len(ns) != 1:
             raise ValueError('co-trained nets step on batches of one size')
         n = ns.pop()
@@ -188,6 +218,11 @@ class CoTrainer:
         for e in self.engs:
             e.last_n, e.last_mode, e._last_fold = n, 'tr', prog['fold']
             e._bind_views(n)
+
+    def set_prologue(self, fn):
+        """fn(stream): the first launch of every joint step (replaces the nets' own prologues in the joint graph)."""
+        self.prologue = fn
+        self._graphs.clear()
 
     def invalidate(self):
         """Drop the merged programs and graphs (an engine reallocated its buffers: a larger batch came by)."""

@@ -148,6 +148,10 @@ class FinishNet(C.Structure):
                 ('inv_n', C.c_float), ('grad_scale', C.c_float), ('w_eq', P), ('packs', P), ('plain_seg', P), ('n_plain', C.c_int)]
 
 
+class AugmentDst(C.Structure):
+    _fields_ = [('draw', P), ('x_out', P), ('y_out', P)]
+
+
 _SIGS = {
     'mpnn_pack_weights': [P, P, P, C.c_int, P],
     'mpnn_step_begin': [P, P, P, C.c_int, P, C.c_long, P],
@@ -161,6 +165,7 @@ _SIGS = {
     'mpnn_debug_set_trace': [P],
     'mpnn_backward_finish': [P, P, P, C.c_int, P, P, P, P, C.c_int, C.c_float, C.c_int, P, P],
     'mpnn_augment_batch': [P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P],
+    'mpnn_augment_batch_multi': [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P],
     'mpnn_msconv_bwd_scale_slots': [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     'mpnn_bn_relu_fwd': [C.POINTER(Act), P, C.c_long, P],
     'mpnn_bn_bwd_reduce': [P, C.POINTER(BnCtx), P, P, C.c_long, P],

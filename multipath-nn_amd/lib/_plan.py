@@ -1468,7 +1468,7 @@ class Engine:
         return ra
 
     # ------------------------------------------------------------------ running
-    def _stage(self, feed):
+    def _stage(self, feed, upload_hyp=True):
         net = self.net
         x0 = feed[net.x0]
         n = int(x0.shape[0])
@@ -1489,6 +1489,9 @@ class Engine:
         put(self.x0[:n], x0)
         put(self.y[:n], feed[net.y])
         h = self._hyp_values(feed, n, put)
+        if not upload_hyp:                      # (lib/_co.py uploads the schedule values of all its nets at once)
+            self._hyp_sent = None
+            return n, feed.get(net.mode, net.mode.default)
         if self._hyp_sent is None or not torch.equal(h, self._hyp_sent):
             # Upload through a ring of pinned buffers: the copy is asynchronous and, under hipGraph
             # replay, the host runs many steps ahead of the stream -- rewriting ONE staging buffer in place
@@ -1504,6 +1507,7 @@ class Engine:
             ev.record(torch.cuda.current_stream())
             self._hyp_ring[k] = (buf, ev)
             self._hyp_sent = h.clone()
+            self._hyp_epoch = getattr(self, '_hyp_epoch', 0) + 1       # (lib/_co.py: this row of its buffer was rewritten)
         return n, feed.get(net.mode, net.mode.default)
 
     def _hyp_values(self, feed, n, put=None):
@@ -1824,6 +1828,7 @@ class Engine:
         ev.record(torch.cuda.current_stream())
         self._hypk_ring[r] = (buf, ev)
         self._hyp_sent = None                                   # (the graph rewrites self.hyp on the device)
+        self._hyp_epoch = getattr(self, '_hyp_epoch', 0) + 1
         if not self._packs_fresh:
             self._pack()
             self._packs_fresh = True

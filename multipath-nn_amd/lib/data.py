@@ -217,6 +217,53 @@ class Dataset:
                          lambda stream, j: self._augment_launch(n, eng.x0[:n], eng.y[:n], stream, draws[j]))
         return BoundInput(eng, 'x0', n), BoundInput(eng, 'y', n)
 
+    def bind_cotrainer(self, co, n=128):
+        """bind_engine for every net of a co-trained group (lib/_co.py), plus ONE gather launch for the whole group at the
+        head of the joint step (mpnn_augment_batch_multi: K x n workgroups instead of K launches of n) reading ONE
+        record buffer [K, n, 4] that stage_cotrainer_draws fills with one upload per step.  Returns the list of (x0, y)
+        feed values, one pair per net."""
+        import torch
+        from . import _hip
+        bound = [self.bind_engine(e, n) for e in co.engs]
+        K = len(co.engs)
+        h, w, c = self.x0_tr.shape[1:]
+        g = dict(n=n, dev=torch.zeros((K, n, 4), dtype=torch.int32, device=self._dev), slot=-1,
+                 ring=[(torch.zeros((K, n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING)])
+        self.__dict__.setdefault('_groups', {})[id(co)] = g
+        state = {}
+
+        def launch(stream):
+            key = tuple(e._gen for e in co.engs)              # (the engines' input buffers may have been reallocated)
+            if state.get('key') != key:
+                recs = []
+                for k, e in enumerate(co.engs):
+                    d = _hip.AugmentDst()
+                    d.draw, d.x_out, d.y_out = g['dev'][k].data_ptr(), e.x0.data_ptr(), e.y.data_ptr()
+                    recs.append(d)
+                state['key'], state['tab'] = key, _hip.to_device_table(recs, self._dev)
+            _hip.check(_hip.load().mpnn_augment_batch_multi(self._x_dev.data_ptr(), self._y_dev.data_ptr(), state['tab'].data_ptr(),
+                                                             K, n, h, w, c, self.y_tr.shape[1], stream),
+                       'augment_batch_multi')
+        co.set_prologue(launch)
+        return bound
+
+    def stage_cotrainer_draws(self, co, r_shift=4):
+        """One step's augmentation records of EVERY net of a bound group: the reference's draws, net after net, from the one
+        numpy stream; one asynchronous upload for the whole group."""
+        import torch
+        g = self._groups[id(co)]
+        k = g['slot'] = (g['slot'] + 1) % len(g['ring'])
+        buf, ev = g['ring'][k]
+        if ev is not None:
+            ev.synchronize()
+        out = buf.numpy()
+        for r in range(out.shape[0]):
+            _draw_augmentation_fast(g['n'], len(self.x0_tr), self._sym_u8, r_shift, out=out[r], all_sym=self._all_sym)
+        g['dev'].copy_(buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        g['ring'][k] = (buf, ev)
+
     def training_batch(self, n=128):
         return batch(self.x0_tr, self.y_tr, n)
 

@@ -136,10 +136,12 @@ def test_train_nets_cli_co_train(tmp_path):
         assert desc['type'] == 'ActorNet' and 0 <= desc['stats_ts']['acc'] <= 1
 
 
-def test_cotrained_pipeline_feeds_each_net_its_own_batches():
+@pytest.mark.parametrize('joint', [True, False])
+def test_cotrained_pipeline_feeds_each_net_its_own_batches(joint):
     """Co-trained nets bound to one Dataset: every net trains on the batch staged for IT (its own record buffer), the draws
     come from the one numpy stream in net order, step after step -- also after a larger evaluation batch reallocated one
-    engine's input buffers between two steps (the joint program is rebuilt)."""
+    engine's input buffers between two steps (the joint program is rebuilt).  joint: ONE gather launch for the whole group
+    (Dataset.bind_cotrainer, mpnn_augment_batch_multi) instead of one per net."""
     import arch_and_hypers as A
     from lib._co import CoTrainer
     from lib.data import Dataset
@@ -148,8 +150,8 @@ def test_cotrained_pipeline_feeds_each_net_its_own_batches():
     nets = _nets([A.ac_chain(k_cpt=k) for k in (0.0, 1e-9, 4e-9)])
     engs = [net.engine() for net in nets]
     n = 32
-    bound = [ds.bind_engine(e, n) for e in engs]
     co = CoTrainer(nets)
+    bound = ds.bind_cotrainer(co, n) if joint else [ds.bind_engine(e, n) for e in engs]
     np.random.seed(11)
     want = []
     state0 = np.random.get_state()
@@ -159,8 +161,11 @@ def test_cotrained_pipeline_feeds_each_net_its_own_batches():
     np.random.set_state(state0)
     for t in range(5):
         feeds = []
+        if joint:
+            ds.stage_cotrainer_draws(co)
         for net, e, (x0, y) in zip(nets, engs, bound):
-            ds.stage_training_draws(n, eng=e)
+            if not joint:
+                ds.stage_training_draws(n, eng=e)
             feeds.append({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.01, net.τ: 1.0})
         co.run(feeds)
         torch.cuda.synchronize()

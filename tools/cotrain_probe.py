@@ -65,3 +65,26 @@ for K in Ks:
             print('   %-16s %-44s %7.1f us  %6.1f TFLOP/s' % (op.what, op.tag[:44], t * 1e3, op.flops / (t * 1e-3) / 1e12 if t else 0))
         for e in co.engs: e.mark_dirty()
     del co, nets, feeds
+
+if os.environ.get('PIPE'):
+    # the same with the input pipeline: every net draws its own batch per step (the reference's draws, one numpy stream),
+    # K record uploads and K on-device gathers at the head of the joint graph
+    from lib.data import Dataset
+    for K in Ks:
+        nets, feeds = make(K)
+        ds = Dataset.synthetic(n_tr=4096, n_ts=256, seed=1)
+        engs = [net.engine() for net in nets]
+        co = CoTrainer(nets)
+        bound = ds.bind_cotrainer(co, n) if os.environ.get('PIPE') != 'each' else [ds.bind_engine(e, n) for e in engs]
+        fs = [{net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.1, net.τ: 1.0} for net, (x0, y) in zip(nets, bound)]
+
+        def step():
+            if os.environ.get('PIPE') != 'each':
+                ds.stage_cotrainer_draws(co)
+            else:
+                for e in engs:
+                    ds.stage_training_draws(n, eng=e)
+            co.run(fs)
+        ms = timed(step, reps=100)
+        print('K = %d co-trained WITH the input pipeline: %.1f us per joint step = %.0f img/s' % (K, ms * 1e3, K * n / (ms * 1e-3)), flush=True)
+        del co, nets, feeds
