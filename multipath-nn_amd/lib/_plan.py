@@ -592,7 +592,8 @@ class Engine:
         groups = max(1, b.C[i] // 64) if b.C[i] % 64 == 0 else (b.C[i] // 32 if b.C[i] % 32 == 0 else b.C[i] // 16)
         if fused:
             groups = b.C[i] // 64 if b.C[i] % 64 == 0 else b.C[i] // 16    # as mpnn_msconv_bwd_scale
-        budget = 512
+        cap = int(os.environ.get('MPNN_WG_CAP', '512'))
+        budget = cap
         if fused:
             # about half of the workgroups that are resident at once: the dgrad bodies of the same
             # launch take the rest, and everything starts together
@@ -601,7 +602,7 @@ class Engine:
             slots = self.lib.mpnn_msconv_bwd_scale_slots(b.H[i], b.W[i], b.C[i], has_dgrad, 1 if i > 0 else 0, dg_items)
             if slots > 0:
                 div = float(os.environ.get('MPNN_WG_DIV', '2'))
-                budget = min(512, int(slots / div) if has_dgrad else slots)      # (a third / a quarter: measured slower)
+                budget = min(cap, int(slots / div) if has_dgrad else slots)      # (a third / a quarter: measured slower)
                 if has_dgrad and b.C[i] % 64 == 0 and dg_items > slots // 3:
                     # a 64-channel layer with three workgroups per CU: the input-gradient bodies get one workgroup
                     # per (tile, row) if that fits, the weight gradients the rest
