@@ -49,8 +49,17 @@ x0, y = ds.bind_engine(eng, N)
 def bound(t):
     ds.stage_training_draws(N, eng=eng)
     net.train.run(feed(x0, y, t))
-full = timed(bound, 'pipeline as train-nets runs it (draws + async upload; augmentation inside the step graph)')
+full = timed(bound, 'pipeline, one hipGraph replay per step (draws + async upload; augmentation inside the step graph)')
 print('pipeline / resident: %.3f' % (full / base))
+
+
+def bound4(t):
+    # (as train-nets runs it since round 5: four iterations per hipGraph replay, Engine.run_steps; `timed` counts calls)
+    for j in range(4):
+        ds.stage_training_draws(N, eng=eng, slot=j)
+    net.train.run_steps([feed(x0, y, 4 * t + j) for j in range(4)])
+full4 = timed(bound4, 'pipeline as train-nets runs it: FOUR steps per replay (time per call = 4 steps)') / 4
+print('  -> %.3f ms per step = %.0f img/s;  pipeline / resident: %.3f' % (full4 * 1e3, N / full4, full4 / base))
 
 sym = _sym_of_sources(ds.y_tr, ds.m_sym)
 t0 = time.perf_counter()
