@@ -8,6 +8,9 @@
 #ifndef MPNN_WG_NINE
 #define MPNN_WG_NINE 1       // 0: the tap-slot form of the weight-gradient MFMA loop (A/B builds)
 #endif
+#ifndef MPNN_WG_SMALLC
+#define MPNN_WG_SMALLC 1     // 0: block 0's image chunk in the general nine-tap form (A/B builds)
+#endif
 #include "conv_kernel.h"
 
 struct WgP {
@@ -24,9 +27,14 @@ template <> struct WGeom<0> { static constexpr int PS = 113; };
 template <> struct WGeom<1> { static constexpr int PS = 113; };
 template <> struct WGeom<2> { static constexpr int PS = 145; };
 
-template <int GK, int OT, int PART>
+// SMALLC (PART == 0, OT == 1, a 1- or 3-channel image as operand A: block 0): the contraction with the roles swapped --
+// D[i = cout][j = (tap, c)] += sum_pixels g[pixel][cout] * x[pixel + tap][c], 9 C <= 27 columns = two N-tiles -- EIGHT
+// MFMAs per wave and tile instead of 36: in the general form 13 of the 16 rows of every tap's M-tile are padding, and the
+// launch that is nothing but this body (h32 3 -> 16) was bound by the MFMA pipe at 14 TFLOP/s of useful work.
+template <int GK, int OT, int PART, bool SMALLC = false>
 __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt, float *cA,
                                            const int bx, const int by, const int bz, const int gx) {
+    static_assert(!SMALLC || (PART == 0 && OT == 1 && MPNN_WG_NINE), "SMALLC: the image chunk of a 16-channel group");
     using G = Geom<GK>;
     constexpr int PS = WGeom<GK>::PS, R = G::R, HR = G::TH + 2;
     constexpr int GS = OT * 16 + 4;                  // g tile row stride (floats)
@@ -57,14 +65,28 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
     // gradient is a plain sum of the g values the wave reads anyway.
     constexpr bool NINE = (OT == 1 || OT == 4) && MPNN_WG_NINE;
     f32x4 acc[NINE ? 1 : 3][OT];
-    f32x4 acc9[NINE ? 9 : 1];
+    f32x4 acc9[(NINE && !SMALLC) ? 9 : 1];
+    [[maybe_unused]] f32x4 accS[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // SMALLC: column idx = nt * 16 + li of the two N-tiles = (tap, c) pair idx = tap * C + c; its LDS offset from the
+    // pixel's slot (floats) and whether it exists
+    [[maybe_unused]] int offS[2];
+    [[maybe_unused]] bool onS[2];
+    if constexpr (SMALLC) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int idx = nt * 16 + li, n9 = 9 * c.a.C;
+            onS[nt] = idx < n9;
+            const int ic = onS[nt] ? idx : 0, tap = ic / c.a.C, cc = ic - tap * c.a.C;
+            offS[nt] = ((tap / 3) * R + (tap % 3)) * 4 + cc;          // (plane 0: channels 0..3 of the chunk)
+        }
+    }
     float bsum = 0.f;
 #pragma unroll
     for (int ti = 0; ti < (NINE ? 1 : 3); ++ti)
 #pragma unroll
         for (int nt = 0; nt < OT; ++nt) acc[ti][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tap = 0; tap < (NINE ? 9 : 1); ++tap) acc9[tap] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tap = 0; tap < ((NINE && !SMALLC) ? 9 : 1); ++tap) acc9[tap] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float *tf = (const float *)tile;
     const int a_lane = (li >> 2) * PS * 4 + (li & 3);      // plane + component of channel li
     const float one_hot = li == 0 ? 1.f : 0.f;
@@ -218,6 +240,22 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         lds_barrier();
         if (t == sq0) trace_stamp(2);
         if (t + NS * sqd < sqn) request(sel, t + NS * sqd);          // flies under NS tiles of MFMAs
+        if constexpr (SMALLC) {
+            float gq[4], xq[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gq[j] = gt[(wid * 16 + 4 * g + j) * GS + li];          // A[i = cout li][k = g]: pixel 4 g + j of this wave's group
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) xq[j][nt] = tf[slot9[j] * 4 + offS[nt]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bsum += gq[j];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    accS[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[j], onS[nt] ? xq[j][nt] : 0.f, accS[nt], 0, 0, 0);
+            }
+        } else
         if constexpr (NINE) {
 #pragma unroll
             for (int kk = 0; kk < (OT == 4 ? 4 : 1); ++kk) {
@@ -302,6 +340,35 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
             b += __shfl_xor(b, 16);
             b += __shfl_xor(b, 32);
             if (g == 0) p.db[soff + co0 + wid * 16 + li] = b;
+        }
+    } else if constexpr (SMALLC) {
+        // D rows = cout (4 g + r), columns = (tap, c) pairs; the four waves' partial sums (their pixel groups) meet in LDS,
+        // summed in wave order; dw[(tap * C + c) * Cout + cout] = dw[idx * Cout + cout]
+        f32x4 *part4 = tile;                             // [wave][N-tile][lane]
+        float *partf = (float *)tile;
+        lds_barrier();                                   // the MFMA reads of the last tile are done
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) part4[(wid * 2 + nt) * 64 + lane] = accS[nt];
+        lds_barrier();
+        {
+            const int r = wid, n9 = 9 * C;               // thread = (component r, lane): two N-tiles each
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += partf[((w * 2 + nt) * 64 + lane) * 4 + r];
+                const int idx = nt * 16 + li, co = 4 * g + r;
+                if (idx < n9) dw[(size_t)idx * c.Cout + co0 + co] = v;
+            }
+        }
+        if (by == 0) {
+            float b = bsum;
+            b += __shfl_xor(b, 16);
+            b += __shfl_xor(b, 32);
+            lds_barrier();
+            if (g == 0) partf[wid * 16 + li] = b;
+            lds_barrier();
+            if (tid < 16) p.db[soff + co0 + tid] = (partf[tid] + partf[16 + tid]) + (partf[32 + tid] + partf[48 + tid]);
         }
     } else if constexpr (NINE) {
         // OT == 1: the four waves hold partial sums over their pixel groups; they meet in LDS three taps at a time

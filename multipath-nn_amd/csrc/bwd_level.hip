@@ -20,7 +20,7 @@
 struct BwdRec { BwdScaleP q; int gk, wide, r0, r1; };
 struct BwdLevelQ { int n; int w0[MPNN_BWD_LEVEL_MAX]; int reps, wpr; };    // reps > 1: `reps` copies of the level's wpr workgroups, copy r on records tab[r * n ..]
 
-template <int GK, int OT>
+template <int GK, int OT, bool SMALLC>
 __device__ __forceinline__ void level_wgrad(const BwdRec *__restrict__ r, int l, char *smem) {
     constexpr int GS = OT * 16 + 4;
     const WgP w = r->q.w;
@@ -31,10 +31,11 @@ __device__ __forceinline__ void level_wgrad(const BwdRec *__restrict__ r, int l,
     float *gt = (float *)(smem + 4 * WGeom<GK>::PS * 16);
     float *cA = gt + 64 * GS;
     if (chunk >= ((w.c.a.C + 15) >> 4)) wgrad_body<GK, OT, 1>(w, tile, gt, cA, bx, chunk, bz, gxw);
+    else if (SMALLC && OT == 1 && w.c.a.C <= 3) { if constexpr (SMALLC && OT == 1) wgrad_body<GK, 1, 0, true>(w, tile, gt, cA, bx, chunk, bz, gxw); }
     else                                 wgrad_body<GK, OT, 0>(w, tile, gt, cA, bx, chunk, bz, gxw);
 }
 
-template <int GK, int OTMASK>
+template <int GK, int OTMASK, bool SMALLC>
 __device__ __forceinline__ void level_member(const BwdRec *__restrict__ r, int id, char *smem) {
     const int gxh = r->q.gxh, gxv = r->q.gxv;
     const int wh = r->q.gyh * gxh, wv = r->q.gyv * gxv;
@@ -49,10 +50,10 @@ __device__ __forceinline__ void level_member(const BwdRec *__restrict__ r, int i
     } else {
         const int l = id - wh - wv;
         if constexpr (OTMASK == 3) {
-            if (r->wide) level_wgrad<GK, 4>(r, l, smem);
-            else         level_wgrad<GK, 1>(r, l, smem);
-        } else if constexpr (OTMASK == 2) level_wgrad<GK, 4>(r, l, smem);
-        else level_wgrad<GK, 1>(r, l, smem);
+            if (r->wide) level_wgrad<GK, 4, false>(r, l, smem);
+            else         level_wgrad<GK, 1, SMALLC>(r, l, smem);
+        } else if constexpr (OTMASK == 2) level_wgrad<GK, 4, false>(r, l, smem);
+        else level_wgrad<GK, 1, SMALLC>(r, l, smem);
     }
 }
 
@@ -72,7 +73,9 @@ template <int GKMASK, int OTMASK> struct LevelSmemAll {
 #ifndef MPNN_OCC_LEVEL
 #define MPNN_OCC_LEVEL 3     // waves per SIMD of the levels without 64-channel weight-gradient groups
 #endif
-template <int GKMASK, int OTMASK>
+// SMALLC: some member's weight gradients have a 1- or 3-channel image as operand A (block 0): those members' image chunk
+// runs the swapped-role body (bwd_bodies.h); levels without such a member keep the instantiation they had.
+template <int GKMASK, int OTMASK, bool SMALLC = false>
 __global__ __launch_bounds__(256, (OTMASK & 2) ? 2 : MPNN_OCC_LEVEL) void bwd_level_k(const BwdRec *__restrict__ tab, const BwdLevelQ lq) {
     __shared__ __attribute__((aligned(16))) char smem[LevelSmemAll<GKMASK, OTMASK>::BYTES];
     int id = blockIdx.x;
@@ -84,28 +87,29 @@ __global__ __launch_bounds__(256, (OTMASK & 2) ? 2 : MPNN_OCC_LEVEL) void bwd_le
     const BwdRec *__restrict__ r = tab + m;
     const int gk = r->gk;
     trace_note(11, m + 1);
-    if constexpr ((GKMASK & 1) != 0) { if (gk == 0) { level_member<0, OTMASK>(r, id - w0, smem); return; } }
-    if constexpr ((GKMASK & 2) != 0) { if (gk == 1) { level_member<1, OTMASK>(r, id - w0, smem); return; } }
-    if constexpr ((GKMASK & 4) != 0) { if (gk == 2) { level_member<2, OTMASK>(r, id - w0, smem); return; } }
+    if constexpr ((GKMASK & 1) != 0) { if (gk == 0) { level_member<0, OTMASK, SMALLC>(r, id - w0, smem); return; } }
+    if constexpr ((GKMASK & 2) != 0) { if (gk == 1) { level_member<1, OTMASK, SMALLC>(r, id - w0, smem); return; } }
+    if constexpr ((GKMASK & 4) != 0) { if (gk == 2) { level_member<2, OTMASK, SMALLC>(r, id - w0, smem); return; } }
 }
 
 // ------------------------------- host ----------------------------------------
 typedef void (*LevelKern)(const BwdRec *, const BwdLevelQ);
-template <int OTMASK>
+template <int OTMASK, bool SMALLC>
 static LevelKern level_kernel_ot(int gkmask) {
     switch (gkmask) {
-        case 1: return bwd_level_k<1, OTMASK>;
-        case 2: return bwd_level_k<2, OTMASK>;
-        case 3: return bwd_level_k<3, OTMASK>;
-        case 4: return bwd_level_k<4, OTMASK>;
-        case 5: return bwd_level_k<5, OTMASK>;
-        case 6: return bwd_level_k<6, OTMASK>;
-        case 7: return bwd_level_k<7, OTMASK>;
+        case 1: return bwd_level_k<1, OTMASK, SMALLC>;
+        case 2: return bwd_level_k<2, OTMASK, SMALLC>;
+        case 3: return bwd_level_k<3, OTMASK, SMALLC>;
+        case 4: return bwd_level_k<4, OTMASK, SMALLC>;
+        case 5: return bwd_level_k<5, OTMASK, SMALLC>;
+        case 6: return bwd_level_k<6, OTMASK, SMALLC>;
+        case 7: return bwd_level_k<7, OTMASK, SMALLC>;
     }
     return nullptr;
 }
-static LevelKern level_kernel(int gkmask, int otmask) {
-    return (otmask & 2) ? level_kernel_ot<3>(gkmask) : level_kernel_ot<1>(gkmask);
+static LevelKern level_kernel(int gkmask, int otmask, bool smallc = false) {
+    if (smallc && MPNN_WG_SMALLC) return (otmask & 2) ? level_kernel_ot<3, true>(gkmask) : level_kernel_ot<1, true>(gkmask);
+    return (otmask & 2) ? level_kernel_ot<3, false>(gkmask) : level_kernel_ot<1, false>(gkmask);
 }
 
 static int geom_kind(int H, int W) {
@@ -132,10 +136,12 @@ extern "C" int mpnn_msconv_bwd_level_slots(const int *H, const int *W, const int
 }
 
 // records + first-workgroup table + kernel variant of a level; total = workgroups of the launch
+static bool g_level_smallc = false;      // (set by level_build: some member's operand A is a 1- / 3-channel image)
 static int level_build(const mpnn_bwd_member *mem, int count, BwdRec *recs, BwdLevelQ &lq, int &gkmask, int &otmask, int &total) {
     if (!mem || count < 1 || count > MPNN_BWD_LEVEL_MAX) return MPNN_E_ARG;
     gkmask = otmask = total = 0;
     lq.n = count;
+    g_level_smallc = false;
     BwdRec scratch;
     for (int k = 0; k < count; ++k) {
         const mpnn_bwd_member &m = mem[k];
@@ -165,6 +171,7 @@ static int level_build(const mpnn_bwd_member *mem, int count, BwdRec *recs, BwdL
         total += q.gyh * q.gxh + q.gyv * q.gxv + gyw * q.gxw;
         gkmask |= 1 << r.gk;
         otmask |= r.wide ? 2 : 1;
+        if (!r.wide && w->a.C <= 3) g_level_smallc = true;
     }
     return 0;
 }
@@ -208,7 +215,7 @@ extern "C" int mpnn_msconv_bwd_level_rep(const mpnn_bwd_member *members, int cou
     int gkmask, otmask, total;
     const int rc = level_build_rep(members, count, reps, nullptr, lq, gkmask, otmask, total);
     if (rc) return rc;
-    LevelKern kern = level_kernel(gkmask, otmask);
+    LevelKern kern = level_kernel(gkmask, otmask, g_level_smallc);
     if (!kern) return MPNN_E_SHAPE;
     hipLaunchKernelGGL(kern, dim3(total * reps), dim3(256), 0, (hipStream_t)stream, (const BwdRec *)dev_records, lq);
     MPNN_LAUNCH_CHECK();
@@ -222,7 +229,7 @@ extern "C" int mpnn_msconv_bwd_level(const mpnn_bwd_member *members, int count, 
     int gkmask, otmask, total;
     const int rc = level_build(members, count, recs, lq, gkmask, otmask, total);
     if (rc) return rc;
-    LevelKern kern = level_kernel(gkmask, otmask);
+    LevelKern kern = level_kernel(gkmask, otmask, g_level_smallc);
     if (!kern) return MPNN_E_SHAPE;
     hipLaunchKernelGGL(kern, dim3(total), dim3(256), 0, (hipStream_t)stream, (const BwdRec *)dev_records, lq);
     MPNN_LAUNCH_CHECK();

@@ -24,7 +24,7 @@
 #include "bwd_bodies.h"
 #include "opt_body.h"
 
-template <int GK, int OT>
+template <int GK, int OT, bool SMALLC = false>
 __global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
     constexpr int PS = WGeom<GK>::PS, GS = OT * 16 + 4;
     // one arena: the tile and g buffers are contiguous (the 16-channel body's final reduction uses them as one)
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
     float *gt = (float *)(smem + 4 * PS * 16);
     float *cA = gt + 64 * GS;
     if ((int)blockIdx.y >= ((p.c.a.C + 15) >> 4)) wgrad_body<GK, OT, 1>(p, tile, gt, cA, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
-    else                                           wgrad_body<GK, OT, 0>(p, tile, gt, cA, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+    else                                           wgrad_body<GK, OT, 0, SMALLC>(p, tile, gt, cA, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void wgrad_k(const WgP p) {
 // HASV = the launch has a dgrad-vert body.  Launches without one (the finest scale of a block) get
 // their own instantiation: the dgrad-vert epilogue prefetch costs ~30 registers, and the narrow
 // variant without it fits 4 waves per SIMD (1024 resident workgroups instead of 768).
-template <int GK, int OT, int NCH, bool HASV>
+// SMALLC = operand A of the weight gradients is a 1- or 3-channel image (block 0): its own instantiation, with the
+// swapped-role weight-gradient body for the image chunk INSTEAD of the general one (both in one kernel spilled).
+template <int GK, int OT, int NCH, bool HASV, bool SMALLC = false>
 __global__ __launch_bounds__(256, (OT == 1 && NCH == 1 && GK != 2 ? (HASV || GK == 1 ? MPNN_OCC_BWD : MPNN_OCC) : 2)) void bwd_scale_k(const BwdScaleP q) {   // (4x4 maps: few workgroups, no spills at 2 waves)
     constexpr int CB = ConvSmem<GK, 4, 16, NCH>::BYTES;
     constexpr int GS = OT * 16 + 4;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256, (OT == 1 && NCH == 1 && GK != 2 ? (HASV || GK 
         float *gt = (float *)(smem + 4 * WGeom<GK>::PS * 16);
         float *cA = gt + 64 * GS;
         if (chunk >= ((q.w.c.a.C + 15) >> 4)) wgrad_body<GK, OT, 1>(q.w, tile, gt, cA, bx, chunk, bz, q.gxw);
-        else                                   wgrad_body<GK, OT, 0>(q.w, tile, gt, cA, bx, chunk, bz, q.gxw);
+        else                                   wgrad_body<GK, OT, 0, SMALLC>(q.w, tile, gt, cA, bx, chunk, bz, q.gxw);
     }
 }
 
@@ -92,7 +94,8 @@ static int wgrad_launch(const WgP &p, int split, hipStream_t st) {
     } else if (c.Cout % 32 == 0) {
         hipLaunchKernelGGL((wgrad_k<GK, 2>), dim3(split, nch, c.Cout / 32), block, 0, st, p);
     } else if (c.Cout % 16 == 0) {
-        hipLaunchKernelGGL((wgrad_k<GK, 1>), dim3(split, nch, c.Cout / 16), block, 0, st, p);
+        if (c.a.C <= 3 && MPNN_WG_SMALLC) hipLaunchKernelGGL((wgrad_k<GK, 1, true>), dim3(split, nch, c.Cout / 16), block, 0, st, p);
+        else hipLaunchKernelGGL((wgrad_k<GK, 1>), dim3(split, nch, c.Cout / 16), block, 0, st, p);
     } else return MPNN_E_SHAPE;
     MPNN_LAUNCH_CHECK();
     return 0;
@@ -146,7 +149,8 @@ int mpnn_fill_dgrad_horz(const mpnn_dgrad_horz_args *a, ConvP &p);     // conv_d
 int mpnn_fill_dgrad_vert(const mpnn_dgrad_vert_args *a, ConvP &p);
 
 template <int GK>
-static auto bwd_scale_kernel(bool wide, bool deep, bool hasv) -> void (*)(const BwdScaleP) {
+static auto bwd_scale_kernel(bool wide, bool deep, bool hasv, bool smallc = false) -> void (*)(const BwdScaleP) {
+    if (smallc && !wide && !deep && MPNN_WG_SMALLC) return hasv ? bwd_scale_k<GK, 1, 1, true, true> : bwd_scale_k<GK, 1, 1, false, true>;
     if (hasv) return deep ? (wide ? bwd_scale_k<GK, 4, 2, true> : bwd_scale_k<GK, 1, 2, true>)
                           : (wide ? bwd_scale_k<GK, 4, 1, true> : bwd_scale_k<GK, 1, 1, true>);
     return deep ? (wide ? bwd_scale_k<GK, 4, 2, false> : bwd_scale_k<GK, 1, 2, false>)
@@ -196,7 +200,7 @@ static int bwd_scale_launch(BwdScaleP &q, bool has_h, bool has_v, int split, hip
     static const int nch_env = [] { const char *e = getenv("MPNN_CONV_NCH"); return e ? atoi(e) : 0; }();
     bool deep = GK != 0 && (q.w.c.Cout % 32) == 0 && (has_h || has_v);
     if (nch_env != 2) deep = false;        // 32-channel units: opt-in (MPNN_CONV_NCH=2); their 82 KB of LDS leaves ONE workgroup per CU
-    void (*kern)(const BwdScaleP) = bwd_scale_kernel<GK>(wide, deep, has_v);
+    void (*kern)(const BwdScaleP) = bwd_scale_kernel<GK>(wide, deep, has_v, q.w.c.a.C <= 3);
     // Fit the grid to what is resident at once: the weight-gradient rows keep their split x rows
     // workgroups (the slabs are sized for them), the two dgrad bodies share the rest by work.
     const long slots = resident_slots((const void *)kern, 0, 256, wide_cap(wide, (long)tiles * (q.gyh + q.gyv)));
