@@ -680,12 +680,15 @@ class Engine:
     # BatchNorm-backward epilogue, a 16-channel weight-gradient tile is cheaper than a dgrad unit (nine-tap
     # accumulation, lean staging), 64-channel groups have four times its MFMAs.
     _LAT = dict(h=1.0, v=1.4, w1=float(os.environ.get('MPNN_LAT_W1', '0.75')), w4=float(os.environ.get('MPNN_LAT_W4', '2.6')))
+    # co-trained groups (throughput-bound launches; swept at K = 8: w4 2.6 -> 2 086 us per joint step, 3.4 -> 2 067, 4.5 -> 2 090)
+    _LAT_CO = dict(h=1.0, v=1.4, w1=float(os.environ.get('MPNN_LAT_W1', '0.75')), w4=float(os.environ.get('MPNN_LAT_W4', '3.4')))
 
     def _level_budget(self, grp, n):
         """Workgroups of every body of a level launch: the assignment that minimises the longest serial chain
         (items per workgroup x item latency) over all bodies with everything resident at once -- small members get
         (nearly) one item per workgroup, the large member the rest.  None: no kernel variant covers the shapes."""
         lib = self.lib
+        LAT = self._LAT if self.co_share == 1 else self._LAT_CO
         H = (C.c_int * len(grp))(*[b.H[i] for _, b, i in grp])
         W = (C.c_int * len(grp))(*[b.W[i] for _, b, i in grp])
         Co = (C.c_int * len(grp))(*[b.C[i] for _, b, i in grp])
@@ -698,12 +701,12 @@ class Engine:
             tiles = lib.mpnn_wgrad_tiles(n, b.H[i], b.W[i])
             units = b.C[i] // 16
             if b.parent is not None:
-                bodies.append((k, 'h', b.parent.C[b.in_map[i]] // 16, tiles, self._LAT['h'] * units))
+                bodies.append((k, 'h', b.parent.C[b.in_map[i]] // 16, tiles, LAT['h'] * units))
             if i > 0:
-                bodies.append((k, 'v', b.C[i - 1] // 16, tiles, self._LAT['v'] * units))
+                bodies.append((k, 'v', b.C[i - 1] // 16, tiles, LAT['v'] * units))
             ot = 4 if b.C[i] % 64 == 0 else 1
             nch = (b.Cin[i] + 15) // 16 + ((b.C[i - 1] + 15) // 16 if i > 0 else 0)
-            bodies.append((k, 'w', nch * (b.C[i] // (16 * ot)), tiles, self._LAT['w%d' % ot]))
+            bodies.append((k, 'w', nch * (b.C[i] // (16 * ot)), tiles, LAT['w%d' % ot]))
         if sum(rows for _, _, rows, _, _ in bodies) > slots:
             return None
 
