@@ -284,6 +284,8 @@ class ConvEngine:
             e.y, e.eps_ce, e.c_err, e.d_cor = self.y.data_ptr(), float(ce.hypers.ϵ), self.c_err.data_ptr(), self.d_cor.data_ptr()
             if not self.generic:
                 self._chk(lib.mpnn_exit_ev_check(C.byref(e)), 'exit_ev record')
+            else:
+                e.z = self.z.data_ptr()            # (scratch map of mpnn_exit_ev_gen: the head logits)
             t_e = _hip.to_device_table([e], self.dev)
             keep.append(t_e)
             self._chk((lib.mpnn_exit_ev_gen if self.generic else lib.mpnn_exit_ev)(t_e.data_ptr(), 1, n, st), 'exit_ev')
