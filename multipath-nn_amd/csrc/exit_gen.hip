@@ -593,6 +593,7 @@ __global__ __launch_bounds__(256) void ev_lin_gen_k(const mpnn_exit_ev_args *__r
     if (s) ct -= T0;
     __shared__ float cA[GEN_C * 3];
     __shared__ float red[4 * 256];
+    if ((s && !a.h1) || (!s && !a.z)) return;       // (a record without its scratch map: nothing to write to)
     if (s) gen_lin_tile(a.a, a.HW, n, a.idx, n0, a.w1, a.b1, M1, ct * 16, a.extra_col != 0, a.alpha_cpt, a.k_cpt, a.h1, cA, red);
     else   gen_lin_tile(a.a, a.HW, n, a.idx, n0, a.w_head, a.b_head, M0, ct * 16, false, 0.f, nullptr, a.z, cA, red);
 }
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(256) void ev_tail_gen_k(const mpnn_exit_ev_args *__
     __shared__ float aL[16 * GEN_R], bL[16 * GEN_R];
     __shared__ int arg_s[EV_SPW], img_s[EV_SPW], base_s[MPNN_MAX_SINKS];
     const int tid = threadIdx.x, sl = tid / HT, part = tid % HT;
-    const int nc = a.w_head ? a.n_cls : 0, R = a.w1 ? a.R : 0, R2 = a.w1 ? (a.R2 > 0 ? a.R2 : a.R) : 0, S = a.w1 ? a.n_sinks : 0;
+    const int nc = (a.w_head && a.z) ? a.n_cls : 0, R = (a.w1 && a.h1) ? a.R : 0, R2 = R ? (a.R2 > 0 ? a.R2 : a.R) : 0, S = R ? a.n_sinks : 0;
     if (tid < EV_SPW) { arg_s[tid] = -1; img_s[tid] = -1; }
     __syncthreads();
     for (int it = 0; it < EV_SPW / 16; ++it) {
