@@ -177,3 +177,29 @@ def test_cotrained_pipeline_feeds_each_net_its_own_batches(joint):
             xb = torch.rand(n * 8, *ds.x0_shape, device='cuda')
             yb = torch.zeros(n * 8, ds.y_shape[0], device='cuda'); yb[:, 0] = 1
             nets[1].eval({nets[1].x0: xb, nets[1].y: yb})
+
+
+def test_train_nets_shard_nets_under_torchrun(tmp_path):
+    """train-nets --shard-nets under torchrun with two ranks (both on GPU 0 here): the nets of the experiment are dealt to
+    the ranks -- rank 0 trains nets 0 and 2 (co-trained), rank 1 net 1 -- with no process group and no collective; every
+    rank writes the files of its own nets."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'nets')
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MPNN_DP_ONE_GPU='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'multipath-nn_amd', 'train-nets'), 'cifar10-cr', '--synthetic',
+           '--iters', '4', '--log-every', '4', '--nets', '0', '1', '2', '--shard-nets', '--co-train', '2', '--stats-batch', '256',
+           '--out', out]
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    base = os.path.join(out, 'cifar10-cr')
+    for i in (0, 1, 2):
+        for f in ('%.4i.npy', '%.4i-stats.npy', '%.4i-log.txt'):
+            assert os.path.exists(os.path.join(base, f % i)), f % i
