@@ -549,7 +549,7 @@ class Engine:
                     b.dzh = z(n, self.n_cls) if b.head is not None else None
                     if b.router is not None:
                         b.dh1 = z(n, b.R)
-                        b.dh2 = z(n, b.R2) if self.generic_exits else None     # (scratch of mpnn_exit_tail_bwd_gen)
+                        b.dh2 = z(n, b.R2) if (self.generic_exits or n > 128) else None     # (scratch of mpnn_exit_tail_bwd_gen)
 
     # ------------------------------------------------------------------ programs
     @staticmethod
@@ -997,7 +997,11 @@ class Engine:
                 fwd.append(call(lib.mpnn_lin_fwd_ks, 'lin_fwd', t_lf.data_ptr(), n_exit, n, kmax, host=lin_f))
             else:
                 fwd.append(call(lib.mpnn_lin_fwd, 'lin_fwd', t_lf.data_ptr(), n_exit, n, host=lin_f))
-            fwd.append(call(lib.mpnn_exit_tail_fwd, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n, host=tail_f))
+            # batches beyond the 128 samples the LDS-resident tails hold: the any-width tails (csrc/exit_gen.hip: every pass on
+            # 1 024 threads) instead of the tuned kernels' any-size forms -- same records; measured at 256 / 512 / 1 024
+            # samples: profiles/r05_train_sweep.txt
+            big_tails = n > 128 and bool(int(os.environ.get('MPNN_BIG_TAILS_GEN', '1')))
+            fwd.append(call(lib.mpnn_exit_tail_fwd_gen if big_tails else lib.mpnn_exit_tail_fwd, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n, host=tail_f))
 
         # ---- route ----
         ra = self._route_args(n, mode, self.loss)
@@ -1015,7 +1019,7 @@ class Engine:
             bwd.append(call(lib.mpnn_exit_tail_bwd_gen, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
             bwd.append(call(lib.mpnn_lin_bwd_gen, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
         elif n_exit:
-            bwd.append(call(lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n, host=tail_b))
+            bwd.append(call(lib.mpnn_exit_tail_bwd_gen if big_tails else lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n, host=tail_b))
             bwd.append(call(lib.mpnn_lin_bwd_rs if n <= 512 else lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax, host=lin_b))
         if dp and 'exit' in self.dp_buckets:
             bwd.append(marker('bucket', 'exit'))       # head + router gradients are final: their all-reduce starts here
