@@ -178,6 +178,27 @@ class Dataset:
         b['ring'][k] = (buf, ev)
         return b['dev'][slot]
 
+    def stage_training_draws_k(self, K, n=128, r_shift=4, eng=None):
+        """stage_training_draws for the K steps of one K-step graph replay (record slots 0 .. K-1, drawn in step order from
+        the one numpy stream) with ONE upload: a small copy on the compute stream in front of a replay costs ~8 us."""
+        import torch
+        b = self._draw_buffers(n, None if eng is None else id(eng))
+        if K > self.SLOTS:
+            raise ValueError('at most %d record slots' % self.SLOTS)
+        if 'ringk' not in b:
+            b['ringk'], b['slotk'] = [(torch.zeros((self.SLOTS, n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING)], -1
+        k = b['slotk'] = (b['slotk'] + 1) % len(b['ringk'])
+        buf, ev = b['ringk'][k]
+        if ev is not None:
+            ev.synchronize()
+        out = buf.numpy()
+        for j in range(K):
+            _draw_augmentation_fast(n, len(self.x0_tr), self._sym_u8, r_shift, out=out[j, :n], all_sym=self._all_sym)
+        b['dev'][:K, :n].copy_(buf[:K, :n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        b['ringk'][k] = (buf, ev)
+
     def _augment_launch(self, n, x_out, y_out, stream, draws=None):
         from . import _hip
         h, w, c = self.x0_tr.shape[1:]

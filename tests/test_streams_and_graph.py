@@ -256,8 +256,11 @@ def test_k_steps_in_one_graph_with_the_input_pipeline():
                     ds.stage_training_draws(n, eng=eng)
                     net.train.run(f(call * K + j))
             else:
-                for j in range(K):
-                    ds.stage_training_draws(n, eng=eng, slot=j)
+                if call == 1:                                  # (both ways of staging the K record slots)
+                    for j in range(K):
+                        ds.stage_training_draws(n, eng=eng, slot=j)
+                else:
+                    ds.stage_training_draws_k(K, n, eng=eng)
                 net.train.run_steps([f(call * K + j) for j in range(K)])
         torch.cuda.synchronize()
         outs.append((eng.P.clone(), eng.x0[:n].clone(), np.random.get_state()[1].copy()))

@@ -55,8 +55,7 @@ print('pipeline / resident: %.3f' % (full / base))
 
 def bound4(t):
     # (as train-nets runs it since round 5: four iterations per hipGraph replay, Engine.run_steps; `timed` counts calls)
-    for j in range(4):
-        ds.stage_training_draws(N, eng=eng, slot=j)
+    ds.stage_training_draws_k(4, N, eng=eng)
     net.train.run_steps([feed(x0, y, 4 * t + j) for j in range(4)])
 full4 = timed(bound4, 'pipeline as train-nets runs it: FOUR steps per replay (time per call = 4 steps)') / 4
 print('  -> %.3f ms per step = %.0f img/s;  pipeline / resident: %.3f' % (full4 * 1e3, N / full4, full4 / base))
