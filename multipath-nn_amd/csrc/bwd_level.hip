@@ -199,6 +199,9 @@ static int level_build_rep(const mpnn_bwd_member *mem, int count, int reps, BwdR
         for (int k = 0; k < count; ++k) if (l2.w0[k] != lq.w0[k]) return MPNN_E_ARG;
     }
     lq.reps = reps;  lq.wpr = total;
+    // the `_rep` forms never use the XCD-aware tile order (see fwd_group_launch in conv_fwd.hip); reps = 1 is the launch of
+    // one net of a group stepping by itself with the group's grids
+    if (recs) for (int k = 0; k < count * reps; ++k) recs[k].q.h.xcd = recs[k].q.v.xcd = recs[k].q.w.c.xcd = 0;
     return 0;
 }
 

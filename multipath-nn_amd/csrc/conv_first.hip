@@ -240,7 +240,8 @@ static int first_conv_launch(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_ar
     p.n = a->n; p.H = a->H; p.W = a->W; p.C = a->a.C;
     p.nslot = a->out_nslot < 1 ? 1 : (a->out_nslot > MPNN_BN_SLOTS ? MPNN_BN_SLOTS : a->out_nslot);
     p.n_tiles = a->n * (a->W >> 4) * (a->H >> 2);
-    p.xcd = xcd_env();
+    const bool use_xcd = reps == 1 && share == 1;       // (see fwd_group_launch)
+    p.xcd = use_xcd ? xcd_env() : 0;
     const bool stats = a->out_sum != nullptr, pool = a->pool_out != nullptr;
     typedef void (*FirstKern)(const FirstP, const mpnn_conv_fwd_args *, const int);
     FirstKern kern = reps > 1 ? (stats ? (pool ? fwd_first_k<true, true, true> : fwd_first_k<true, false, true>)
@@ -251,7 +252,7 @@ static int first_conv_launch(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_ar
     const long need = (p.n_tiles + 3) / 4;
     if (wgs > need) wgs = need;
     if (wgs < 1) wgs = 1;
-    const int grid = xcd_round((int)wgs);
+    const int grid = use_xcd ? xcd_round((int)wgs) : (int)wgs;
     hipLaunchKernelGGL(kern, dim3(grid * reps), dim3(256), 0, st, p, dev_args, grid);
     MPNN_LAUNCH_CHECK();
     return 0;

@@ -213,6 +213,10 @@ static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_
         wide ? (any_idx ? fwd_group_k<false, true, true> : fwd_group_k<false, false, true>) :
         any_idx ? (any_small ? fwd_group_k<true, true> : fwd_group_k<false, true>)
                 : (any_small ? fwd_group_k<true, false> : fwd_group_k<false, false>);
+    // (nets that share the device: no XCD-aware tile order -- its grids are rounded down to multiples of 8 workgroups, a large
+    // fraction of slots / share, and the copies' workgroup offsets break the image -> XCD rule anyway: 2 057 -> 2 010 us per
+    // joint step of 8 nets with it off)
+    const bool use_xcd = reps == 1 && share == 1;
     long slots = resident_slots((const void *)kern, lds) / share;
     if (slots < 1) slots = 1;
     // work of a member = tile-rows x units per tile (16-channel chunks of both operands)
@@ -227,7 +231,7 @@ static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_
         if (g < 1) g = 1;
         if (g > hp[k].n_tiles) g = hp[k].n_tiles;
         if (q.gk[k] >= 3 && g > (hp[k].n_tiles + 3) / 4) g = (hp[k].n_tiles + 3) / 4;       // a wave per strip of >= 4 rows
-        q.gx[k] = xcd_round((int)g);
+        q.gx[k] = use_xcd ? xcd_round((int)g) : (int)g;
         if (q.gk[k] >= 3) {
             // rows per strip: the longest (least halo) that still gives every wave of the member's workgroups a strip
             const long cols = (long)hp[k].n * (hp[k].W >> 4);
@@ -240,7 +244,7 @@ static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_
         if (q.gx[k] > gxm) gxm = q.gx[k];
     }
     q.n = count;
-    q.xcd = xcd_env();
+    q.xcd = use_xcd ? xcd_env() : 0;
     int n_wg = 0;
     for (int k = 0; k < count; ++k) { q.w0[k] = n_wg; n_wg += q.gx[k] * q.gy[k]; }
     (void)gxm; (void)rows;

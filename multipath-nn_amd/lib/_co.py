@@ -119,7 +119,7 @@ class CoTrainer:
                 keep.append(arr)
                 merged.append(launch_of(lib.mpnn_route_multi, what, flops, tag, arr, dev.data_ptr(), K))
             elif what == 'bwd_scale':
-                if o0.fn is not lib.mpnn_msconv_bwd_level:
+                if o0.fn is not lib.mpnn_msconv_bwd_level_rep:
                     raise NotImplementedError('co-training: a backward launch is not in its table-driven form')
                 cnt = o0.args[1]
                 mem = (_hip.BwdMember * (cnt * K))()

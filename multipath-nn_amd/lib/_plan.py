@@ -744,7 +744,8 @@ class Engine:
                 for (k, kind, rows, tiles, lat), g in zip(bodies, gx)))
         out = [dict(gxh=0, gxv=0, split=1) for _ in grp]
         for (k, kind, rows, tiles, lat), g in zip(bodies, gx):
-            g = self._xcd_round(g)
+            if self.co_share == 1:              # (co-trained groups: no XCD-aware order, no rounding of slots / K: see conv_fwd.hip)
+                g = self._xcd_round(g)
             if kind == 'w':
                 kb, b, i = grp[k]
                 w_bytes = 4 * 9 * b.C[i] * (b.Cin[i] + (b.C[i - 1] if i > 0 else 0))
@@ -1188,8 +1189,12 @@ class Engine:
                     dev_rec = torch.empty(rec_bytes * len(built), dtype=torch.uint8, device=self.dev)
                     keep.append(dev_rec)
                     level_fix[-1] += (dev_rec,)
-                    bwd.append(call(lib.mpnn_msconv_bwd_level, 'bwd_scale', mem, len(built), dev_rec.data_ptr(),
-                                    flops=sum(x[4] for x in built), tag=' | '.join(x[5] for x in built)))
+                    if self.co_share > 1:      # (one net of a co-trained group by itself: the group's launch form, one copy)
+                        bwd.append(call(lib.mpnn_msconv_bwd_level_rep, 'bwd_scale', mem, len(built), 1, dev_rec.data_ptr(),
+                                        flops=sum(x[4] for x in built), tag=' | '.join(x[5] for x in built)))
+                    else:
+                        bwd.append(call(lib.mpnn_msconv_bwd_level, 'bwd_scale', mem, len(built), dev_rec.data_ptr(),
+                                        flops=sum(x[4] for x in built), tag=' | '.join(x[5] for x in built)))
                 if last_cut is not None and g == last_cut:
                     if any(m[0] for m in slab_members):
                         mid_pos = len(bwd)
@@ -1282,7 +1287,10 @@ class Engine:
                             self.bn_decay, n, keep_ptr))
         # member records of the level launches: every pointer is final now
         for mem, cnt, host, rec_bytes, dev_rec in level_fix:
-            _hip.check(lib.mpnn_msconv_bwd_level_prepare(mem, cnt, C.cast(host, C.c_void_p)), 'bwd_level records')
+            if self.co_share > 1:
+                _hip.check(lib.mpnn_msconv_bwd_level_prepare_rep(mem, cnt, 1, C.cast(host, C.c_void_p)), 'bwd_level records')
+            else:
+                _hip.check(lib.mpnn_msconv_bwd_level_prepare(mem, cnt, C.cast(host, C.c_void_p)), 'bwd_level records')
             dev_rec.copy_(torch.frombuffer(bytearray(host.raw), dtype=torch.uint8))
         if dp:
             bwd.append(marker('bucket', 'end'))
