@@ -87,16 +87,18 @@ __global__ __launch_bounds__(256, WIDE ? 2 : (SMALL ? 3 : MPNN_OCC)) void fwd_gr
     }
 }
 
-// One deep small-map member alone in its launch: K-split body, 512 threads (see conv_body).
-template <int GK>
-__global__ __launch_bounds__(512) void fwd_ks_k(const mpnn_conv_fwd_args *__restrict__ tab, const int gx, const int xcd) {
-    __shared__ __attribute__((aligned(16))) char smem[ConvSmem<GK, 4, 16, 2>::BYTES];
+// One deep small-map member alone in its launch: K-split body (see conv_body) -- KS thread groups of 256, each one of the
+// unit's KS 16-channel chunks: 512 threads / 32-channel units, or (inputs of >= 128 channels, all chunk counts multiples of
+// four) 1 024 threads / 64-channel units: one workgroup per CU, four waves per SIMD, half the unit chain again.
+template <int GK, int KS = 2>
+__global__ __launch_bounds__(KS * 256) void fwd_ks_k(const mpnn_conv_fwd_args *__restrict__ tab, const int gx, const int xcd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // ConvSmem<GK, 4, 16, KS>::BYTES (above 64 KB for KS = 4)
     const int id = blockIdx.x, yy = id / gx, bx = id - yy * gx;
     ConvP p = {};
     fill_fwd(tab, p);
     p.xcd = xcd;
     p.n_tiles = conv_grid_x<GK>(p.n, p.H, p.W);
-    conv_body<GK, 1, 1, 4, 1, false, EPI_FWD, 2, true>(p, bx, yy, gx, smem);
+    conv_body<GK, 1, 1, 4, 1, false, EPI_FWD, KS, true>(p, bx, yy, gx, smem);
 }
 
 int mpnn_first_conv_launch_rep(const mpnn_conv_fwd_args *a, const mpnn_conv_fwd_args *dev_args, int reps, int share, hipStream_t st);
@@ -185,11 +187,28 @@ static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_
         hp[0].a.C + hp[0].Cv >= 64) {
         const int gy = q.gy[0];
         int gx = hp[0].n_tiles;
-        const long slots = q.gk[0] == 1 ? resident_slots((const void *)fwd_ks_k<1>, 0, 512) : resident_slots((const void *)fwd_ks_k<2>, 0, 512);
+        // (the four-way split: correct, measured NOT faster -- h4 64+64->64 15.4 -> 15.7 us, h4 128->128 15.7 -> 16.6 us in situ:
+        // half the unit chain, but sixteen-wave workgroups start later and stage twice the LDS per barrier -- opt-in;
+        // read at every launch so that a test can switch it)
+        const int ks4_env = [] { const char *e = getenv("MPNN_FWD_KSPLIT4"); return e ? atoi(e) : 0; }();
+        const bool ks4 = ks4_env && (hp[0].a.C % 64) == 0 && (hp[0].Cv % 64) == 0 && hp[0].a.C + hp[0].Cv >= 128;
+        typedef void (*KsKern)(const mpnn_conv_fwd_args *, const int, const int);
+        const KsKern kern = q.gk[0] == 1 ? (ks4 ? fwd_ks_k<1, 4> : fwd_ks_k<1, 2>) : (ks4 ? fwd_ks_k<2, 4> : fwd_ks_k<2, 2>);
+        const int lds_ks = q.gk[0] == 1 ? (ks4 ? ConvSmem<1, 4, 16, 4>::BYTES : ConvSmem<1, 4, 16, 2>::BYTES)
+                                        : (ks4 ? ConvSmem<2, 4, 16, 4>::BYTES : ConvSmem<2, 4, 16, 2>::BYTES);
+        static bool raised = false;
+        if (!raised) {                              // (more than the default 64 KB of dynamic LDS)
+            (void)hipFuncSetAttribute((const void *)fwd_ks_k<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvSmem<1, 4, 16, 4>::BYTES);
+            (void)hipFuncSetAttribute((const void *)fwd_ks_k<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvSmem<2, 4, 16, 4>::BYTES);
+            (void)hipFuncSetAttribute((const void *)fwd_ks_k<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvSmem<1, 4, 16, 2>::BYTES);
+            (void)hipFuncSetAttribute((const void *)fwd_ks_k<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ConvSmem<2, 4, 16, 2>::BYTES);
+            raised = true;
+        }
+        const int threads = ks4 ? 1024 : 512;
+        const long slots = resident_slots((const void *)kern, lds_ks, threads);
         if ((long)gx * gy > slots) gx = (int)(slots / gy > 0 ? slots / gy : 1);
         gx = xcd_round(gx);
-        if (q.gk[0] == 1) hipLaunchKernelGGL(fwd_ks_k<1>, dim3(gx * gy), dim3(512), 0, (hipStream_t)stream, dev_args, gx, xcd_env());
-        else              hipLaunchKernelGGL(fwd_ks_k<2>, dim3(gx * gy), dim3(512), 0, (hipStream_t)stream, dev_args, gx, xcd_env());
+        hipLaunchKernelGGL(kern, dim3(gx * gy), dim3(threads), lds_ks, (hipStream_t)stream, dev_args, gx, xcd_env());
         MPNN_LAUNCH_CHECK();
         return 0;
     }

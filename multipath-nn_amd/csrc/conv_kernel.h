@@ -335,24 +335,29 @@ __device__ __forceinline__ void st_items(f32x4 *tile, const f32x4 (*xr)[XW], con
 // loads of unit u+1 are in flight, and they are transformed and written to the
 // other buffer before the single barrier that ends the unit.
 // ---------------------------------------------------------------------------
+template <int WNT> struct CT_OK { static constexpr bool v = WNT == 1; };      // (the K-split exchange holds 16-channel tiles)
 // LDS bytes of one workgroup (all variants of a launch share one arena).
 template <int GK, int WM, int CT, int NCH = 1>
 struct ConvSmem {
+    // POOL: the 2x2-pooling exchange [64 px][CT]; the K-split bodies' partial-sum exchange shares it ((NCH - 1) x 4 KB:
+    // beside the pooling area where a map is pooled -- 8x8 --, on top of it on the 4x4 maps, which are never pooled and
+    // whose four-way split sits 192 bytes under the 160 KB of a CU)
+    static constexpr int KRED0 = (NCH == 4 && GK != 2) ? 64 * CT * 4 : 0;          // byte offset of the partial sums in POOL
     static constexpr int TILE = NCH * 2 * 4 * Geom<GK>::P * 16, WT = NCH * 2 * 36 * CT * 16, CA = 128 * 5 * 4, CE = CT * 5 * 4,
-                         RED = WM * CT * 2 * 8, POOL = 64 * CT * 4;
+                         RED = WM * CT * 2 * 8, POOL = NCH == 4 ? KRED0 + 3 * 4096 : 64 * CT * 4;
     static constexpr int BYTES = TILE + WT + CA + ((CE + 15) & ~15) + RED + POOL;
 };
 
 // NCH = 16-channel chunks per unit (1 or 2).  With 2 a unit spans 32 input channels: half as many
 // barriers and load round trips on the deep-K, small-M layers whose per-unit MFMA time (~0.5 us)
 // cannot cover a load latency (~2 us).  Requires every operand's channel count % 32 == 0.
-// KSPLIT (with NCH == 2, 512 threads): the workgroup's two 256-thread halves each stage and multiply ONE
+// KSPLIT (with NCH == 2, 512 threads, or NCH == 4, 1 024 threads): the workgroup's 256-thread groups each stage and multiply ONE
 // of the unit's two chunks; their partial sums meet in LDS when a tile is finished.  For the deep 4x4 /
 // 8x8 layers, whose 128-256 workgroups otherwise leave one wave per SIMD with nothing to overlap.
 // IDX (forward only): routed evaluation -- the tile's image slots go through p.idx (see ConvP).
 template <int GK, int MT, int NT, int WM, int WN, bool SMALL_A, int EPI, int NCH = 1, bool KSPLIT = false, bool IDX = false>
 __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const int by, const int gx, char *smem) {
-    static_assert(!KSPLIT || (NCH == 2 && MT == 1 && NT == 1 && !SMALL_A && EPI == EPI_FWD), "K-split: forward, 32-channel units");
+    static_assert(!KSPLIT || ((NCH == 2 || NCH == 4) && MT == 1 && NT == 1 && !SMALL_A && EPI == EPI_FWD && CT_OK<WN * NT>::v), "K-split: forward, 32- / 64-channel units");
     static_assert(!IDX || (EPI == EPI_FWD && !KSPLIT), "index lists: forward bodies of the evaluation path");
     constexpr int SC = KSPLIT ? 1 : NCH;            // chunks staged / multiplied by ONE thread group per unit
     using G = Geom<GK>;
@@ -603,7 +608,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         }
     }
     if constexpr (XItems<GK>::INTERIOR)                // the halo ring of both tile buffers: zero for the whole kernel
-        zero_ring<GK, P>(&tile[0][0], 2 * NCH * 4, threadIdx.x, KSPLIT ? 512 : 256);
+        zero_ring<GK, P>(&tile[0][0], 2 * NCH * 4, threadIdx.x, KSPLIT ? NCH * 256 : 256);
     if (n_units > 0) unit_store(cu, xrA, brA, 0, true);
     __syncthreads();
     trace_stamp(2);
@@ -728,11 +733,14 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         // ----------------------------- epilogue of a finished tile -----------------
         // D layout: col = lane & 15 (channel), row = (lane >> 4) * 4 + r (pixel of the M-tile).
         if ((!more || t2 != t) && !MPNN_DBG(p, 4)) {
-            if constexpr (KSPLIT) {                     // partial sums of the second K-group -> LDS -> first group
-                f32x4 *kred = (f32x4 *)pool_lds;         // [wave][lane]: the wave's own kilobyte of the pooling area
-                if (kg == 1) kred[wid * 64 + lane] = acc[0][0];
+            if constexpr (KSPLIT) {                     // partial sums of the other K-groups -> LDS -> first group, in group order
+                f32x4 *kred = (f32x4 *)((char *)pool_lds + SM::KRED0);      // [group - 1][wave][lane]
+                if (kg > 0) kred[(kg - 1) * 256 + wid * 64 + lane] = acc[0][0];
                 lds_barrier();
-                if (kg == 0) acc[0][0] += kred[wid * 64 + lane];
+                if (kg == 0) {
+#pragma unroll
+                    for (int q = 1; q < NCH; ++q) acc[0][0] += kred[(q - 1) * 256 + wid * 64 + lane];
+                }
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {

@@ -409,12 +409,14 @@ int mpnn_trace_install_lin(void *buf);
 int mpnn_trace_install_tail(void *buf);
 int mpnn_trace_install_route(void *buf);
 int mpnn_trace_install_level(void *buf);
+int mpnn_trace_install_level_small(void *buf);
 
 extern "C" int mpnn_debug_set_trace(unsigned long long *buf) {
     int rc = mpnn_trace_install_fwd(buf);
     if (!rc) rc = mpnn_trace_install_dgrad(buf);
     if (!rc) rc = mpnn_trace_install_wgrad(buf);
     if (!rc) rc = mpnn_trace_install_level(buf);
+    if (!rc) rc = mpnn_trace_install_level_small(buf);
     if (!rc) rc = mpnn_trace_install_lin(buf);
     if (!rc) rc = mpnn_trace_install_tail(buf);
     if (!rc) rc = mpnn_trace_install_route(buf);

@@ -358,12 +358,16 @@ def test_lin_bwd_fused_bn_reduce(C_):
     close(red1, red_ref, 1e-4)
 
 
-@pytest.mark.parametrize('shape', [(4, 64, 64, 64), (4, 64, 0, 128), (4, 128, 0, 128), (8, 64, 0, 64), (8, 32, 32, 64), (16, 32, 0, 32)])
-def test_one_member_group_equals_single_launch(shape):
+@pytest.mark.parametrize('shape', [(4, 64, 64, 64), (4, 64, 0, 128), (4, 128, 0, 128), (8, 64, 0, 64), (8, 32, 32, 64), (16, 32, 0, 32),
+                                   (8, 64, 64, 64), (8, 128, 0, 32), (4, 128, 64, 64), (4, 64, 128, 16)])
+@pytest.mark.parametrize('ks4', ['0', '1'])
+def test_one_member_group_equals_single_launch(shape, ks4, monkeypatch):
     """mpnn_msconv_fwd_group with ONE member (the deep 4x4 / 8x8 shapes take the K-split body: 512
-    threads, the two halves' partial sums meet in LDS) against mpnn_msconv_fwd and the oracle, on a
-    ragged batch, with BatchNorm on load and the pooled output."""
+    threads, the two halves' partial sums meet in LDS; ks4: the opt-in four-way split, 1 024 threads, for inputs of
+    at least 128 channels) against mpnn_msconv_fwd and the oracle, on a ragged batch, with BatchNorm on load and the
+    pooled output."""
     import hiputil as U
+    monkeypatch.setenv('MPNN_FWD_KSPLIT4', ks4)
     H, ca, cv, co = shape
     rng = np.random.default_rng(sum(shape))
     n = 11
