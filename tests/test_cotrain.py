@@ -29,7 +29,7 @@ def _copy_state(src, dst):
     ed.invalidate_packs()
 
 
-@pytest.mark.parametrize('kind,K,n', [('ac', 3, 32), ('cr', 2, 16), ('ac', 8, 128), ('sr', 3, 16)])
+@pytest.mark.parametrize('kind,K,n', [('ac', 3, 32), ('cr', 2, 16), ('ac', 8, 128), ('sr', 3, 16), ('tree', 2, 8)])
 def test_cotrained_step_equals_the_solo_step(kind, K, n):
     """Every net of a co-trained group takes the step it would take alone from the same state.  "Alone" with the planner
     setting of the co-trained program (`Engine.co_share = K`: every launch gets the grid it has inside the joint launch
@@ -41,7 +41,8 @@ def test_cotrained_step_equals_the_solo_step(kind, K, n):
     import arch_and_hypers as A
     from lib._co import CoTrainer
     ks = A.k_cpts
-    mk = {'ac': lambda i: A.ac_chain(k_cpt=ks[i % 8]), 'cr': lambda i: A.cr_chain(k_cpt=ks[i % 8]), 'sr': lambda i: A.sr_chain(8)}[kind]
+    mk = {'ac': lambda i: A.ac_chain(k_cpt=ks[i % 8]), 'cr': lambda i: A.cr_chain(k_cpt=ks[i % 8]), 'sr': lambda i: A.sr_chain(8),
+          'tree': lambda i: A.ac_tree(k_cpt=ks[(i + 2) % 8])}[kind]        # (the reference's 47-block tree: siblings accumulate into one map)
     co_nets = _nets([mk(i) for i in range(K)])
     solo = _nets([mk(i) for i in range(K)])
     co = CoTrainer(co_nets)
