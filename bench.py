@@ -230,7 +230,7 @@ def time_experiment(dev, n, single_ms, reps=100):
     Aggregate images/s of the 8 co-trained nets beside the serial rate (the single-net headline): the dependency depth
     of a step stays 33 launches, the work per launch grows 8-fold."""
     import arch_and_hypers as A
-    from lib._co import CoTrainer
+    from lib._co import CoTrainer, CoGroups
     nets, feeds = [], []
     g = torch.Generator().manual_seed(99)
     for i, k in enumerate(A.k_cpts):
@@ -242,17 +242,40 @@ def time_experiment(dev, n, single_ms, reps=100):
         eng.y[:n].copy_(torch.nn.functional.one_hot(torch.randint(0, 10, (n,), generator=g), 10).float().to(dev))
         nets.append(net)
         feeds.append({net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr', net.λ_lrn: A.λ_lrn(0), net.τ: A.τ_ds(0)})
+    K = len(nets)
     co = CoTrainer(nets)
     for _ in range(5):
         co.run(feeds)
     torch.cuda.synchronize()
-    ms = time_replays(lambda: co.run(feeds), reps)
-    K = len(nets)
-    return {'nets': K, 'what': 'cifar10-ac experiment: ac_chain(k_cpt=k) for the 8 k_cpts, batch %d each, co-trained (one hipGraph, '
-                               'launch j = launch j of all nets)' % n,
+    ms_one = time_replays(lambda: co.run(feeds), reps)
+    del co
+    # the same 8 nets as 4 groups of 2, each group's joint hipGraph on a stream of its own (lib/_co.py: CoGroups;
+    # `train-nets --co-train 8` runs this form): a second hardware queue fills the ramps and drains of the first
+    cg = CoGroups.plan(nets, streams=4)
+    for _ in range(5):
+        cg.run(feeds)
+    cg.join()
+    torch.cuda.synchronize()
+    main_st, per = torch.cuda.current_stream(), []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main_st)
+        for _ in range(max(1, reps // 5)):
+            cg.run(feeds)                           # (the groups free-run against each other; no barrier between steps)
+        cg.join()
+        e1.record(main_st)
+        torch.cuda.synchronize()
+        per.append(e0.elapsed_time(e1) / max(1, reps // 5))
+    ms = float(np.median(per))
+    return {'nets': K, 'what': 'cifar10-ac experiment: ac_chain(k_cpt=k) for the 8 k_cpts, batch %d each, co-trained: %d groups of %d '
+                               '(one hipGraph per group: launch j = launch j of its nets) side by side on %d streams'
+                               % (n, len(cg.groups), max(c.K for c in cg.groups), len(cg.streams)),
             'images_per_s': K * n / (ms * 1e-3), 'ms_per_joint_step': ms, 'ms_per_net_step': ms / K,
             'images_per_s_serial': n / (single_ms * 1e-3), 'speedup_vs_serial': K * single_ms / ms,
-            'step_frac_of_mfma_roofline': K * n / (ms * 1e-3) * F_TRAIN / 1e12 / PEAK_F32_MFMA}
+            'step_frac_of_mfma_roofline': K * n / (ms * 1e-3) * F_TRAIN / 1e12 / PEAK_F32_MFMA,
+            'groups': [c.K for c in cg.groups], 'streams': len(cg.streams), 'share': cg.share,
+            'one_group': {'what': 'all 8 nets in ONE joint hipGraph on one stream', 'images_per_s': K * n / (ms_one * 1e-3),
+                          'ms_per_joint_step': ms_one, 'speedup_vs_serial': K * single_ms / ms_one}}
 
 
 def main():

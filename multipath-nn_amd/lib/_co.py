@@ -28,7 +28,7 @@ from lib._plan import CAPTURE_MODE
 
 
 class CoTrainer:
-    def __init__(self, nets):
+    def __init__(self, nets, share=None):
         if len(nets) < 1:
             raise ValueError('CoTrainer needs at least one net')
         self.nets = list(nets)
@@ -44,6 +44,11 @@ class CoTrainer:
                 raise ValueError('co-trained nets live on one device')
         self.lib, self.dev = e0.lib, e0.dev
         self.K = len(self.nets)
+        # the planner budgets every net's grids against resident slots / share: K when the group has the GPU to itself;
+        # larger when several groups run side by side on streams of their own (train-nets --co-train K --streams S)
+        self.share = self.K if share is None else int(share)
+        if self.K > 1 and self.share < 2:
+            raise ValueError('a group of several nets runs the table-driven launch forms: share >= 2')
         # the nets' schedule / hyper-parameter values side by side in ONE device buffer: one upload per joint step instead of
         # one per net (the learning rate changes every step).  The engines' own `hyp` become rows of it; programs that
         # baked the old pointers in are dropped.
@@ -70,7 +75,7 @@ class CoTrainer:
         K, lib, keep = self.K, self.lib, self._keep
         progs = []
         for e in self.engs:
-            e.co_share = K                                 # (a planner setting of THIS program only: the net's solo programs keep 1)
+            e.co_share = self.share                        # (a planner setting of THIS program only: the net's solo programs keep 1)
             try:
                 progs.append(e.program('tr', n))
             finally:
@@ -108,7 +113,7 @@ class CoTrainer:
                         arr[r * cnt + k] = o.args[0][k]
                 dev = table(list(arr))
                 keep.append(arr)
-                merged.append(launch_of(lib.mpnn_msconv_fwd_group_rep, what, flops, tag, arr, dev.data_ptr(), cnt, K, K))
+                merged.append(launch_of(lib.mpnn_msconv_fwd_group_rep, what, flops, tag, arr, dev.data_ptr(), cnt, K, self.share))
             elif what in ('lin_fwd', 'exit_tail_fwd', 'exit_tail_bwd', 'lin_bwd'):
                 recs = [r for o in ops for r in o.host]
                 dev = table(recs)
@@ -228,3 +233,98 @@ class CoTrainer:
         """Drop the merged programs and graphs (an engine reallocated its buffers: a larger batch came by)."""
         self._progs.clear()
         self._graphs.clear()
+
+
+class CoGroups:
+    """Several co-trained groups SIDE BY SIDE: each group's joint hipGraph replays on a stream of its own.
+
+    A joint step of one group is still a chain of 33 dependent launches, each with its ramp and its drain; a second group
+    on another hardware queue fills them.  There are no edges between the graphs (the 20-30 us a cross-stream graph edge
+    costs, DESIGN.md §6, is never paid), and every group budgets its grids against resident slots / share with the
+    groups together asking for about TWICE the resident slots -- the dispatcher keeps the compute units busy from
+    whichever queue has a workgroup ready (tools/streams_probe.py: 8 nets as 4 groups of 2, share 4: 1.07 x one group of
+    8; 16 nets as 4 groups of 4, share 8: 1.10 x one group of 16; more streams than the 4 hardware queues: slower).
+
+    Groups of ONE net run the net's own launch list (any architecture): the statically-routed chains of the *-sr
+    experiments, which differ in depth and cannot share launches, still run side by side.
+
+    ``run(feeds)`` does not wait: the groups free-run against each other from step to step.  ``join()`` makes the
+    caller's stream wait for all of them (before a statistics pass, a checkpoint, any read of the nets' state).
+    """
+    def __init__(self, nets, sizes, streams=4, share=None):
+        if sum(sizes) != len(nets) or min(sizes) < 1:
+            raise ValueError('group sizes must add up to the number of nets')
+        self.nets = list(nets)
+        K = len(self.nets)
+        if share is None:
+            # groups that run at once ask together for about twice the resident slots (measured: the sweet spot for 4, 8 and
+            # 16 nets, groups of 1, 2 and 4); a lone group has the GPU to itself
+            share = -(-max(sizes) * min(len(sizes), int(streams)) // 2) if len(sizes) > 1 else K
+        self.share = max(int(share), 2 if max(sizes) > 1 else 1)
+        self.groups, self.spans, at = [], [], 0
+        for s in sizes:
+            self.groups.append(CoTrainer(self.nets[at:at + s], share=self.share))
+            self.spans.append((at, at + s))
+            at += s
+        self.dev = self.groups[0].dev
+        self.n_streams = max(1, min(int(streams), len(self.groups)))
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_streams)] if len(self.groups) > 1 else [None]
+        self._forked = False
+
+    @classmethod
+    def plan(cls, nets, streams=4, share=None):
+        """Split nets (in order) into runs of one architecture, and those into about `streams` equal groups."""
+        sig = _arch_signature
+        runs, sizes = [], []
+        for net in nets:
+            s = sig(net)
+            if runs and runs[-1][0] == s:
+                runs[-1][1] += 1
+            else:
+                runs.append([s, 1])
+        K = len(nets)
+        for _, cnt in runs:
+            g = max(1, min(cnt, round(streams * cnt / K)))
+            base, extra = divmod(cnt, g)
+            sizes += [base + (1 if i < extra else 0) for i in range(g)]
+        return cls(nets, sizes, streams, share)
+
+    def stream_of(self, g):
+        return self.streams[g % len(self.streams)]
+
+    def _fork(self):
+        if not self._forked and self.streams[0] is not None:
+            main = torch.cuda.current_stream()
+            for s in self.streams:
+                s.wait_stream(main)
+        self._forked = True
+
+    def on_group_streams(self, fn):
+        """fn(g, group, (lo, hi)) for every group, on the group's stream."""
+        self._fork()
+        for g, (co, span) in enumerate(zip(self.groups, self.spans)):
+            s = self.stream_of(g)
+            if s is None:
+                fn(g, co, span)
+            else:
+                with torch.cuda.stream(s):
+                    fn(g, co, span)
+
+    def run(self, feeds):
+        if len(feeds) != len(self.nets):
+            raise ValueError('one feed per net')
+        self.on_group_streams(lambda g, co, span: co.run(feeds[span[0]:span[1]]))
+
+    def join(self):
+        if self._forked and self.streams[0] is not None:
+            main = torch.cuda.current_stream()
+            for s in self.streams:
+                main.wait_stream(s)
+        self._forked = False
+
+
+def _arch_signature(net):
+    """What two nets must share to share launches (CoTrainer checks the launch lists themselves): the tree's
+    shape and every parameter's owner type, name and shape, in link order."""
+    return (tuple(len(ℓ.sinks) for ℓ in net.layers),
+            tuple((type(p.owner).__name__, p.name, tuple(p.shape)) for p in net._all_params))

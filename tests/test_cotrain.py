@@ -46,19 +46,25 @@ def test_cotrained_step_equals_the_solo_step(kind, K, n):
     co_nets = _nets([mk(i) for i in range(K)])
     solo = _nets([mk(i) for i in range(K)])
     co = CoTrainer(co_nets)
+    _compare_with_solo_steps(co_nets, solo, co.run, K, n, routed=kind != 'sr')
+
+
+def _compare_with_solo_steps(co_nets, solo, run_co, share, n, routed=True, steps=4):
     for b in solo:
-        b.engine().co_share = K
-    for t in range(4):                                        # eager, capture + replay, replays
+        b.engine().co_share = share
+    for t in range(steps):                                    # eager, capture + replay, replays
         feeds_co, feeds_so = [], []
         for i, (a, b) in enumerate(zip(co_nets, solo)):
             _copy_state(a, b)                                 # teacher-forced: the solo net starts the step from the co net's state
             x0, y = batch(n, seed=10 * t + i)
-            extra = {} if kind == 'sr' else {a.τ: 0.5 + 0.1 * i}
-            extra_b = {} if kind == 'sr' else {b.τ: 0.5 + 0.1 * i}
+            r = routed[i] if isinstance(routed, list) else routed
+            extra = {a.τ: 0.5 + 0.1 * i} if r else {}
+            extra_b = {b.τ: 0.5 + 0.1 * i} if r else {}
             feeds_co.append({a.x0: x0, a.y: y, a.mode: 'tr', a.λ_lrn: 0.05 / (1 + t), **extra})
             feeds_so.append({b.x0: x0, b.y: y, b.mode: 'tr', b.λ_lrn: 0.05 / (1 + t), **extra_b})
         before = [a.engine().P.clone() for a in co_nets]
-        co.run(feeds_co)
+        torch.cuda.synchronize()
+        run_co(feeds_co)
         for b, f in zip(solo, feeds_so):
             b.train.run(f)
         torch.cuda.synchronize()
@@ -84,6 +90,29 @@ def test_cotrained_step_equals_the_solo_step(kind, K, n):
         e._pack()
         torch.cuda.synchronize()
         assert torch.equal(kept, e.packs)
+
+
+@pytest.mark.parametrize('makers,streams,sizes,share', [
+    ('ac4', 2, [2, 2], 2), ('ac5', 4, [2, 1, 1, 1], 4), ('sr_mixed', 4, [1, 1, 1], 2), ('ac2_tree2_sr', 2, [2, 2, 1], 2), ('ac4', 1, [4], 4)])
+def test_groups_side_by_side_equal_the_solo_steps(makers, streams, sizes, share):
+    """CoGroups: the nets split into groups of one architecture, each group's joint hipGraph on its own stream, the groups
+    free-running side by side (no edges between the graphs).  Nothing of that may show in the results: every net takes
+    the step it takes alone with the groups' planner setting (co_share = the groups' share).  Nets of different
+    architectures (chains of 2, 5 and 8 blocks, statically routed) run as groups of one."""
+    import arch_and_hypers as A
+    from lib._co import CoGroups
+    ks = A.k_cpts
+    mk = {'ac4': lambda: [A.ac_chain(k_cpt=ks[i]) for i in range(4)], 'ac5': lambda: [A.ac_chain(k_cpt=ks[i]) for i in range(5)],
+          'sr_mixed': lambda: [A.sr_chain(2), A.sr_chain(5), A.sr_chain(8)],
+          'ac2_tree2_sr': lambda: [A.ac_chain(k_cpt=ks[1]), A.ac_chain(k_cpt=ks[2]), A.ac_tree(k_cpt=ks[3]), A.ac_tree(k_cpt=ks[4]), A.sr_chain(3)]}[makers]
+    co_nets, solo = _nets(mk()), _nets(mk())
+    cg = CoGroups.plan(co_nets, streams=streams)
+    assert [c.K for c in cg.groups] == sizes and cg.share == share
+    def run(feeds):
+        cg.run(feeds)
+        cg.join()
+    routed = [net._net_kind != 'sr' for net in co_nets]
+    _compare_with_solo_steps(co_nets, solo, run, cg.share, 16, routed=routed)
 
 
 @pytest.mark.parametrize('kind,K,n', [('ac', 2, 16), ('cr', 3, 16), ('ac', 8, 128)])
@@ -178,6 +207,64 @@ def test_cotrained_pipeline_feeds_each_net_its_own_batches(joint):
             xb = torch.rand(n * 8, *ds.x0_shape, device='cuda')
             yb = torch.zeros(n * 8, ds.y_shape[0], device='cuda'); yb[:, 0] = 1
             nets[1].eval({nets[1].x0: xb, nets[1].y: yb})
+
+
+def test_groups_pipeline_feeds_each_net_its_own_batches():
+    """CoGroups through the input pipeline, as train-nets --co-train runs it: one gather launch and one record upload per
+    GROUP, queued on the group's stream; the draws still come from the one numpy stream in net order."""
+    import arch_and_hypers as A
+    from lib._co import CoGroups
+    from lib.data import Dataset
+    ds = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+    ref = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+    nets = _nets([A.ac_chain(k_cpt=k) for k in (0.0, 1e-9, 4e-9, 8e-9)] + [A.sr_chain(2)])
+    engs = [net.engine() for net in nets]
+    n, K = 32, len(nets)
+    ds.to_device('cuda:0')
+    cg = CoGroups.plan(nets, streams=2)
+    assert [c.K for c in cg.groups] == [2, 2, 1]
+    bound = [None] * K
+
+    def bind(g, co, span):
+        bound[span[0]:span[1]] = ds.bind_cotrainer(co, n)
+    cg.on_group_streams(bind)
+    np.random.seed(11)
+    state0 = np.random.get_state()
+    want = [ref.augmented_training_batch(n) for _ in range(4 * K)]
+    np.random.set_state(state0)
+    for t in range(4):
+        feeds = [{net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.01, **({net.τ: 1.0} if net._net_kind != 'sr' else {})}
+                 for net, (x0, y) in zip(nets, bound)]
+
+        def step(g, co, span):
+            ds.stage_cotrainer_draws(co)
+            co.run(feeds[span[0]:span[1]])
+        cg.on_group_streams(step)
+        cg.join()
+        torch.cuda.synchronize()
+        for k, e in enumerate(engs):
+            wx, wy = want[K * t + k]
+            assert np.abs(e.x0[:n].cpu().numpy() - wx).max() <= 1e-6, (t, k)
+            assert np.array_equal(e.y[:n].cpu().numpy(), wy), (t, k)
+
+
+def test_train_nets_cli_co_train_mixed_architectures(tmp_path):
+    """train-nets cifar10-sr --co-train 3: chains of 1, 2 and 4 blocks cannot share launches; they run side by side, each
+    net's own hipGraph on its own stream, and log / checkpoint like the serial loop."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'nets')
+    cmd = [sys.executable, os.path.join(root, 'multipath-nn_amd', 'train-nets'), 'cifar10-sr', '--synthetic', '--iters', '4',
+           '--log-every', '2', '--nets', '0', '1', '3', '--co-train', '3', '--stats-batch', '256', '--out', out]
+    subprocess.check_call(cmd, cwd=str(tmp_path))
+    base = os.path.join(out, 'cifar10-sr')
+    for i in (0, 1, 3):
+        for f in ('%.4i.npy', '%.4i-stats.npy', '%.4i-log.txt', '%.4i-stats/00000002.npy', '%.4i-stats/00000004.npy'):
+            assert os.path.exists(os.path.join(base, f % i)), f % i
+        desc = np.load(os.path.join(base, '%.4i-stats.npy' % i), allow_pickle=True)[()]
+        assert desc['type'] == 'SRNet' and 0 <= desc['stats_ts']['acc'] <= 1
 
 
 def test_train_nets_shard_nets_under_torchrun(tmp_path):
