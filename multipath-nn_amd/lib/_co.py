@@ -268,7 +268,7 @@ class CoGroups:
             at += s
         self.dev = self.groups[0].dev
         self.n_streams = max(1, min(int(streams), len(self.groups)))
-        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(self.n_streams)] if len(self.groups) > 1 else [None]
+        self.streams = concurrent_streams(self.dev, self.n_streams) if len(self.groups) > 1 else [None]
         self._forked = False
 
     @classmethod
@@ -321,6 +321,45 @@ class CoGroups:
             for s in self.streams:
                 main.wait_stream(s)
         self._forked = False
+
+
+def concurrent_streams(dev, want, candidates=12, us=60.0):
+    """`want` streams whose kernels really run side by side.  The runtime multiplexes its streams onto a few hardware
+    queues (4 by default), and two streams that land on one queue serialise: four groups on what are in fact two queues
+    run 30 % SLOWER than one joint graph (measured: a process that had used other streams before).  Which queue a stream
+    gets is not visible through the API, so it is measured: a stream joins the set if a one-workgroup spin kernel on it
+    overlaps one on every stream already chosen.  ~15 ms, once per CoGroups."""
+    import os
+    import time
+    lib = _hip.load()
+    cands = [torch.cuda.Stream(device=dev) for _ in range(max(candidates, want))]
+    if want <= 1 or os.environ.get('MPNN_CO_CALIBRATE', '1') == '0':
+        return cands[:want]
+    for c in cands:
+        _hip.check(lib.mpnn_debug_noop(c.cuda_stream), 'noop')        # (the first launch on a stream binds its queue)
+    torch.cuda.synchronize(dev)
+
+    def together(a, b, links=3):
+        # chains of DEPENDENT launches, enqueued alternately: two streams on one hardware queue may still overlap single
+        # kernels (packets without a barrier bit run concurrently), but a dependent launch waits for everything ahead of
+        # it in its queue -- which is what a training step is made of
+        best = 1e9
+        for _ in range(3):
+            a.synchronize(); b.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(links):
+                lib.mpnn_debug_spin(1, 64, us, a.cuda_stream)
+                lib.mpnn_debug_spin(1, 64, us, b.cuda_stream)
+            a.synchronize(); b.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best < 1.45 * links * us * 1e-6
+    chosen = [cands[0]]
+    for c in cands[1:]:
+        if len(chosen) == want:
+            break
+        if all(together(c, s) for s in chosen):
+            chosen.append(c)
+    return chosen
 
 
 def _arch_signature(net):
