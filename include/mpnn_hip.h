@@ -623,6 +623,15 @@ int mpnn_maxpool_bwd(const float *x, const float *y, const float *cnt, const flo
 long mpnn_draw_augmentation(const unsigned int *raw, long n_raw, int n, long n_src, const unsigned char *sym,
                             int r_shift, int *draw, long *state);
 
+/* The same draws from a PRIVATE MT19937 state in numpy's legacy layout (key[624], *pos in 0..624: the fields of
+ * numpy.random.RandomState.get_state()), the generator stepped here: `batches` batches of n samples per call, written
+ * to draw as [batches][n][4] -- or, with draw == NULL, only skipped.  A net trained beside others (lib/_co.py, train-nets
+ * --shard-nets) gets the batches of the reference's serial experiment loop (scripts/train-nets:159-164: ONE global
+ * stream, net after net) by advancing the experiment's stream over the iterations of the nets in front of it.  key / pos
+ * are updated in place.  0, or MPNN_E_ARG. */
+long mpnn_draw_augmentation_mt(unsigned int *key, int *pos, long batches, int n, long n_src, const unsigned char *sym,
+                               int r_shift, int *draw);
+
 /* Data parallelism (new here: the reference is single-process, scripts/train-nets:159-164).  Compute units every
  * persistent grid launched AFTER this call leaves free (0: none, the default): RCCL's all-reduce kernels run beside
  * the backward launches of the bucket sections (lib/_plan.py), and a grid fitted to every resident workgroup slot

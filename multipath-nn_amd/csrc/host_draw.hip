@@ -81,3 +81,64 @@ extern "C" long mpnn_draw_augmentation(const uint32_t *raw, long n_raw, int n, l
     }
     return need;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same draws from a PRIVATE MT19937 state (numpy's legacy layout: key[624] + position), generator included: no Python
+// per sample or per round, and any number of batches per call -- which is what lets a net that is trained beside others
+// (co-trained groups, nets sharded over ranks) see EXACTLY the batches it sees in the reference's serial experiment loop
+// (scripts/train-nets:159-164: one global stream, net after net): its stream is the experiment's stream advanced over the
+// draws of all iterations of the nets in front of it (draw == NULL: advance only; ~1 us per batch of 128).
+// MT19937 (Matsumoto & Nishimura 1998) exactly as numpy.random.RandomState steps it: regenerate the 624 words when the
+// position reaches 624, then temper key[pos++].
+namespace {
+struct Mt {
+    uint32_t *key;
+    int pos;
+    inline uint32_t next() {
+        if (pos >= 624) {
+            for (int k = 0; k < 624; ++k) {
+                const uint32_t y = (key[k] & 0x80000000u) | (key[(k + 1) % 624] & 0x7fffffffu);
+                key[k] = key[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            pos = 0;
+        }
+        uint32_t y = key[pos++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    inline uint32_t bounded(uint32_t rng, uint32_t mask) {       // numpy's legacy masked rejection (rng > 0)
+        uint32_t v;
+        do v = next() & mask; while (v > rng);
+        return v;
+    }
+};
+}  // namespace
+
+extern "C" long mpnn_draw_augmentation_mt(uint32_t *key, int *pos, long batches, int n, long n_src, const unsigned char *sym,
+                                          int r_shift, int *draw) {
+    if (!key || !pos || *pos < 0 || *pos > 624 || batches < 0 || n < 0 || n_src < 1 || n_src > 0xFFFFFFFFL || r_shift < 0) return MPNN_E_ARG;
+    Mt g{key, *pos};
+    const uint32_t rng_j = (uint32_t)(n_src - 1), mask_j = mask_of(rng_j);
+    const uint32_t rng_s = (uint32_t)(2 * r_shift), mask_s = mask_of(rng_s);
+    for (long b = 0; b < batches; ++b)
+        for (int i = 0; i < n; ++i) {
+            const uint32_t j = rng_j ? g.bounded(rng_j, mask_j) : 0u;
+            int flip = 0;
+            if (!sym || sym[j]) {
+                const uint32_t a = g.next() >> 5, c = g.next() >> 6;
+                const double u = ((double)a * 67108864.0 + (double)c) / 9007199254740992.0;
+                flip = !(u < 0.5);
+            }
+            const int du = rng_s ? (int)g.bounded(rng_s, mask_s) - r_shift : 0;
+            const int dv = rng_s ? (int)g.bounded(rng_s, mask_s) - r_shift : 0;
+            if (draw) {
+                int *d = draw + ((size_t)b * n + i) * 4;
+                d[0] = (int)j; d[1] = flip; d[2] = du; d[3] = dv;
+            }
+        }
+    *pos = g.pos;
+    return 0;
+}

@@ -210,9 +210,10 @@ _SIGS = {
     'mpnn_debug_spin': [C.c_int, C.c_int, C.c_float, P],
     'mpnn_debug_noop': [P],
     'mpnn_draw_augmentation': [P, C.c_long, C.c_int, C.c_long, P, C.c_int, P, P],
+    'mpnn_draw_augmentation_mt': [P, P, C.c_long, C.c_int, C.c_long, P, C.c_int, P],
 }
 
-_LONG = {'mpnn_draw_augmentation'}
+_LONG = {'mpnn_draw_augmentation', 'mpnn_draw_augmentation_mt'}
 EXPORTS = sorted(_SIGS) + ['mpnn_version']
 
 _lib = None

@@ -14,7 +14,7 @@ vectorised gather per batch; the mean fill (data.py:19) is per image and channel
 import numpy as np
 import numpy.random as rand
 
-__all__ = ['Dataset']
+__all__ = ['Dataset', 'DrawStream']
 
 
 def _sym_of_sources(y, m_sym):
@@ -66,6 +66,43 @@ def _draw_augmentation_fast(n, n_src, sym_u8, r_shift, out=None, all_sym=False):
     if need < 0:
         raise _hip.HipError('mpnn_draw_augmentation: status %d' % need)
     return out
+
+
+class DrawStream:
+    """A private copy of numpy's legacy random stream (MT19937: key[624] + position) that only ever serves augmentation
+    draws, stepped by the library's host function (mpnn_draw_augmentation_mt): no Python per sample, any number of
+    batches per call.  `DrawStream(seed)` starts where `numpy.random.seed(seed)` starts; `skip(batches, ...)` advances
+    over whole batches.  `serial_positions` hands every net of an experiment the stream position it has in the
+    reference's serial loop (scripts/train-nets:159-164: ONE stream, the nets one after another), so that nets trained
+    side by side train on exactly the batches they see there."""
+    def __init__(self, seed=None, state=None):
+        st = np.random.RandomState(seed).get_state() if state is None else state
+        self.key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        import ctypes as C
+        self.pos = C.c_int(int(st[2]))
+
+    def copy(self):
+        return DrawStream(state=('MT19937', self.key, self.pos.value))
+
+    def state(self):
+        """As numpy.random.RandomState.set_state takes it."""
+        return ('MT19937', self.key.copy(), int(self.pos.value), 0, 0.0)
+
+    def draw(self, n, n_src, sym_u8, r_shift, out=None, batches=1):
+        """`batches` batches of n records (j, flip, du, dv) into out ([batches, n, 4] or [n, 4] int32; None: skip them)."""
+        import ctypes as C
+        from . import _hip
+        lib = _hip.load()
+        if out is not None and not (out.dtype == np.int32 and out.flags.c_contiguous and out.size == batches * n * 4):
+            raise ValueError('out: a C-contiguous int32 array of batches * n * 4 entries')
+        rc = lib.mpnn_draw_augmentation_mt(self.key.ctypes.data_as(C.c_void_p), C.byref(self.pos), batches, n, n_src,
+                                           None if sym_u8 is None else sym_u8.ctypes.data_as(C.c_void_p), r_shift,
+                                           None if out is None else out.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise _hip.HipError('mpnn_draw_augmentation_mt: status %d' % rc)
+        return out
+
+    skip = lambda self, batches, n, n_src, sym_u8, r_shift: self.draw(n, n_src, sym_u8, r_shift, None, batches)
 
 
 def augmented_batch(x0, y, n, m_sym, r_shift, draws=None):
@@ -178,7 +215,7 @@ class Dataset:
         b['ring'][k] = (buf, ev)
         return b['dev'][slot]
 
-    def stage_training_draws_k(self, K, n=128, r_shift=4, eng=None):
+    def stage_training_draws_k(self, K, n=128, r_shift=4, eng=None, stream=None):
         """stage_training_draws for the K steps of one K-step graph replay (record slots 0 .. K-1, drawn in step order from
         the one numpy stream) with ONE upload: a small copy on the compute stream in front of a replay costs ~8 us."""
         import torch
@@ -192,8 +229,14 @@ class Dataset:
         if ev is not None:
             ev.synchronize()
         out = buf.numpy()
-        for j in range(K):
-            _draw_augmentation_fast(n, len(self.x0_tr), self._sym_u8, r_shift, out=out[j, :n], all_sym=self._all_sym)
+        if stream is not None and out.shape[1] == n:
+            stream.draw(n, len(self.x0_tr), self._sym_u8, r_shift, out=out[:K], batches=K)
+        else:
+            for j in range(K):
+                if stream is not None:
+                    stream.draw(n, len(self.x0_tr), self._sym_u8, r_shift, out=out[j, :n])
+                else:
+                    _draw_augmentation_fast(n, len(self.x0_tr), self._sym_u8, r_shift, out=out[j, :n], all_sym=self._all_sym)
         b['dev'][:K, :n].copy_(buf[:K, :n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -268,9 +311,25 @@ class Dataset:
         co.set_prologue(launch)
         return bound
 
-    def stage_cotrainer_draws(self, co, r_shift=4):
+    def serial_positions(self, positions, iters, n=128, r_shift=4, seed=0):
+        """One DrawStream per entry of `positions` (ascending): where the reference's serial experiment loop (one numpy
+        stream seeded with `seed`, `iters` batches of n per net, net after net) starts its net number positions[q].  The
+        nets in between are skipped by the library at a few us per batch."""
+        if getattr(self, '_sym_u8', None) is None:
+            self._sym_u8 = np.ascontiguousarray(_sym_of_sources(self.y_tr, self.m_sym), dtype=np.uint8)
+        s, at, out = DrawStream(seed), 0, []
+        for q in positions:
+            if q < at:
+                raise ValueError('positions must ascend')
+            s.skip(iters * (q - at), n, len(self.x0_tr), self._sym_u8, r_shift)
+            at = q
+            out.append(s.copy())
+        return out
+
+    def stage_cotrainer_draws(self, co, r_shift=4, streams=None):
         """One step's augmentation records of EVERY net of a bound group: the reference's draws, net after net, from the one
-        numpy stream; one asynchronous upload for the whole group."""
+        numpy stream -- or, with streams (one DrawStream per net), every net from its own; one asynchronous upload for the
+        whole group."""
         import torch
         g = self._groups[id(co)]
         k = g['slot'] = (g['slot'] + 1) % len(g['ring'])
@@ -279,7 +338,10 @@ class Dataset:
             ev.synchronize()
         out = buf.numpy()
         for r in range(out.shape[0]):
-            _draw_augmentation_fast(g['n'], len(self.x0_tr), self._sym_u8, r_shift, out=out[r], all_sym=self._all_sym)
+            if streams is not None:                # (net r's own stream: DrawStream, e.g. its position in the serial loop)
+                streams[r].draw(g['n'], len(self.x0_tr), self._sym_u8, r_shift, out=out[r])
+            else:
+                _draw_augmentation_fast(g['n'], len(self.x0_tr), self._sym_u8, r_shift, out=out[r], all_sym=self._all_sym)
         g['dev'].copy_(buf, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())

@@ -209,17 +209,21 @@ def test_cotrained_pipeline_feeds_each_net_its_own_batches(joint):
             nets[1].eval({nets[1].x0: xb, nets[1].y: yb})
 
 
-def test_groups_pipeline_feeds_each_net_its_own_batches():
+@pytest.mark.parametrize('draws', ['joint', 'serial'])
+def test_groups_pipeline_feeds_each_net_its_own_batches(draws):
     """CoGroups through the input pipeline, as train-nets --co-train runs it: one gather launch and one record upload per
-    GROUP, queued on the group's stream; the draws still come from the one numpy stream in net order."""
+    GROUP, queued on the group's stream.  joint: the draws come from the one numpy stream in net order, iteration after
+    iteration.  serial: every net has its own copy of the stream (lib.data.DrawStream), advanced over all iterations of
+    the nets in front of it -- it trains on exactly the batches the SERIAL experiment loop (net after net) feeds it."""
     import arch_and_hypers as A
     from lib._co import CoGroups
     from lib.data import Dataset
     ds = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
     ref = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+    ds.m_sym = ref.m_sym = np.array([1, 0, 1, 1, 0, 0, 1, 0, 1, 1], bool)       # (some classes without the flip draw)
     nets = _nets([A.ac_chain(k_cpt=k) for k in (0.0, 1e-9, 4e-9, 8e-9)] + [A.sr_chain(2)])
     engs = [net.engine() for net in nets]
-    n, K = 32, len(nets)
+    n, K, T = 32, len(nets), 4
     ds.to_device('cuda:0')
     cg = CoGroups.plan(nets, streams=2)
     assert [c.K for c in cg.groups] == [2, 2, 1]
@@ -230,20 +234,27 @@ def test_groups_pipeline_feeds_each_net_its_own_batches():
     cg.on_group_streams(bind)
     np.random.seed(11)
     state0 = np.random.get_state()
-    want = [ref.augmented_training_batch(n) for _ in range(4 * K)]
+    if draws == 'joint':
+        seq = [ref.augmented_training_batch(n) for _ in range(T * K)]
+        want = lambda t, k: seq[K * t + k]
+        streams = None
+    else:
+        seq = [ref.augmented_training_batch(n) for _ in range(K * T)]           # the serial loop: net 0's T batches, then net 1's ...
+        want = lambda t, k: seq[T * k + t]
+        streams = ds.serial_positions(list(range(K)), T, n, seed=11)
     np.random.set_state(state0)
-    for t in range(4):
+    for t in range(T):
         feeds = [{net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.01, **({net.τ: 1.0} if net._net_kind != 'sr' else {})}
                  for net, (x0, y) in zip(nets, bound)]
 
         def step(g, co, span):
-            ds.stage_cotrainer_draws(co)
+            ds.stage_cotrainer_draws(co, streams=None if streams is None else streams[span[0]:span[1]])
             co.run(feeds[span[0]:span[1]])
         cg.on_group_streams(step)
         cg.join()
         torch.cuda.synchronize()
         for k, e in enumerate(engs):
-            wx, wy = want[K * t + k]
+            wx, wy = want(t, k)
             assert np.abs(e.x0[:n].cpu().numpy() - wx).max() <= 1e-6, (t, k)
             assert np.array_equal(e.y[:n].cpu().numpy(), wy), (t, k)
 

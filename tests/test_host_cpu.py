@@ -300,3 +300,41 @@ def test_host_only_entry_points_without_a_gpu():
     assert lib.mpnn_set_reserved_cus(-1) == 0                    # query
     assert lib.mpnn_set_reserved_cus(24) == 0 and lib.mpnn_set_reserved_cus(-1) == 24
     assert lib.mpnn_set_reserved_cus(0) == 24 and lib.mpnn_set_reserved_cus(-1) == 0
+
+
+def test_draw_stream_is_numpys_legacy_stream():
+    """lib.data.DrawStream (mpnn_draw_augmentation_mt: MT19937 stepped inside the library) against the reference's call
+    sequence on numpy's global stream (scripts/lib/data.py:24-34): the same draws, batch after batch, and the same stream
+    position afterwards -- also across the generator's 624-word refills; serial_positions hands net q the stream of the
+    serial experiment loop after q nets of `iters` batches."""
+    import numpy as np
+    from lib import data as D
+    ds = D.Dataset.synthetic(n_tr=300, n_ts=10, seed=1)
+    ds.m_sym = np.array([1, 0, 1, 1, 0, 0, 1, 0, 1, 1], bool)
+    sym = np.ascontiguousarray(D._sym_of_sources(ds.y_tr, ds.m_sym), dtype=np.uint8)
+    for seed, n, r in ((0, 33, 4), (7, 128, 4), (3, 5, 0), (9, 64, 1)):
+        np.random.seed(seed)
+        s = D.DrawStream(seed)
+        for b in range(6):
+            j, flip, sh = D._draw_augmentation(n, 300, ds.y_tr, ds.m_sym, r)
+            out = s.draw(n, 300, sym, r, np.empty((n, 4), np.int32))
+            assert np.array_equal(out[:, 0], j) and np.array_equal(out[:, 1].astype(bool), flip) and np.array_equal(out[:, 2:], sh), (seed, b)
+        rs = np.random.RandomState()
+        rs.set_state(s.state())
+        assert np.array_equal(rs.randint(0, 2 ** 32, 700, dtype=np.uint32), np.random.randint(0, 2 ** 32, 700, dtype=np.uint32))
+    # several batches per call == one per call; skipping == drawing and discarding
+    a, b, c = D.DrawStream(5), D.DrawStream(5), D.DrawStream(5)
+    many = a.draw(17, 300, sym, 3, np.empty((4, 17, 4), np.int32), batches=4)
+    for k in range(4):
+        assert np.array_equal(many[k], b.draw(17, 300, sym, 3, np.empty((17, 4), np.int32)))
+    c.skip(4, 17, 300, sym, 3)
+    assert np.array_equal(c.key, a.key) and c.pos.value == a.pos.value
+    # positions of the serial loop
+    ps = ds.serial_positions([0, 2, 3], 10, n=17, r_shift=3, seed=5)
+    np.random.seed(5)
+    for q in range(4):
+        for it in range(10):
+            j, flip, sh = D._draw_augmentation(17, 300, ds.y_tr, ds.m_sym, 3)
+            if q in (0, 2, 3):
+                out = ps[[0, 2, 3].index(q)].draw(17, 300, sym, 3, np.empty((17, 4), np.int32))
+                assert np.array_equal(out[:, 0], j) and np.array_equal(out[:, 1].astype(bool), flip) and np.array_equal(out[:, 2:], sh), (q, it)
