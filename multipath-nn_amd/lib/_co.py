@@ -252,6 +252,9 @@ class CoGroups:
     caller's stream wait for all of them (before a statistics pass, a checkpoint, any read of the nets' state).
     """
     def __init__(self, nets, sizes, streams=4, share=None):
+        # streams: how many, or a list of torch streams (plan() measures which ones run side by side before it splits)
+        given = None if isinstance(streams, int) else list(streams)
+        streams = len(given) if given is not None else int(streams)
         if sum(sizes) != len(nets) or min(sizes) < 1:
             raise ValueError('group sizes must add up to the number of nets')
         self.nets = list(nets)
@@ -268,12 +271,21 @@ class CoGroups:
             at += s
         self.dev = self.groups[0].dev
         self.n_streams = max(1, min(int(streams), len(self.groups)))
-        self.streams = concurrent_streams(self.dev, self.n_streams) if len(self.groups) > 1 else [None]
+        if len(self.groups) == 1:
+            self.streams = [None]
+        else:
+            self.streams = (given if given is not None else concurrent_streams(self.dev, self.n_streams))[:self.n_streams]
         self._forked = False
 
     @classmethod
     def plan(cls, nets, streams=4, share=None):
-        """Split nets (in order) into runs of one architecture, and those into about `streams` equal groups."""
+        """Split nets (in order) into runs of one architecture, and those into about `streams` equal groups -- `streams` capped
+        by the number of streams that really run side by side on this device (concurrent_streams: with fewer hardware
+        queues than groups the groups would serialise, and one joint graph is the better form)."""
+        found = None
+        if streams > 1 and len(nets) > 1:
+            found = concurrent_streams(nets[0].engine().dev, streams)
+            streams = len(found)
         sig = _arch_signature
         runs, sizes = [], []
         for net in nets:
@@ -287,7 +299,7 @@ class CoGroups:
             g = max(1, min(cnt, round(streams * cnt / K)))
             base, extra = divmod(cnt, g)
             sizes += [base + (1 if i < extra else 0) for i in range(g)]
-        return cls(nets, sizes, streams, share)
+        return cls(nets, sizes, found if (found and len(sizes) > 1) else streams, share)
 
     def stream_of(self, g):
         return self.streams[g % len(self.streams)]
