@@ -115,6 +115,32 @@ def test_groups_side_by_side_equal_the_solo_steps(makers, streams, sizes, share)
     _compare_with_solo_steps(co_nets, solo, run, cg.share, 16, routed=routed)
 
 
+def test_groups_side_by_side_are_deterministic():
+    """A race detector for the side-by-side form: groups on different streams share nothing but the read-only dataset, and
+    every group's joint graph is deterministic -- so 60 free-running rounds (no barrier between steps, the groups drift
+    against each other) from one state, twice, must end in bit-identical parameters, momentum and BatchNorm state,
+    whatever the interleaving was."""
+    import arch_and_hypers as A
+    from lib._co import CoGroups
+    ks = A.k_cpts
+    outs = []
+    for rep in range(2):
+        nets = _nets([A.ac_chain(k_cpt=ks[i]) for i in range(4)] + [A.sr_chain(3)])
+        cg = CoGroups.plan(nets, streams=4)
+        assert [c.K for c in cg.groups] == [2, 1, 1, 1] or len(cg.streams) < 4
+        xs = [batch(32, seed=50 + i) for i in range(len(nets))]
+        for t in range(60):
+            feeds = [{net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.02, **({net.τ: 1.0 - 0.01 * t} if net._net_kind != 'sr' else {})}
+                     for net, (x0, y) in zip(nets, xs)]
+            cg.run(feeds)
+        cg.join()
+        torch.cuda.synchronize()
+        outs.append([(net.engine().P.clone(), net.engine().A.clone(), net.engine().S.clone()) for net in nets])
+    for (p0, a0, s0), (p1, a1, s1) in zip(*outs):
+        assert torch.equal(p0, p1) and torch.equal(a0, a1) and torch.equal(s0, s1)
+        assert bool(torch.isfinite(p0).all())
+
+
 @pytest.mark.parametrize('kind,K,n', [('ac', 2, 16), ('cr', 3, 16), ('ac', 8, 128)])
 def test_cotrained_net_matches_the_oracle(kind, K, n):
     """The whole-net oracle check of tests/test_net_parity.py (decision-forced float64, every gradient and update within
