@@ -433,6 +433,28 @@ typedef struct {
 int mpnn_exit_ev(const mpnn_exit_ev_args *dev_table, int count, int n_max, void *stream);
 int mpnn_exit_ev_check(const mpnn_exit_ev_args *host_record);
 
+/* The routed evaluation's dense prefix made routed after the fact (csrc/exit_ev.hip): the exits of the blocks whose
+ * convs run on every sample anyway (the first d0 tree depths) are evaluated densely in ONE mpnn_exit_ev launch; this
+ * launch then walks every sample through the prefix's switches (arg-max of the router outputs, first index on ties:
+ * net_types.py:127-129), clears r / c_err / d_cor of the prefix nodes the sample does not reach and appends it to the
+ * sample list of the frontier block it arrives at.  Same results as the exit-by-exit routed pass, (d0 - 1) serial
+ * launches fewer.  Records in topological order; parent[j] = record of the nearest switch above record j (-1: every
+ * sample reaches it), parent_sink[j] = the sink of that switch that leads to j; n_sinks[j] = 0: no router at j;
+ * c_err[j] / d_cor[j] NULL: no head at j.  front_*: the lists to fill.  host_rec is validated, dev_rec (the same
+ * record in device memory) is what the kernel reads. */
+#define MPNN_PREFIX_MAX 64
+typedef struct {
+    int n, count, n_front, pad_;
+    int parent[MPNN_PREFIX_MAX], parent_sink[MPNN_PREFIX_MAX], n_sinks[MPNN_PREFIX_MAX], r_stride[MPNN_PREFIX_MAX];
+    float *r[MPNN_PREFIX_MAX];
+    float *c_err[MPNN_PREFIX_MAX];
+    float *d_cor[MPNN_PREFIX_MAX];
+    int front_parent[MPNN_PREFIX_MAX], front_sink[MPNN_PREFIX_MAX];
+    int *front_idx[MPNN_PREFIX_MAX];
+    int *front_cnt[MPNN_PREFIX_MAX];
+} mpnn_ev_prefix_args;
+int mpnn_ev_prefix_walk(const mpnn_ev_prefix_args *host_rec, const mpnn_ev_prefix_args *dev_rec, void *stream);
+
 /* ---- any-WIDTH forms of the exit path (csrc/exit_gen.hip) -------------------
  * LinTrans takes any n_chan (layer_types.py:39-53) and the router MLP any hidden width (arch_and_hypers.py:14,45-49);
  * the tuned kernels above hold n_cls <= 16 and two EQUAL hidden layers of <= 16 units.  The same argument records go

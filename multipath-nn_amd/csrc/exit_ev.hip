@@ -238,3 +238,79 @@ extern "C" int mpnn_exit_ev_check(const mpnn_exit_ev_args *host_rec) {
     if (a.idx && !a.cnt) return MPNN_E_ARG;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mpnn_ev_prefix_walk: the routed evaluation's DENSE PREFIX made routed after the fact.
+//
+// A routed pass is a chain of (conv, exit) launches per tree depth: a router's decision gates the NEXT exit, so eight
+// blocks are eight serial exit launches of ~15 us where the dense pass has one -- which is what keeps the routed pass
+// slower than the dense one below ~1 000 samples, where running deep blocks on fewer samples saves nothing.  The blocks
+// of the first d0 depths run their convs on every sample anyway (Engine.routed_prefix); so their exits run densely too,
+// in ONE mpnn_exit_ev launch, and this kernel restores the routed pass's contract afterwards: one thread per sample
+// walks the prefix's switches top-down (arg-max of the router outputs, first index on ties -- the rule of exit_ev_k),
+// ZEROES r / c_err / delta_cor of every prefix node the sample does not reach, and appends the sample to the list of the
+// frontier block (depth d0) it arrives at (ballot + popcount prefix, one atomic per wave and list, as in exit_ev_k).
+// Results are identical to the exit-by-exit routed pass: same kernels, same per-sample arithmetic, same lists.
+__global__ __launch_bounds__(256) void ev_prefix_k(const mpnn_ev_prefix_args *__restrict__ tab) {
+    const mpnn_ev_prefix_args &a = *tab;
+    const int s = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const bool live = s < a.n;
+    const size_t sv = live ? s : 0;
+    // pass 1: every switch's decision (2 bits each); the loads of different records are independent
+    unsigned long long arg_lo = 0ull, arg_hi = 0ull;
+#pragma unroll 4
+    for (int j = 0; j < a.count; ++j) {
+        const int S = a.n_sinks[j];
+        if (S <= 0) continue;
+        const float *r = a.r[j] + sv * a.r_stride[j];
+        int arg = 0; float best = r[0];
+        for (int i = 1; i < S; ++i) { const float v = r[i]; if (v > best) { best = v; arg = i; } }
+        if (j < 32) arg_lo |= (unsigned long long)arg << (2 * j); else arg_hi |= (unsigned long long)arg << (2 * (j - 32));
+    }
+    auto arg_of = [&](int j) { return (int)(((j < 32 ? arg_lo >> (2 * j) : arg_hi >> (2 * (j - 32)))) & 3ull); };
+    // pass 2: reach bits in topological order (parents first), entries of unreached nodes cleared
+    unsigned long long reach = 0ull;
+    for (int j = 0; j < a.count; ++j) {
+        const int p = a.parent[j];
+        const bool here = p < 0 || (((reach >> p) & 1ull) && arg_of(p) == a.parent_sink[j]);
+        if (here) reach |= 1ull << j;
+        else if (live) {
+            if (a.c_err[j]) { a.c_err[j][s] = 0.f; a.d_cor[j][s] = 0.f; }
+            if (a.n_sinks[j] > 0) { float *r = a.r[j] + sv * a.r_stride[j]; for (int i = 0; i < a.n_sinks[j]; ++i) r[i] = 0.f; }
+        }
+    }
+    // pass 3: the frontier blocks' sample lists
+    for (int f = 0; f < a.n_front; ++f) {
+        const int p = a.front_parent[f];
+        const bool mine = live && ((reach >> p) & 1ull) && arg_of(p) == a.front_sink[f];
+        const unsigned long long m = __ballot(mine);
+        if (!m) continue;                                   // (wave-uniform)
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.front_cnt[f], (int)__popcll(m));
+        base = __shfl(base, 0);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (mine && pos < a.n) a.front_idx[f][pos] = s;
+    }
+}
+
+extern "C" int mpnn_ev_prefix_walk(const mpnn_ev_prefix_args *host_rec, const mpnn_ev_prefix_args *dev_rec, void *stream) {
+    if (!host_rec || !dev_rec) return MPNN_E_ARG;
+    const mpnn_ev_prefix_args &a = *host_rec;
+    if (a.n <= 0) return 0;
+    if (a.count < 1 || a.count > MPNN_PREFIX_MAX || a.n_front < 0 || a.n_front > MPNN_PREFIX_MAX) return MPNN_E_SHAPE;
+    for (int j = 0; j < a.count; ++j) {
+        if (a.parent[j] >= j) return MPNN_E_ARG;                                  // (parents first)
+        if (a.parent[j] >= 0 && (a.n_sinks[a.parent[j]] <= 0 || a.parent_sink[j] < 0 || a.parent_sink[j] >= a.n_sinks[a.parent[j]])) return MPNN_E_ARG;
+        if (a.n_sinks[j] < 0 || a.n_sinks[j] > MPNN_MAX_SINKS) return MPNN_E_SHAPE;
+        if (a.n_sinks[j] > 0 && (!a.r[j] || a.r_stride[j] < a.n_sinks[j])) return MPNN_E_ARG;
+        if ((a.c_err[j] != nullptr) != (a.d_cor[j] != nullptr)) return MPNN_E_ARG;
+    }
+    for (int f = 0; f < a.n_front; ++f) {
+        const int p = a.front_parent[f];
+        if (p < 0 || p >= a.count || a.n_sinks[p] <= 0 || a.front_sink[f] < 0 || a.front_sink[f] >= a.n_sinks[p] ||
+            !a.front_idx[f] || !a.front_cnt[f]) return MPNN_E_ARG;
+    }
+    hipLaunchKernelGGL(ev_prefix_k, dim3((a.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dev_rec);
+    MPNN_LAUNCH_CHECK();
+    return 0;
+}

@@ -148,6 +148,17 @@ class FinishNet(C.Structure):
                 ('inv_n', C.c_float), ('grad_scale', C.c_float), ('w_eq', P), ('packs', P), ('plain_seg', P), ('n_plain', C.c_int)]
 
 
+PREFIX_MAX = 64
+
+
+class EvPrefixArgs(C.Structure):
+    _fields_ = [('n', C.c_int), ('count', C.c_int), ('n_front', C.c_int), ('pad_', C.c_int),
+                ('parent', C.c_int * PREFIX_MAX), ('parent_sink', C.c_int * PREFIX_MAX), ('n_sinks', C.c_int * PREFIX_MAX),
+                ('r_stride', C.c_int * PREFIX_MAX), ('r', P * PREFIX_MAX), ('c_err', P * PREFIX_MAX), ('d_cor', P * PREFIX_MAX),
+                ('front_parent', C.c_int * PREFIX_MAX), ('front_sink', C.c_int * PREFIX_MAX),
+                ('front_idx', P * PREFIX_MAX), ('front_cnt', P * PREFIX_MAX)]
+
+
 class AugmentDst(C.Structure):
     _fields_ = [('draw', P), ('x_out', P), ('y_out', P)]
 
@@ -211,6 +222,7 @@ _SIGS = {
     'mpnn_debug_noop': [P],
     'mpnn_draw_augmentation': [P, C.c_long, C.c_int, C.c_long, P, C.c_int, P, P],
     'mpnn_draw_augmentation_mt': [P, P, C.c_long, C.c_int, C.c_long, P, C.c_int, P],
+    'mpnn_ev_prefix_walk': [C.POINTER(EvPrefixArgs), P, P],
 }
 
 _LONG = {'mpnn_draw_augmentation', 'mpnn_draw_augmentation_mt'}

@@ -105,7 +105,7 @@ class Engine:
         self.multi_stream = bool(int(os.environ.get('MPNN_STREAMS', '0')))
         self.group_fwd = bool(int(os.environ.get('MPNN_FWD_GROUP', '1')))   # wavefront-grouped forward launches
         self.bwd_levels = bool(int(os.environ.get('MPNN_BWD_LEVELS', '1')))  # one backward launch per dependency level
-        self.routed_min_batch = int(os.environ.get('MPNN_ROUTED_MIN_BATCH', '1280'))
+        self.routed_min_batch = int(os.environ.get('MPNN_ROUTED_MIN_BATCH', '512'))
         self.fold_clear = bool(int(os.environ.get('MPNN_FOLD_CLEAR', '1')))  # no clearing launch in a training step
         self._acc_clean = False          # the step's accumulators (slot sums, TALR statistics, loss) are cleared
         self._streams = []
@@ -774,7 +774,7 @@ class Engine:
             if n >= lim:
                 return d0
         return self._ROUTED_PREFIX[-1][1]
-    _ROUTED_PREFIX = ((6144, 1), (3072, 2), (1536, 3), (0, 4))
+    _ROUTED_PREFIX = ((6144, 1), (3072, 2), (1536, 3), (640, 4), (0, 6))     # (re-swept with the prefix walk: profiles/r05_eval_prefix_sweep.txt)
 
     def _program(self, mode, n, routed):
         # routed='auto': routed above ROUTED_MIN_BATCH samples, dense below (the routed schedule is block-serial --
@@ -1338,11 +1338,28 @@ class Engine:
         # program); from depth d0 on a block's convs gather through its sample list.  Every EXIT runs on its block's list
         # (so that r / c_err / d_cor are only written where a sample reaches the node), whatever the depth.
         d0 = int(routed)
+        # The dense prefix's EXITS in one launch as well (d0 >= 2): a routed pass is a chain of (conv, exit) launches per
+        # depth, each exit gated by the router above it -- d0 serial exit launches for blocks whose convs run on every
+        # sample anyway.  Their exits run densely in ONE launch instead; mpnn_ev_prefix_walk then clears the entries of the
+        # samples that do not reach a node and writes the lists of the blocks at depth d0 (csrc/exit_ev.hip).  Same results.
+        def src_of(b):
+            # the nearest switch above block b and the sink of it that leads to b (None: every sample reaches b)
+            child, p = b, b.parent
+            while p is not None and p.router is None:
+                child, p = p, p.parent
+            return None if p is None else (p, p.sink_blocks.index(child))
+        prefix = [b for b in self.blocks if routed and depth[id(b)] < d0]
+        walk = bool(routed) and d0 >= 2 and os.environ.get('MPNN_EV_PREFIX_WALK', '1') != '0' and \
+            sum(1 for b in prefix if b.has_exit) <= _hip.PREFIX_MAX and \
+            sum(1 for b in self.blocks if depth[id(b)] == d0) <= _hip.PREFIX_MAX
+        in_prefix = {id(b) for b in prefix} if walk else set()
         # sample lists: a block below a dynamic switch owns one; below a static node it shares its parent's
         for b in self.blocks:
             par = b.parent
-            if not routed or par is None:
+            if not routed or par is None or id(b) in in_prefix:
                 b.ev_list = None
+            elif walk and depth[id(b)] == d0:          # (frontier: its list comes from the prefix walk)
+                b.ev_list = (b.ev_idx, b.ev_cnt) if src_of(b) is not None else None
             elif par.router is not None:
                 b.ev_list = (b.ev_idx, b.ev_cnt)
             else:
@@ -1410,7 +1427,7 @@ class Engine:
                 e.w3, e.bias3 = D(l3.params.w), D(l3.params.b)
                 e.bn_eps = float(bn1.hypers.ϵ)
                 e.r, e.r_stride = self.r[sw * n * MS:].data_ptr(), MS
-                if routed:
+                if routed and id(b) not in in_prefix:       # (a prefix exit runs on every sample: the walk writes the lists)
                     for i, sb in enumerate(b.sink_blocks):
                         if sb is not None:
                             e.child_idx[i], e.child_cnt[i] = sb.ev_idx.data_ptr(), sb.ev_cnt.data_ptr()
@@ -1448,8 +1465,36 @@ class Engine:
             for b in self.blocks:
                 by_depth.setdefault(depth[id(b)], []).append(b)
             wavefront([b for b in self.blocks if depth[id(b)] < d0])
+            if walk:
+                exits_of(prefix)
+                pa, rec_of = _hip.EvPrefixArgs(), {}
+                pa.n = n
+                for b in prefix:
+                    if not b.has_exit:
+                        continue
+                    j = rec_of[id(b)] = len(rec_of)
+                    src = src_of(b)
+                    pa.parent[j], pa.parent_sink[j] = (-1, 0) if src is None else (rec_of[id(src[0])], src[1])
+                    e = recs[id(b)]
+                    if b.router is not None:
+                        pa.n_sinks[j], pa.r_stride[j], pa.r[j] = e.n_sinks, e.r_stride, e.r
+                    if b.head is not None:
+                        pa.c_err[j], pa.d_cor[j] = e.c_err, e.d_cor
+                pa.count = len(rec_of)
+                for b in self.blocks:
+                    if depth[id(b)] == d0 and b.ev_list is not None:
+                        f = pa.n_front
+                        src = src_of(b)
+                        pa.front_parent[f], pa.front_sink[f] = rec_of[id(src[0])], src[1]
+                        pa.front_idx[f], pa.front_cnt[f] = b.ev_idx.data_ptr(), b.ev_cnt.data_ptr()
+                        pa.n_front = f + 1
+                dev_pa = _hip.to_device_table([pa], self.dev)
+                keep.extend([pa, dev_pa])
+                fwd.append(call(lib.mpnn_ev_prefix_walk, 'ev_prefix_walk', C.byref(pa), dev_pa.data_ptr()))
             for d in sorted(by_depth):
                 bs = by_depth[d]
+                if walk and d < d0:
+                    continue
                 if d >= d0:
                     for i in range(max(b.L for b in bs)):
                         members = [(b, i) for b in bs if i < b.L]

@@ -156,7 +156,7 @@ class Net(metaclass=ABCMeta):
         """Forward pass + routing in evaluation mode ('ev': BatchNorm moving averages, hard routing);
         per-layer results are then readable as ``ℓ.p_ev``, ``ℓ.δ_cor`` ... device tensors.
 
-        routed='auto' picks the routed evaluation from 1 280 samples per launch on and the dense one below
+        routed='auto' picks the routed evaluation from 512 samples per launch on and the dense one below
         (Engine.routed_min_batch); routed=True runs the ROUTED evaluation: a block only processes the samples its ancestors'
         routers sent to it (sample lists compacted on the device, no host sync) -- from a depth the engine picks by
         batch size (Engine.routed_prefix: the first blocks lose few samples, and below ~6 000 samples running their

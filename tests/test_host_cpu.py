@@ -40,7 +40,7 @@ def test_ctypes_structs_match_the_c_layout():
              ('mpnn_exit_tail_bwd_args', _hip.ExitTailBwdArgs), ('mpnn_route_args', _hip.RouteArgs),
              ('mpnn_exit_ev_args', _hip.ExitEvArgs), ('mpnn_conv_nhwc_fwd_args', _hip.ConvNhwcFwdArgs),
              ('mpnn_conv_nhwc_dgrad_args', _hip.ConvNhwcDgradArgs), ('mpnn_conv_nhwc_wgrad_args', _hip.ConvNhwcWgradArgs),
-             ('mpnn_finish_net', _hip.FinishNet)]
+             ('mpnn_finish_net', _hip.FinishNet), ('mpnn_ev_prefix_args', _hip.EvPrefixArgs)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mpnn_hip.h"', 'int main(void){']
     for cname, cls in pairs:
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
@@ -62,7 +62,7 @@ def test_ctypes_structs_match_the_c_layout():
               'MPNN_HYP_N': _hip.HYP_N, 'MPNN_BWD_LEVEL_MAX': _hip.BWD_LEVEL_MAX, 'MPNN_HYP_TAU': _hip.HYP_TAU, 'MPNN_HYP_EPS': _hip.HYP_EPS,
               'MPNN_NET_CRITIC': _hip.NET_CRITIC, 'MPNN_ACT_BN_MOVING': _hip.ACT_BN_MOVING,
               'MPNN_SLAB_ITEM': _hip.SLAB_ITEM, 'MPNN_LIN_KSLICES': _hip.LIN_KSLICES, 'MPNN_SEG_INTS': _hip.SEG_INTS,
-              'MPNN_LIN_RSPLIT': _hip.LIN_RSPLIT, 'MPNN_LIN_RS_TILE': _hip.LIN_RS_TILE}.get(name)
+              'MPNN_PREFIX_MAX': _hip.PREFIX_MAX, 'MPNN_LIN_RSPLIT': _hip.LIN_RSPLIT, 'MPNN_LIN_RS_TILE': _hip.LIN_RS_TILE}.get(name)
         if py is not None:
             assert py == int(val), name
 
@@ -338,3 +338,31 @@ def test_draw_stream_is_numpys_legacy_stream():
             if q in (0, 2, 3):
                 out = ps[[0, 2, 3].index(q)].draw(17, 300, sym, 3, np.empty((17, 4), np.int32))
                 assert np.array_equal(out[:, 0], j) and np.array_equal(out[:, 1].astype(bool), flip) and np.array_equal(out[:, 2:], sh), (q, it)
+
+
+def test_ev_prefix_walk_refuses_bad_records():
+    """mpnn_ev_prefix_walk validates the host record before anything is launched (no GPU needed to be refused)."""
+    import ctypes as C
+    from lib import _hip
+    lib = _hip.load()
+    a = _hip.EvPrefixArgs()
+    assert lib.mpnn_ev_prefix_walk(None, None, None) == _hip.E_ARG
+    a.n = 0
+    assert lib.mpnn_ev_prefix_walk(C.byref(a), 1, None) == 0                  # (nothing to do)
+    a.n, a.count = 16, 0
+    assert lib.mpnn_ev_prefix_walk(C.byref(a), 1, None) == _hip.E_SHAPE
+    a.count = _hip.PREFIX_MAX + 1
+    assert lib.mpnn_ev_prefix_walk(C.byref(a), 1, None) == _hip.E_SHAPE
+    a.count = 2
+    a.parent[0], a.parent[1] = -1, 1                                          # a record below itself
+    assert lib.mpnn_ev_prefix_walk(C.byref(a), 1, None) == _hip.E_ARG
+    a.parent[1], a.parent_sink[1], a.n_sinks[0] = 0, 2, 2                      # sink 2 of a two-way switch
+    a.r[0], a.r_stride[0] = 64, 2
+    assert lib.mpnn_ev_prefix_walk(C.byref(a), 1, None) == _hip.E_ARG
+    a.parent_sink[1], a.n_sinks[0] = 1, _hip.MAX_SINKS + 1
+    assert lib.mpnn_ev_prefix_walk(C.byref(a), 1, None) == _hip.E_SHAPE
+    a.n_sinks[0], a.r_stride[0] = 2, 1                                         # rows narrower than the sinks
+    assert lib.mpnn_ev_prefix_walk(C.byref(a), 1, None) == _hip.E_ARG
+    a.r_stride[0], a.n_front = 2, 1
+    a.front_parent[0], a.front_sink[0] = 1, 0                                  # a list below a node without a switch
+    assert lib.mpnn_ev_prefix_walk(C.byref(a), 1, None) == _hip.E_ARG

@@ -195,6 +195,38 @@ def test_exit_fractions_one_eighth_each(kind):
     assert np.allclose(hist, 1 / 8), hist
 
 
+@pytest.mark.parametrize('kind', ['ac', 'cr'])
+def test_prefix_walk_at_every_depth(kind):
+    """The dense prefix's exits in ONE launch + mpnn_ev_prefix_walk (d0 >= 2: lib/_plan.py:_program_ev): for every prefix
+    depth of the 8-block chain -- up to d0 = 8, where nothing is left to gather and the walk only clears the entries of
+    the samples that do not reach a node -- the routed pass still equals the dense one exactly, unreached entries are 0
+    and the frontier's list == nonzero(p_ev); and it equals the exit-by-exit routed pass (MPNN_EV_PREFIX_WALK=0)."""
+    import os
+    net = make(kind, seed=21, k_cpt=1e-9)
+    randomise_routers(net, seed=4, scale=1.0)
+    x0, y = batch(200, seed=9)
+    calibrate_exit_fractions(net, x0, y, [0.1, 0.2, 0.05, 0.15, 0.1, 0.1, 0.1])
+    check_routed_equals_dense(net, x0, y, modes=(2, 4, 5, 7, 8))
+    eng = net.engine()
+    net.eval({net.x0: x0, net.y: y}, routed=5)
+    torch.cuda.synchronize()
+    assert any(op.what == 'ev_prefix_walk' for op in eng.program('ev', 200, routed=5)['fwd'])
+    with_walk = snapshot(net)
+    os.environ['MPNN_EV_PREFIX_WALK'] = '0'
+    try:
+        eng._progs.clear(); eng._graphs.clear()
+        net.eval({net.x0: x0, net.y: y}, routed=5)
+        torch.cuda.synchronize()
+        assert not any(op.what == 'ev_prefix_walk' for op in eng.program('ev', 200, routed=5)['fwd'])
+        without = snapshot(net)
+    finally:
+        del os.environ['MPNN_EV_PREFIX_WALK']
+        eng._progs.clear(); eng._graphs.clear()
+    for grp in ('p_ev', 'c_err', 'd_cor', 'r'):
+        for k in with_walk[grp]:
+            assert np.array_equal(with_walk[grp][k], without[grp][k]), (grp, k)
+
+
 def test_tree_net_routed_equals_dense_at_600():
     """A TREE (ac_tree: multi-child blocks, 3-way switches) at an evaluation-size batch: the strip bodies and the
     32-channel tiles run inside the tree's groups too; routed == dense bit for bit, sample lists == nonzero(p_ev)."""
@@ -208,7 +240,7 @@ def test_tree_net_routed_equals_dense_at_600():
             p.assign(rng.random(p.shape) * 0.5 + (0.75 if p.name == 'v_avg' else -0.25))
     randomise_routers(net, seed=3, scale=1.0)
     x0, y = batch(600, seed=12)
-    dense = check_routed_equals_dense(net, x0, y)
+    dense = check_routed_equals_dense(net, x0, y, modes=(True, 1, 2, 3, 4))
     hist = np.stack([dense['p_ev'][nd.idx] for nd in eng.leaves]).mean(1)
     assert (hist > 0).sum() >= 4, hist
 

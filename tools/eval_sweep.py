@@ -21,7 +21,7 @@ for nb in [int(a) for a in sys.argv[1:]] or [1024, 4096, 8192]:
     if os.environ.get('PREFIX_SWEEP'):
         # routed evaluation with the convs of the blocks above depth d0 run on every sample (lib/_plan.py:_program_ev)
         line = []
-        for d0 in (False, 1, 2, 3, 4, 5, 6):
+        for d0 in (False, 1, 2, 3, 4, 5, 6, 7, 8):
             for _ in range(3): net.eval(feed, routed=d0)
             torch.cuda.synchronize(); t = time.perf_counter()
             for _ in range(20): net.eval(feed, routed=d0)
