@@ -181,8 +181,15 @@ def attach(net, force=False):
         return net
     eng = net.engine()
     if not hasattr(eng, 'dp_buckets'):
-        raise NotImplementedError('%s has no gradient buckets: data-parallel training covers the multiscale chain / tree '
-                                  'engine (lib/_plan.py), not the single-scale Conv engine' % type(eng).__name__)
+        # the single-scale Conv engine (lib/_plan_conv.py: eager launches, no BatchNorm): one blocking all-reduce of G in
+        # front of its optimizer launch, identical replicas to start from
+        eng.world, eng.allreduce = dist.get_world_size(), allreduce_async
+        for buf in (eng.P, eng.A):
+            if buf.is_cuda and dist.get_backend() == 'gloo':
+                h = buf.cpu(); dist.broadcast(h, src=0); buf.copy_(h)
+            else:
+                dist.broadcast(buf, src=0)
+        return net
     eng.world = dist.get_world_size()
     eng.allreduce = allreduce_async
     eng.allreduce_capturable = dist.get_backend() == 'nccl' and eng.P.is_cuda     # RCCL collectives capture into hipGraphs
@@ -209,6 +216,9 @@ def attach(net, force=False):
 def detach(net):
     """Back to single-process training (bench: after the 1-rank structure measurement)."""
     eng = net.engine()
+    if not hasattr(eng, 'dp_buckets'):
+        eng.world, eng.allreduce = 1, None
+        return net
     eng.world, eng.allreduce, eng.allreduce_capturable, eng.dp_agree, eng.dp_quiesce = 1, None, False, None, None
     eng._graphs.clear()
     return net

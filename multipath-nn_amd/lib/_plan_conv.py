@@ -351,7 +351,9 @@ class ConvEngine:
             w.a, w.g = self._act(k), self.g[k].data_ptr()
             w.n, w.H, w.W, w.Cout, w.supp = n, hi, wi, self.C[k + 1], supp
             pw, pb = c.params.w, c.params.b
-            split = self.n_split[k] if supp == 3 else 1
+            # (n_split was sized for the CAPACITY; a smaller batch may have fewer pixel tiles than that, and a split without
+            # a tile never writes its slab -- the reduction would add whatever an earlier stage left there)
+            split = min(self.n_split[k], max(1, lib.mpnn_wgrad_tiles(n, hi, wi))) if supp == 3 else 1
             if supp == 3 and split > 1:
                 stride = (pw.size + pb.size + 3) // 4 * 4
                 w.dw, w.db = self.slab.data_ptr(), self.slab[pw.size:].data_ptr()
@@ -381,8 +383,14 @@ class ConvEngine:
             if supp == 3 and self.pack[k][1] is None:
                 raise NotImplementedError('3x3 Conv above the first stage needs a multiple of 16 input channels')
             self._chk(lib.mpnn_conv_nhwc_dgrad(C.byref(d), st), 'conv_nhwc_dgrad')
+        if self.allreduce is not None:
+            # data parallel (lib/_dp.py): every rank's gradient SUMS over its n samples -> all-reduce (sum), then the
+            # optimizer divides by n * world: the step of the global batch (no BatchNorm here: nothing else to exchange)
+            h = self.allreduce(self.G)
+            if hasattr(h, 'wait'):
+                h.wait()
         self._chk(lib.mpnn_talr_momentum_step(self.P.data_ptr(), self.A.data_ptr(), self.G.data_ptr(), self.seg.data_ptr(),
-                                              self.n_seg, self.node_stat.data_ptr(), self.hyp.data_ptr(), 0, 1.0 / n, 1.0,
+                                              self.n_seg, self.node_stat.data_ptr(), self.hyp.data_ptr(), 0, 1.0 / (n * self.world), 1.0 / self.world,
                                               self.w_eq.data_ptr() if self.w_eq is not None else None, None, st), 'talr_momentum_step')
 
     def state(self):

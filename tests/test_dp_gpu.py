@@ -120,6 +120,55 @@ def test_two_ranks_match_hand_summed_gradients(tmp_path):
     assert np.abs(p0 - pa).max() <= 3e-4 * scale, np.abs(p0 - pa).max()
 
 
+def _conv_batch(rank, n=12):
+    g = np.random.default_rng(300 + rank)
+    return g.random((n, 16, 16, 3)).astype(np.float32), np.eye(10, dtype=np.float32)[g.integers(0, 10, n)]
+
+
+def _conv_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, 'multipath-nn_amd'), os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from test_conv_layer import conv_net
+    from lib import _dp
+    net = conv_net(res=True)((16, 16, 3), (10,))
+    net.engine().init_params(4 + rank)               # (different on purpose: attach broadcasts rank 0's)
+    _dp.init('gloo')
+    torch.cuda.set_device(0)
+    _dp.attach(net)
+    x0, y = _conv_batch(rank)
+    for t in range(3):
+        net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.05, net.μ_lrn: 0.9})
+    torch.cuda.synchronize()
+    np.save(os.path.join(out, 'C%d.npy' % rank), net.engine().P.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_scale_conv_engine_is_data_parallel(tmp_path):
+    """_dp.attach on the single-scale Conv engine (lib/_plan_conv.py; round 4 refused it): two ranks x 12 images take
+    the steps one process takes on the 24 images (no BatchNorm in these nets: the global-batch step exactly, up to
+    fp32 summation order), replicas bit-identical."""
+    world, port = 2, _free_port()
+    mp.spawn(_conv_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    p0, p1 = (np.load(str(tmp_path / ('C%d.npy' % r))) for r in range(2))
+    assert np.array_equal(p0, p1), 'replicas diverged'
+    for p in (os.path.join(ROOT, 'tests'),):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from test_conv_layer import conv_net
+    net = conv_net(res=True)((16, 16, 3), (10,))
+    net.engine().init_params(4)
+    (xa, ya), (xb, yb) = _conv_batch(0), _conv_batch(1)
+    x0, y = np.concatenate([xa, xb]), np.concatenate([ya, yb])
+    for t in range(3):
+        net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.05, net.μ_lrn: 0.9})
+    torch.cuda.synchronize()
+    want = net.engine().P.cpu().numpy()
+    assert np.abs(p0 - want).max() <= 2e-5 * np.abs(want).max(), np.abs(p0 - want).max()
+
+
 def _rccl_one_rank(_idx, port, out, one_graph='1'):
     os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                       MPNN_DP_ONE_GRAPH=one_graph)
