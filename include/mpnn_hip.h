@@ -513,6 +513,12 @@ typedef struct {
     float *node_stat;                    /* [n_nodes][2] accumulated               */
     double *loss;                        /* [4] accumulated                        */
     int n;  int n_total;                 /* n_total: samples the mean is over      */
+    /* node_stat with MORE THAN TWO workgroups (two fp32 atomics onto a cleared sum commute; three do not): every
+     * workgroup stores its partial sums in stat_part (floats [workgroups][n_nodes][2], then doubles [workgroups][4] for
+     * the loss sums; room for ceil(n / 16) workgroups: ceil(n / 16) * (2 * n_nodes + 8) floats, 8-byte aligned), the last
+     * one to finish (stat_ticket: one int, zero between launches) adds them up in workgroup order -- the TALR statistics,
+     * and with them the whole step, are the same bits from run to run.  NULL: atomics (evaluation; small batches). */
+    float *stat_part;  int *stat_ticket;
 } mpnn_route_args;
 int mpnn_route(const mpnn_route_args *args, void *stream);
 /* mpnn_route of `count` co-trained nets with the same tree shape and batch size as one launch (host_table sizes it,

@@ -51,9 +51,10 @@ __device__ __forceinline__ int4 uniform4(int4 v) {   // a record is the same in 
 
 // blk = workgroup index within the net's launch (RB samples each)
 template <int RB>
-__device__ __forceinline__ void route_body(const mpnn_route_args &a, const int blk) {
+__device__ __forceinline__ void route_body(const mpnn_route_args &a, const int blk, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n = a.n, NN = a.n_nodes, MS = a.max_sinks;
+    const bool det_stat = a.node_stat && a.stat_part && nblk > 2;     // (uniform; <= 2 workgroups: two atomics onto a cleared sum commute)
     trace_stamp(0); trace_note(6, 14);
     float *P = lds;                               // p_tr per node            [NN][RB]
     float *PE = P + NN * RB;                      // p_ev per node            [NN][RB]
@@ -292,7 +293,10 @@ __device__ __forceinline__ void route_body(const mpnn_route_args &a, const int b
         if (a.node_stat) {                         // TALR: sum p_tr, sum p_tr^2
             const float pl = live ? ptr : 0.f;
             const float s1 = wave_sum_f(pl), s2 = wave_sum_f(pl * pl);
-            if (lane_t == 0) { atomicAdd(a.node_stat + j * 2, s1); atomicAdd(a.node_stat + j * 2 + 1, s2); }
+            if (lane_t == 0) {
+                if (det_stat) { a.stat_part[((size_t)blk * NN + j) * 2] = s1; a.stat_part[((size_t)blk * NN + j) * 2 + 1] = s2; }
+                else { atomicAdd(a.node_stat + j * 2, s1); atomicAdd(a.node_stat + j * 2 + 1, s2); }
+            }
         }
         if (dyn && sw >= 0 && ns >= 2) {
             const float p = ptr;
@@ -343,27 +347,53 @@ __device__ __forceinline__ void route_body(const mpnn_route_args &a, const int b
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < RT_WAVES; ++w) t += lsum[w * 4 + threadIdx.x];
-            atomicAdd(a.loss + threadIdx.x, t);
+            if (det_stat) ((double *)(a.stat_part + (size_t)nblk * NN * 2))[blk * 4 + threadIdx.x] = t;     // (summed below, in order)
+            else atomicAdd(a.loss + threadIdx.x, t);
+        }
+    }
+    if (det_stat) {
+        // the partial sums of all workgroups, added in workgroup order by whichever finishes last
+        int *last_s = (int *)lds + 128;                   // (dynamic LDS, behind the loss sums: the launch may use all 160 KB)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            *last_s = atomicAdd(a.stat_ticket, 1) == nblk - 1;
+        }
+        __syncthreads();
+        if (*last_s) {
+            __threadfence();
+            for (int i = threadIdx.x; i < 2 * NN; i += RT_THREADS) {
+                float t = 0.f;
+                for (int b = 0; b < nblk; ++b) t += __builtin_nontemporal_load(a.stat_part + (size_t)b * NN * 2 + i);
+                a.node_stat[i] += t;
+            }
+            if (a.loss && threadIdx.x < 4) {
+                const double *lp = (const double *)(a.stat_part + (size_t)nblk * NN * 2);
+                double t = 0.0;
+                for (int b = 0; b < nblk; ++b) t += __builtin_nontemporal_load(lp + b * 4 + threadIdx.x);
+                a.loss[threadIdx.x] += t;
+            }
+            if (threadIdx.x == 0) *a.stat_ticket = 0;
         }
     }
     trace_stamp(5);
 }
 
 template <int RB>
-__global__ __launch_bounds__(RT_THREADS) void route_k(const mpnn_route_args a) { route_body<RB>(a, blockIdx.x); }
+__global__ __launch_bounds__(RT_THREADS) void route_k(const mpnn_route_args a) { route_body<RB>(a, blockIdx.x, gridDim.x); }
 
 // Several nets of one tree shape in one launch (co-training, lib/_co.py): wpn workgroups per net, net r's record tab[r].
 template <int RB>
 __global__ __launch_bounds__(RT_THREADS) void route_multi_k(const mpnn_route_args *__restrict__ tab, const int wpn) {
     const int net = blockIdx.x / wpn;
     const mpnn_route_args a = tab[net];            // (by value: every field's scalar load in the entry block)
-    route_body<RB>(a, blockIdx.x - net * wpn);
+    route_body<RB>(a, blockIdx.x - net * wpn, wpn);
 }
 
 int mpnn_trace_install_route(void *buf) { return mpnn_trace_install(buf); }
 
 extern "C" int mpnn_route(const mpnn_route_args *args, void *stream) {
-    if (!args || !args->nodes || !args->p_tr || !args->p_ev) return MPNN_E_ARG;
+    if (!args || !args->nodes || !args->p_tr || !args->p_ev || (args->stat_part && !args->stat_ticket)) return MPNN_E_ARG;
     if (args->n_nodes > MPNN_MAX_NODES || args->max_sinks > MPNN_MAX_SINKS) return MPNN_E_SHAPE;
     if (args->n <= 0) return 0;
     const size_t per = (size_t)(4 * args->n_nodes + 2 * args->n_switches * args->max_sinks + args->n_switches + 2 * args->n_leaves) * 4;
@@ -394,7 +424,7 @@ extern "C" int mpnn_route_multi(const mpnn_route_args *host_table, const mpnn_ro
     const mpnn_route_args *args = host_table;
     for (int k = 0; k < count; ++k) {
         const mpnn_route_args &b = host_table[k];
-        if (!b.nodes || !b.p_tr || !b.p_ev) return MPNN_E_ARG;
+        if (!b.nodes || !b.p_tr || !b.p_ev || (b.stat_part && !b.stat_ticket)) return MPNN_E_ARG;
         if (b.n != args->n || b.n_nodes != args->n_nodes || b.n_switches != args->n_switches || b.n_leaves != args->n_leaves ||
             b.max_sinks != args->max_sinks) return MPNN_E_ARG;
     }

@@ -138,7 +138,7 @@ class RouteArgs(C.Structure):
                 ('max_sinks', C.c_int), ('optimistic', C.c_int), ('use_cls_err', C.c_int), ('want_grad', C.c_int),
                 ('nodes', P), ('sw_children', P), ('node_ops', P), ('hyp', P), ('k_cpt_vec', P), ('r', P),
                 ('c_err', P), ('d_cor', P), ('p_tr', P), ('p_ev', P), ('w_cerr', P), ('dr', P),
-                ('node_stat', P), ('loss', P), ('n', C.c_int), ('n_total', C.c_int)]
+                ('node_stat', P), ('loss', P), ('n', C.c_int), ('n_total', C.c_int), ('stat_part', P), ('stat_ticket', P)]
 
 
 class FinishNet(C.Structure):

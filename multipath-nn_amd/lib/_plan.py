@@ -1523,6 +1523,15 @@ class Engine:
         ra.r, ra.c_err, ra.d_cor = self.r.data_ptr(), self.c_err.data_ptr(), self.d_cor.data_ptr()
         ra.p_tr, ra.p_ev, ra.w_cerr, ra.dr = self.p_tr.data_ptr(), self.p_ev.data_ptr(), self.w_cerr.data_ptr(), self.dr.data_ptr()
         ra.node_stat = self.node_stat.data_ptr() if mode == 'tr' else None
+        if mode == 'tr':
+            # more than two workgroups (trees at 128 samples, chains beyond): per-workgroup partial sums + a last-arriver sum in
+            # workgroup order instead of fp32 atomics -- the TALR statistics are the same bits from run to run
+            need = (n + 15) // 16 * (len(self.nodes) * 2 + 8)          # (+ 4 doubles per workgroup: the loss sums)
+            if getattr(self, '_stat_part', None) is None or self._stat_part.numel() < need:
+                self._stat_part = torch.zeros(need, device=self.dev)
+                self._stat_ticket = torch.zeros(4, dtype=torch.int32, device=self.dev)
+            ra.stat_part, ra.stat_ticket = self._stat_part.data_ptr(), self._stat_ticket.data_ptr()
+            self._keep += [self._stat_part, self._stat_ticket]
         ra.loss = loss.data_ptr()
         ra.n, ra.n_total = n, n
         self._keep.append(ra)
