@@ -127,3 +127,122 @@ def test_long_lived_engine_equals_fresh_engines(kind, seed):
         for key in want:
             assert torch.equal(got[key], want[key]), (kind, seed, t, op, key, float((got[key].double() - want[key].double()).abs().max()))
         del fresh
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+_MORE = int(os.environ.get('MPNN_STATE_FUZZ_MORE', '0'))
+
+
+@pytest.mark.parametrize('seed', list(range(_MORE)) or [0, 1, 2])
+def test_long_lived_conv_engine_equals_fresh_engines(seed):
+    """The same for the single-scale Conv engine (lib/_plan_conv.py: capacity 128 at construction, reallocation beyond):
+    training steps at 3 ... 130 samples and evaluations at 7 ... 200 in a random order."""
+    from test_conv_layer import conv_net, pooled_conv_net
+    rng = np.random.default_rng(40 + seed)
+    mk = (conv_net(res=True), pooled_conv_net(), conv_net(res=False))[seed % 3]
+
+    def make():
+        net = mk((16, 16, 3), (10,))
+        net.engine().init_params(9)
+        return net
+
+    def apply(net, op, t):
+        what, n = op
+        g = np.random.default_rng(2000 + t)
+        x0 = g.random((n, 16, 16, 3)).astype(np.float32)
+        y = np.eye(10, dtype=np.float32)[g.integers(0, 10, n)]
+        if what == 'train':
+            net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.05, net.μ_lrn: 0.9})
+        else:
+            net.eval({net.x0: x0, net.y: y})
+
+    def results(net):
+        e = net.engine()
+        torch.cuda.synchronize()
+        out = {'P': e.P.clone(), 'A': e.A.clone()}
+        out.update({('state', k[1]): v.clone() for k, v in net.state().items()})
+        return out
+    ops = [(('train', int(rng.choice([3, 5, 24, 64, 130]))) if rng.random() < 0.6 else ('eval', int(rng.choice([7, 100, 200])))) for _ in range(8)]
+    long_lived = make()
+    for t, op in enumerate(ops):
+        e = long_lived.engine()
+        before = (e.P.clone(), e.A.clone())
+        apply(long_lived, op, t)
+        got = results(long_lived)
+        fresh = make()
+        fresh.engine().P.copy_(before[0]); fresh.engine().A.copy_(before[1])
+        apply(fresh, op, t)
+        want = results(fresh)
+        for key in want:
+            # 1x1 convolutions add their weight gradients with fp32 atomics (csrc/conv_nhwc.hip): the order of the addends varies
+            tol = 0.0 if op[0] == 'eval' else 2e-6
+            d = float((got[key].double() - want[key].double()).abs().max())
+            assert d <= tol * (1.0 + float(want[key].double().abs().max())), (seed, t, op, key, d)
+
+
+@pytest.mark.parametrize('seed', list(range(_MORE)) or [0, 1])
+def test_long_lived_cotrainer_equals_fresh_ones(seed):
+    """A co-trained group that lives through joint steps, SOLO steps of one member (its row of the joint schedule buffer is
+    rewritten), evaluations that reallocate a member's buffers (the joint program is rebuilt) and K-step graphs of a
+    member, against fresh groups loaded with the state before each operation: bit for bit."""
+    import arch_and_hypers as A
+    from lib._co import CoTrainer
+    rng = np.random.default_rng(70 + seed)
+    K, n = 3, (16, 16, 128, 37)[seed % 4]
+
+    def make():
+        nets = []
+        for i in range(K):
+            net = (A.ac_chain if seed % 2 == 0 else A.cr_chain)(k_cpt=A.k_cpts[i + 1])((32, 32, 3), (10,))
+            net.engine().init_params(30 + i)
+            perturb_routers(net, seed=8 + i)
+            nets.append(net)
+        return nets, CoTrainer(nets)
+
+    def feed(net, t, i):
+        x0, y = batch(n, seed=3000 + 10 * t + i)
+        return {net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.04 / (1 + t % 3), net.τ: 0.6 + 0.1 * i}
+
+    def apply(nets, co, op, t):
+        what, arg = op
+        if what == 'joint':
+            for rep in range(arg):
+                co.run([feed(net, t + rep, i) for i, net in enumerate(nets)])
+        elif what == 'solo':
+            nets[arg].train.run(feed(nets[arg], t, arg))
+        elif what == 'eval':
+            x0, y = batch(arg[1], seed=4000 + t)
+            nets[arg[0]].eval({nets[arg[0]].x0: x0, nets[arg[0]].y: y}, routed=bool(t % 2))
+        elif what == 'steps':
+            net = nets[arg]; e = net.engine()
+            x0, y = batch(n, seed=5000 + t)
+            e._ensure_capacity(n)
+            e.x0[:n].copy_(torch.from_numpy(x0)); e.y[:n].copy_(torch.from_numpy(y))
+            for rep in range(3):
+                net.train.run_steps([{net.x0: e.x0[:n], net.y: e.y[:n], net.mode: 'tr', net.λ_lrn: 0.02, net.τ: 0.9} for _ in range(2)])
+
+    def results(nets):
+        torch.cuda.synchronize()
+        out = {}
+        for i, net in enumerate(nets):
+            e = net.engine()
+            out.update({('P', i): e.P.clone(), ('A', i): e.A.clone(), ('S', i): e.S.clone()})
+        return out
+    ops = []
+    for _ in range(9):
+        u = rng.random()
+        ops.append(('joint', int(rng.choice([1, 3]))) if u < 0.5 else ('solo', int(rng.integers(0, K))) if u < 0.65 else
+                   ('eval', (int(rng.integers(0, K)), int(rng.choice([8, 300])))) if u < 0.85 else ('steps', int(rng.integers(0, K))))
+    ops.append(('joint', 2))
+    nets, co = make()
+    for t, op in enumerate(ops):
+        before = [_state(net) for net in nets]
+        apply(nets, co, op, t)
+        got = results(nets)
+        fnets, fco = make()
+        for net, st in zip(fnets, before):
+            _load(net, st)
+        apply(fnets, fco, op, t)
+        want = results(fnets)
+        for key in want:
+            assert torch.equal(got[key], want[key]), (seed, t, op, key, float((got[key].double() - want[key].double()).abs().max()))
