@@ -246,3 +246,57 @@ def test_long_lived_cotrainer_equals_fresh_ones(seed):
         want = results(fnets)
         for key in want:
             assert torch.equal(got[key], want[key]), (seed, t, op, key, float((got[key].double() - want[key].double()).abs().max()))
+
+
+@pytest.mark.parametrize('seed', list(range(_MORE)) or [0, 1, 2])
+def test_bound_input_pipeline_through_a_random_sequence(seed):
+    """Dataset.bind_engine under a random mix of single steps, K-step graphs (record slots 0 .. K-1, one upload), private
+    draw streams (DrawStream) and evaluations that reallocate the engine's input buffers: after every call the engine's
+    input buffers hold exactly the batch the reference's draw sequence assigns to the LAST step of that call."""
+    import arch_and_hypers as A
+    from lib.data import Dataset, DrawStream
+    rng = np.random.default_rng(90 + seed)
+    n = int(rng.choice([16, 32]))
+    ds = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+    ref = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+    ds.m_sym = ref.m_sym = np.array([1, 0, 1, 1, 0, 0, 1, 0, 1, 1], bool)
+    net = (A.ac_chain(k_cpt=1e-9), A.sr_chain(3), A.cr_chain(k_cpt=4e-9))[seed % 3]((32, 32, 3), (10,))
+    eng = net.engine()
+    eng.init_params(3)
+    if net._net_kind != 'sr':
+        perturb_routers(net, seed=2)
+    ds.to_device('cuda:0')
+    x0, y = ds.bind_engine(eng, n)
+    private = bool(seed % 2)                             # the engine's batches from a private copy of the stream
+    stream = DrawStream(123 + seed) if private else None
+    ops, total = [], 0
+    for _ in range(10):
+        u = rng.random()
+        if u < 0.45:
+            ops.append(('one', 1)); total += 1
+        elif u < 0.8:
+            k = int(rng.integers(2, 5)); ops.append(('k', k)); total += k
+        else:
+            ops.append(('eval', int(rng.choice([8, 200, 400]))))
+    np.random.seed(123 + seed)
+    want = [ref.augmented_training_batch(n) for _ in range(total)]
+    np.random.seed(123 + seed)
+    τ = {} if net._net_kind == 'sr' else {net.τ: 0.8}
+    done = 0
+    for t, (what, arg) in enumerate(ops):
+        if what == 'eval':
+            xb, yb = batch(arg, seed=t)
+            net.eval({net.x0: xb, net.y: yb})
+            continue
+        if what == 'one' and not private:
+            ds.stage_training_draws(n, eng=eng)
+            net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.01, **τ})
+        else:
+            ds.stage_training_draws_k(arg, n, eng=eng, stream=stream)
+            net.train.run_steps([{net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.01, **τ} for _ in range(arg)])
+        done += arg
+        torch.cuda.synchronize()
+        wx, wy = want[done - 1]
+        assert np.abs(eng.x0[:n].cpu().numpy() - wx).max() <= 1e-6, (seed, t, what, arg)
+        assert np.array_equal(eng.y[:n].cpu().numpy(), wy), (seed, t, what, arg)
+    assert bool(torch.isfinite(eng.P).all())
