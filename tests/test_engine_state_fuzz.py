@@ -300,3 +300,65 @@ def test_bound_input_pipeline_through_a_random_sequence(seed):
         assert np.abs(eng.x0[:n].cpu().numpy() - wx).max() <= 1e-6, (seed, t, what, arg)
         assert np.array_equal(eng.y[:n].cpu().numpy(), wy), (seed, t, what, arg)
     assert bool(torch.isfinite(eng.P).all())
+
+
+@pytest.mark.parametrize('seed', list(range(_MORE)) or [0, 1])
+def test_long_lived_groups_on_streams_equal_fresh_ones(seed):
+    """CoGroups (groups side by side on streams) through free-running rounds, joins, evaluations on the caller's stream
+    that reallocate a member's buffers, solo steps of a member and more rounds -- against fresh groups loaded with the
+    state before each operation.  A missing fork / join, or a buffer freed under a running group, shows as a mismatch."""
+    import arch_and_hypers as A
+    from lib._co import CoGroups
+    rng = np.random.default_rng(110 + seed)
+    n = (16, 32)[seed % 2]
+
+    def make():
+        nets = [A.ac_chain(k_cpt=A.k_cpts[i])((32, 32, 3), (10,)) for i in range(4)] + [A.sr_chain(2 + seed % 3)((32, 32, 3), (10,))]
+        for i, net in enumerate(nets):
+            net.engine().init_params(50 + i)
+            if net._net_kind != 'sr':
+                perturb_routers(net, seed=4 + i)
+        return nets, CoGroups.plan(nets, streams=(2, 4)[seed % 2])
+
+    def feeds(nets, t):
+        out = []
+        for i, net in enumerate(nets):
+            x0, y = batch(n, seed=6000 + 10 * t + i)
+            out.append({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.03, **({net.τ: 0.7} if net._net_kind != 'sr' else {})})
+        return out
+
+    def apply(nets, cg, op, t):
+        what, arg = op
+        if what == 'rounds':
+            for r in range(arg):
+                cg.run(feeds(nets, t + r))
+            cg.join()
+        elif what == 'eval':
+            x0, y = batch(arg[1], seed=7000 + t)
+            nets[arg[0]].eval({nets[arg[0]].x0: x0, nets[arg[0]].y: y})
+        elif what == 'solo':
+            f = feeds(nets, t)[arg]
+            nets[arg].train.run(f)
+
+    ops = [('rounds', 2)]
+    for _ in range(6):
+        u = rng.random()
+        ops.append(('rounds', int(rng.choice([1, 3]))) if u < 0.5 else ('eval', (int(rng.integers(0, 5)), int(rng.choice([8, 200])))) if u < 0.8
+                   else ('solo', int(rng.integers(0, 5))))
+    ops.append(('rounds', 2))
+    nets, cg = make()
+    for t, op in enumerate(ops):
+        torch.cuda.synchronize()
+        before = [_state(net) for net in nets]
+        apply(nets, cg, op, t)
+        torch.cuda.synchronize()
+        got = [_state(net) for net in nets]
+        fnets, fcg = make()
+        for net, st in zip(fnets, before):
+            _load(net, st)
+        apply(fnets, fcg, op, t)
+        torch.cuda.synchronize()
+        want = [_state(net) for net in fnets]
+        for i, (g, w) in enumerate(zip(got, want)):
+            for name, a, b in zip('PAS', g, w):
+                assert torch.equal(a, b), (seed, t, op, i, name, float((a.double() - b.double()).abs().max()))
