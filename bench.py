@@ -304,6 +304,13 @@ def main():
         # and exits with their code.
         return spawn_ranks(args.gpus)
 
+    # stdout carries ONE line, the JSON record: everything else this process (or a library under it: RCCL prints a version
+    # banner through C stdio) writes to file descriptor 1 goes to stderr instead; the record is written to the real
+    # stdout at the very end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch.distributed as dist
     import arch_and_hypers as A
     from lib import _dp
@@ -585,7 +592,8 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1:
         dist.destroy_process_group()
 
