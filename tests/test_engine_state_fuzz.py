@@ -92,11 +92,11 @@ def _draw_ops(rng, kind, count):
     for _ in range(count):
         u = rng.random()
         if u < 0.4:
-            ops.append(('train', int(rng.choice([3, 16, 37, 128])), int(rng.choice([1, 1, 3]))))
+            ops.append(('train', int(rng.choice([3, 16, 37, 128, 128, 200] if kind != 'tree' else [3, 16, 37, 128])), int(rng.choice([1, 1, 3]))))
         elif u < 0.5 and kind != 'tree':
             ops.append(('steps', int(rng.choice([16, 128])), int(rng.choice([2, 3]))))
         elif u < 0.9:
-            n = int(rng.choice([5, 64, 200, 600]))
+            n = int(rng.choice([5, 64, 200, 600, 1500] if kind != 'tree' else [5, 64, 200, 600]))
             routed = False if kind == 'sr' else [False, True, 1, 2, 4, 'auto'][int(rng.integers(0, 6))]
             ops.append(('eval', n, routed))
         else:
