@@ -991,7 +991,7 @@ class Engine:
         t_tf, t_tb = _hip.to_device_table(tail_f, self.dev), _hip.to_device_table(tail_b, self.dev)
         keep += [t_lf, t_lb, t_tf, t_tb]
         if n_exit and self.generic_exits:
-            fwd.append(call(lib.mpnn_lin_fwd_gen, 'lin_fwd', t_lf.data_ptr(), n_exit, n))
+            fwd.append(call(lib.mpnn_lin_fwd_gen, 'lin_fwd', t_lf.data_ptr(), n_exit, n, host=lin_f))
             fwd.append(call(lib.mpnn_exit_tail_fwd_gen, 'exit_tail_fwd', t_tf.data_ptr(), n_exit, n, host=tail_f))
         elif n_exit:
             if n <= 512:
@@ -1018,7 +1018,7 @@ class Engine:
         level_fix = []
         if n_exit and self.generic_exits:
             bwd.append(call(lib.mpnn_exit_tail_bwd_gen, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n))
-            bwd.append(call(lib.mpnn_lin_bwd_gen, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax))
+            bwd.append(call(lib.mpnn_lin_bwd_gen, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax, host=lin_b))
         elif n_exit:
             bwd.append(call(lib.mpnn_exit_tail_bwd_gen if big_tails else lib.mpnn_exit_tail_bwd, 'exit_tail_bwd', t_tb.data_ptr(), n_exit, n, host=tail_b))
             bwd.append(call(lib.mpnn_lin_bwd_rs if n <= 512 else lib.mpnn_lin_bwd, 'lin_bwd', t_lb.data_ptr(), n_exit, n, kmax, host=lin_b))
@@ -1844,10 +1844,11 @@ class Engine:
         mpnn_exit_tail_fwd (mpnn_exit_tail_args.hyp_src: no launch of its own); with the input pipeline bound
         (Dataset.bind_engine) launch 0 of step j gathers the batch staged in record slot j.  Without it every feed
         must name the engine's resident input buffers (the same batch K times: the benchmark).  Falls back to K
-        single-step calls where the one-graph form does not apply (data parallel, eager, per-sample k_cpt)."""
+        single-step calls where the one-graph form does not apply (data parallel, eager).  Per-sample k_cpt vectors
+        (dyn_k_cpt nets) ride in a device ring like the schedule values; the launches that read them get per-step records."""
         net, K = self.net, len(feeds)
-        ok = (1 < K <= self.STEPS_MAX and self.use_graph and self.allreduce is None and not self.multi_stream
-              and not getattr(net.hypers, 'dyn_k_cpt', False))
+        dyn = bool(getattr(net.hypers, 'dyn_k_cpt', False))
+        ok = 1 < K <= self.STEPS_MAX and self.use_graph and self.allreduce is None and not self.multi_stream
         if ok:
             xs = [f[net.x0] for f in feeds]
             bound = all(isinstance(x, BoundInput) for x in xs)
@@ -1887,7 +1888,43 @@ class Engine:
             self._hypk = torch.zeros(self.STEPS_MAX, _hip.HYP_N, device=self.dev)
             self._hypk_ring = [(torch.zeros(self.STEPS_MAX, _hip.HYP_N).pin_memory(), None) for _ in range(8)]
             self._hypk_slot = -1
-        hs = torch.stack([self._hyp_values(f, n).clone() for f in feeds])
+        if dyn:
+            # per-sample k_cpt (net_types.py:149-160): step j's vector in slot j of a device ring; the K vectors travel in one
+            # upload, and the launches that read them (mpnn_lin_fwd / _bwd: the k_cpt column; mpnn_route) get per-step records
+            if getattr(self, '_kck', None) is None or self._kck.shape[1] < self.n_max:
+                self._kck = torch.zeros(self.STEPS_MAX, self.n_max, device=self.dev)
+                self._kck_ring = [(torch.zeros(self.STEPS_MAX, self.n_max).pin_memory(), None) for _ in range(8)]
+                self._kck_slot = -1
+                self._graphs = {k: v for k, v in self._graphs.items() if k[0] != 'trK'}
+                g = self._graphs.get(key)
+                if g is None:
+                    one_by_one()
+                    self._graphs[key] = 'warm'
+                    return
+            r = self._kck_slot = (self._kck_slot + 1) % len(self._kck_ring)
+            kbuf, kev = self._kck_ring[r]
+            if kev is not None:
+                kev.synchronize()
+            stage, on_dev = [], {}
+            for j, f in enumerate(feeds):
+                def put_k(dst, src, j=j):
+                    if isinstance(src, torch.Tensor) and src.is_cuda:
+                        on_dev[j] = src                     # (already on the device: copied there, no host round trip)
+                    else:
+                        src = src if isinstance(src, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32))
+                        kbuf[j, :n].copy_(src.reshape(-1))
+                stage.append(self._hyp_values(f, n, put_k).clone())
+            hs = torch.stack(stage)
+            if not on_dev:
+                self._kck[:K, :n].copy_(kbuf[:K, :n], non_blocking=True)
+            else:
+                for j in range(K):
+                    self._kck[j, :n].copy_(on_dev[j].reshape(-1) if j in on_dev else kbuf[j, :n], non_blocking=True)
+            kev = torch.cuda.Event()
+            kev.record(torch.cuda.current_stream())
+            self._kck_ring[r] = (kbuf, kev)
+        else:
+            hs = torch.stack([self._hyp_values(f, n).clone() for f in feeds])
         if getattr(self, '_hypk_sent', None) is None or self._hypk_sent.shape != hs.shape or not torch.equal(hs, self._hypk_sent):
             r = self._hypk_slot = (self._hypk_slot + 1) % len(self._hypk_ring)
             buf, ev = self._hypk_ring[r]
@@ -1923,6 +1960,26 @@ class Engine:
                     recs.append(c)
                 tabs.append(_hip.to_device_table(recs, self.dev))
             self._keep += tabs
+            ktabs = {}                       # (step, launch) -> the launch's records with step j's k_cpt vector
+            if dyn:
+                for j in range(K):
+                    kp = self._kck[j].data_ptr()
+                    for op in ops:
+                        if op.what in ('lin_fwd', 'lin_bwd') and getattr(op, 'host', None):
+                            recs = []
+                            for rec in op.host:
+                                c = type(rec)()
+                                C.memmove(C.byref(c), C.byref(rec), C.sizeof(rec))
+                                if c.k_cpt:
+                                    c.k_cpt = kp
+                                recs.append(c)
+                            ktabs[(j, id(op))] = _hip.to_device_table(recs, self.dev)
+                        elif op.what == 'route':
+                            c = type(op.host)()
+                            C.memmove(C.byref(c), C.byref(op.host), C.sizeof(op.host))
+                            c.k_cpt_vec = kp
+                            ktabs[(j, id(op))] = c
+                self._keep += list(ktabs.values())
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                 st = torch.cuda.current_stream().cuda_stream
@@ -1932,6 +1989,10 @@ class Engine:
                     for op in ops:
                         if op.what == 'exit_tail_fwd':
                             _hip.check(op.fn(tabs[j].data_ptr(), *op.args[1:], st), 'exit_tail_fwd')
+                        elif (j, id(op)) in ktabs and op.what == 'route':
+                            _hip.check(op.fn(C.byref(ktabs[(j, id(op))]), st), 'route')
+                        elif (j, id(op)) in ktabs:
+                            _hip.check(op.fn(ktabs[(j, id(op))].data_ptr(), *op.args[1:], st), op.what)
                         else:
                             op(st)
             self._graphs[key] = g

@@ -215,9 +215,10 @@ class Dataset:
         b['ring'][k] = (buf, ev)
         return b['dev'][slot]
 
-    def stage_training_draws_k(self, K, n=128, r_shift=4, eng=None, stream=None):
+    def stage_training_draws_k(self, K, n=128, r_shift=4, eng=None, stream=None, between=None):
         """stage_training_draws for the K steps of one K-step graph replay (record slots 0 .. K-1, drawn in step order from
-        the one numpy stream) with ONE upload: a small copy on the compute stream in front of a replay costs ~8 us."""
+        the one numpy stream) with ONE upload: a small copy on the compute stream in front of a replay costs ~8 us.
+        between(j) runs right after step j's draws (the caller's own per-iteration draws keep their place in the stream)."""
         import torch
         b = self._draw_buffers(n, None if eng is None else id(eng))
         if K > self.SLOTS:
@@ -229,7 +230,7 @@ class Dataset:
         if ev is not None:
             ev.synchronize()
         out = buf.numpy()
-        if stream is not None and out.shape[1] == n:
+        if stream is not None and out.shape[1] == n and between is None:
             stream.draw(n, len(self.x0_tr), self._sym_u8, r_shift, out=out[:K], batches=K)
         else:
             for j in range(K):
@@ -237,6 +238,8 @@ class Dataset:
                     stream.draw(n, len(self.x0_tr), self._sym_u8, r_shift, out=out[j, :n])
                 else:
                     _draw_augmentation_fast(n, len(self.x0_tr), self._sym_u8, r_shift, out=out[j, :n], all_sym=self._all_sym)
+                if between is not None:
+                    between(j)             # (whatever else the loop draws per iteration, in the loop's order: train-adaptive-nets' k_cpt choice)
         b['dev'][:K, :n].copy_(buf[:K, :n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())

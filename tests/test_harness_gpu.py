@@ -284,3 +284,37 @@ def test_bound_input_pipeline_feeds_every_step_in_every_graph_form(form):
     assert all(np.abs(a - b).max() > 0 for a, b in zip(seen, seen[1:]))
     if form == 'sections':
         assert len(calls) >= 6 and eng._graphs and all(v[1] != 'whole' for v in eng._graphs.values() if isinstance(v, tuple))
+
+
+def test_adaptive_loop_draws_in_the_reference_order():
+    """train-adaptive-nets with several iterations per hipGraph replay: per iteration the reference draws the batch's
+    augmentation records and THEN rand.choice(k_cpts, batch) (scripts/train-adaptive-nets:24-27,93-97).  Staging K
+    iterations at once keeps that order (stage_training_draws_k(between=...)): records and k_cpt vectors equal the
+    per-iteration loop's on the same seed, and so does the stream position afterwards."""
+    import arch_and_hypers as A
+    from lib import data as D
+    ds = D.Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+    ds.m_sym = np.array([1, 0, 1, 1, 0, 0, 1, 0, 1, 1], bool)
+    ds.to_device('cuda:0')
+    n, K = 24, 4
+    np.random.seed(5)
+    want = []
+    for t in range(2 * K):
+        j, flip, sh = D._draw_augmentation(n, 300, ds.y_tr, ds.m_sym, 4)
+        want.append((j, flip, sh, np.random.choice(A.k_cpts, n)))
+    tail = np.random.randint(0, 2 ** 32, 8, dtype=np.uint32)
+    np.random.seed(5)
+    got_k = []
+    for call in range(2):
+        ks = [None] * K
+
+        def between(jj):
+            ks[jj] = np.random.choice(A.k_cpts, n)
+        ds.stage_training_draws_k(K, n, between=between)
+        torch.cuda.synchronize()
+        rec = ds._draw_buffers(n)['dev'][:K, :n].cpu().numpy()
+        for jj in range(K):
+            j, flip, sh, kc = want[call * K + jj]
+            assert np.array_equal(rec[jj][:, 0], j) and np.array_equal(rec[jj][:, 1].astype(bool), flip) and np.array_equal(rec[jj][:, 2:], sh)
+            assert np.array_equal(ks[jj], kc)
+    assert np.array_equal(np.random.randint(0, 2 ** 32, 8, dtype=np.uint32), tail)

@@ -192,21 +192,26 @@ def test_backward_dependency_levels():
     assert float((out[0] - out[1]).abs().max()) <= 2e-6 * float(out[1].abs().max())
 
 
-@pytest.mark.parametrize('kind', ['ac', 'cr', 'sr'])
+@pytest.mark.parametrize('kind', ['ac', 'cr', 'sr', 'dyn', 'dyn_dev', 'dyn_cr_wide'])
 def test_k_steps_in_one_graph_equal_k_single_steps(kind):
     """Engine.run_steps: K training steps as ONE hipGraph replay -- the schedule values of step j (learning rate,
     temperature: different in every step here) reach the step through the device ring and the head workgroup of its
     mpnn_exit_tail_fwd -- against K single-step replays from the same state: the same launches on the same data, so the
-    parameters agree to the last bits of the fp64-atomic statistics (1e-6), call after call (warm-up, capture, replays)."""
+    parameters agree to the last bits of the fp64-atomic statistics (1e-6), call after call (warm-up, capture, replays).
+    dyn*: per-sample k_cpt vectors (dyn_k_cpt nets, train-adaptive-nets), a different one in every step -- from the host
+    (dyn), as device tensors (dyn_dev), and on the any-width exit kernels (dyn_cr_wide: 20 classes)."""
     import arch_and_hypers as A
-    mk = {'ac': lambda: A.ac_chain(k_cpt=1.6e-8, seed=7), 'cr': lambda: A.cr_chain(k_cpt=8e-9, seed=7), 'sr': lambda: A.sr_chain(8)}[kind]
-    nets = [mk()((32, 32, 3), (10,)) for _ in range(2)]
+    mk = {'ac': lambda: A.ac_chain(k_cpt=1.6e-8, seed=7), 'cr': lambda: A.cr_chain(k_cpt=8e-9, seed=7), 'sr': lambda: A.sr_chain(8),
+          'dyn': lambda: A.ac_chain(dyn_k_cpt=True, seed=7), 'dyn_dev': lambda: A.ac_chain(dyn_k_cpt=True, seed=7),
+          'dyn_cr_wide': lambda: A.cr_chain(dyn_k_cpt=True, seed=7)}[kind]
+    n_cls = 20 if kind == 'dyn_cr_wide' else 10
+    nets = [mk()((32, 32, 3), (n_cls,)) for _ in range(2)]
     for net in nets:
         net.engine().init_params(77)
     n, K = 32, 4
     rng = np.random.default_rng(3)
     x0 = torch.from_numpy(rng.random((n, 32, 32, 3)).astype(np.float32)).cuda()
-    y = torch.from_numpy(np.eye(10, dtype=np.float32)[rng.integers(0, 10, n)]).cuda()
+    y = torch.from_numpy(np.eye(n_cls, dtype=np.float32)[rng.integers(0, n_cls, n)]).cuda()
     engs = [net.engine() for net in nets]
     for e in engs:
         e._ensure_capacity(n)
@@ -217,6 +222,9 @@ def test_k_steps_in_one_graph_equal_k_single_steps(kind):
         f = {net.x0: e.x0[:n], net.y: e.y[:n], net.mode: 'tr', net.λ_lrn: 0.05 / (1 + 0.3 * t)}
         if kind != 'sr':
             f[net.τ] = 1.0 / (1 + 0.1 * t)
+        if kind.startswith('dyn'):
+            kv = np.random.default_rng(100 + t).choice(A.k_cpts, n).astype(np.float32)
+            f[net.k_cpt] = torch.from_numpy(kv).cuda() if kind == 'dyn_dev' else kv
         return f
     a, b = nets
     rel = lambda u, v: float((u - v).abs().max() / v.abs().max())
