@@ -189,8 +189,9 @@ def measure_corunner(single_ms, n, k=16, T=40.0):
 
 
 def time_configs(dev, n, reps=200):
-    """SURVEY 8(d)'s other timing configurations, full training steps at batch n (one hipGraph per step),
-    `reps` replays each after 5 warm-up steps: img/s and ms/step.  The headline stays cifar10-ac k_cpt=0."""
+    """SURVEY 8(d)'s other timing configurations, full training steps at batch n (four steps per hipGraph replay, like the
+    headline; the per-sample k_cpt vector of the adaptive net fed with every step), `reps` steps each after 12 warm-up steps:
+    img/s and ms/step.  The headline stays cifar10-ac k_cpt=0."""
     import arch_and_hypers as A
     kv = torch.from_numpy(np.random.default_rng(0).choice(A.k_cpts, n).astype(np.float32)).to(dev)
     table = [
@@ -212,11 +213,11 @@ def time_configs(dev, n, reps=200):
             eng.y[:n].copy_(torch.nn.functional.one_hot(torch.randint(0, 10, (n,), generator=g), 10).float().to(dev))
             feed = {net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr', net.λ_lrn: A.λ_lrn(0)}
             feed.update(extra(net))
-            for _ in range(5):
-                net.train.run(feed)
+            for _ in range(3):
+                net.train.run_steps([feed] * 4)         # (four steps per hipGraph replay, as the headline)
             torch.cuda.synchronize()
-            ms = time_replays(lambda: net.train.run(feed), reps)
-            out[name] = {'images_per_s': n / (ms * 1e-3), 'ms_per_step': ms}
+            ms = time_replays(lambda: net.train.run_steps([feed] * 4), max(1, reps // 4), chunk=5) / 4
+            out[name] = {'images_per_s': n / (ms * 1e-3), 'ms_per_step': ms, 'steps_per_graph': 4}
             del net, eng
         except Exception as e:                      # a config that cannot run must not take the headline down
             out[name] = {'error': repr(e)}
