@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 def _make(kind):
     import arch_and_hypers as A
     mk = {'ac': lambda: A.ac_chain(k_cpt=1.6e-8), 'cr': lambda: A.cr_chain(k_cpt=4e-9, optimistic=True),
-          'sr': lambda: A.sr_chain(5), 'tree': lambda: A.ac_tree(k_cpt=1e-9)}[kind]()
+          'sr': lambda: A.sr_chain(5), 'tree': lambda: A.ac_tree(k_cpt=1e-9), 'dyn': lambda: A.cr_chain(dyn_k_cpt=True)}[kind]()
     net = mk((32, 32, 3), (10,))
     net.engine().init_params(77)
     if net._net_kind != 'sr':
@@ -67,6 +67,13 @@ def _apply(net, op, t):
     what, n, arg = op
     x0, y = batch(n, seed=1000 + 17 * t)
     τ = {} if net._net_kind == 'sr' else {net.τ: 0.7 + 0.05 * (t % 5)}
+    if getattr(net.hypers, 'dyn_k_cpt', False):           # per-sample k_cpt: a vector with every feed
+        import arch_and_hypers as A
+        kvec = lambda j: np.random.default_rng(31 * t + j).choice(A.k_cpts, n).astype(np.float32)
+    else:
+        kvec = None
+    if kvec is not None and what != 'steps':
+        τ[net.k_cpt] = kvec(0)
     if what == 'train':
         for rep in range(arg):                        # (1: whatever comes next of eager / capture / replay; 3: all of them)
             net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.03 / (1 + rep), **τ})
@@ -76,10 +83,11 @@ def _apply(net, op, t):
         e._ensure_capacity(n)
         e.x0[:n].copy_(torch.from_numpy(x0)); e.y[:n].copy_(torch.from_numpy(y))
         for rep in range(3):                          # warm, capture, replay of the K-step graph
-            net.train.run_steps([{net.x0: e.x0[:n], net.y: e.y[:n], net.mode: 'tr', net.λ_lrn: 0.02 / (1 + j), **τ} for j in range(arg)])
+            net.train.run_steps([{net.x0: e.x0[:n], net.y: e.y[:n], net.mode: 'tr', net.λ_lrn: 0.02 / (1 + j), **τ,
+                                  **({net.k_cpt: kvec(j)} if kvec is not None else {})} for j in range(arg)])
         return True
     if what == 'eval':
-        net.eval({net.x0: x0, net.y: y}, routed=arg)
+        net.eval({net.x0: x0, net.y: y, **({net.k_cpt: kvec(0)} if kvec is not None else {})}, routed=arg)
         return False
     if what == 'fwd_tr':                              # a fetch in mode 'tr' without the train op (moves the moving averages)
         net.eval({net.x0: x0, net.y: y, net.mode: 'tr', **τ})
@@ -105,10 +113,10 @@ def _draw_ops(rng, kind, count):
 
 
 import os
-_CASES = [('ac', 0), ('ac', 1), ('cr', 2), ('sr', 3), ('tree', 4), ('cr', 5), ('ac', 6), ('tree', 7)]
+_CASES = [('ac', 0), ('ac', 1), ('cr', 2), ('sr', 3), ('tree', 4), ('cr', 5), ('ac', 6), ('tree', 7), ('dyn', 8), ('dyn', 9)]
 if os.environ.get('MPNN_STATE_FUZZ_SEEDS'):           # (a longer hunt: MPNN_STATE_FUZZ_SEEDS="100 140" -> seeds 100 .. 139)
     lo, hi = (int(v) for v in os.environ['MPNN_STATE_FUZZ_SEEDS'].split())
-    _CASES = [(('ac', 'cr', 'sr', 'tree')[s % 4], s) for s in range(lo, hi)]
+    _CASES = [(('ac', 'cr', 'sr', 'tree', 'dyn')[s % 5], s) for s in range(lo, hi)]
 
 
 @pytest.mark.parametrize('kind,seed', _CASES)
