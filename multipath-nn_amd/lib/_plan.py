@@ -1297,6 +1297,12 @@ class Engine:
         return prog
 
     # ------------------------------------------------------------------ evaluation programs
+    def _depths(self):
+        depth = {}
+        for b in self.blocks:
+            depth[id(b)] = 0 if b.parent is None else depth[id(b.parent)] + 1
+        return depth
+
     def _groupable(self):
         return all(c % 16 == 0 and not (c % 64 == 0 and h >= 16) for b in self.blocks for c, h in zip(b.C, b.H))
 
@@ -1320,8 +1326,12 @@ class Engine:
         ϕ = net.hypers
         act_mode = _hip.ACT_BN_MOVING
         fwd = []
-        if not self._groupable():
-            raise NotImplementedError('evaluation programs need 16-channel-tile geometries')
+        # A geometry the group launch has no body for (64+ channels on 16x16 / 32x32 maps: no shipped spec has one): every
+        # conv as its own mpnn_msconv_fwd launch.  That entry point takes no sample lists, so a ROUTED pass of such a net
+        # runs every conv densely (d0 beyond the deepest block) and is made routed by mpnn_ev_prefix_walk alone.
+        singles = not self._groupable()
+        if singles and routed:
+            routed = 1 + max(self._depths().values())
 
         def call(fn, what, *args, flops=0.0, tag=''):
             def launch(st):
@@ -1387,6 +1397,13 @@ class Engine:
         tag_f = lambda b, i: 'h%d %d+%d->%d' % (b.H[i], b.Cin[i], b.C[i - 1] if i > 0 else 0, b.C[i])
 
         def group_launches(members):
+            if singles:
+                for b, i in members:
+                    a = _hip.ConvFwdArgs()
+                    fwd_args(b, i, a)
+                    keep.append(a)
+                    fwd.append(call(lib.mpnn_msconv_fwd, 'fwd', C.byref(a), flops=fl_f(b, i), tag=tag_f(b, i)))
+                return
             for c0 in range(0, len(members), 4):
                 grp = members[c0:c0 + 4]
                 arr = (_hip.ConvFwdArgs * len(grp))()
