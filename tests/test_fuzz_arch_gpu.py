@@ -57,20 +57,21 @@ def test_random_architectures(seed):
     kind = (ActorNet, CriticNet, SRNet)[int(rng.integers(0, 3))]
     c0 = int(rng.choice([3, 3, 1]))
     n = int(rng.choice([6, 16, 40, 128]))
+    hw = int(os.environ.get('MPNN_FUZZ_ARCH_HW', '32'))
     hyp = {} if kind is SRNet else dict(k_cpt=float(rng.choice([0.0, 4e-9])))
     print('seed %d: %s, arch %s, %d input channels, batch %d' % (seed, kind.__name__, arch, c0, n))
     mk = make_chain(kind, arch, len(arch[0]), **hyp)
     feeds = (lambda net, t: {}) if kind is SRNet else (lambda net, t: {net.τ: 0.7})
     try:
-        run_case(mk, n, feeds, steps=2, c0=c0)
+        run_case(mk, n, feeds, steps=2, c0=c0, hw=hw)
     except NotImplementedError as e:
         pytest.skip('refused loudly: %s' % e)
     if kind is SRNet:
         return
-    net = mk((32, 32, c0), (10,))
+    net = mk((hw, hw, c0), (10,))
     net.engine().init_params(5)
     perturb_routers(net)
-    x0, y = batch(200, c0, 10, seed=seed)
+    x0, y = batch(200, c0, 10, seed=seed, hw=hw)
     net.eval({net.x0: x0, net.y: y})
     dense = [ℓ.p_ev.clone() for ℓ in net.layers]
     ce = [ℓ.c_err.clone() for ℓ in net.leaves]

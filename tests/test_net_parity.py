@@ -24,9 +24,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def batch(n, c0=3, n_cls=10, seed=0):
+def batch(n, c0=3, n_cls=10, seed=0, hw=32):
     rng = np.random.default_rng(seed)
-    x0 = rng.random((n, 32, 32, c0)).astype(np.float32)
+    x0 = rng.random((n, hw, hw, c0)).astype(np.float32)
     y = np.eye(n_cls, dtype=np.float32)[rng.integers(0, n_cls, n)]
     return x0, y
 
@@ -74,14 +74,14 @@ def rel(a, b):
     return np.abs(a - b).max() / (1e-12 + np.abs(b).max())
 
 
-def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL, n_cls=10, stepper=None):
+def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL, n_cls=10, stepper=None, hw=32):
     """Teacher-forced: before every step the oracle is re-synchronised from the product's
     parameters, momentum accumulators and BatchNorm state, so each step checks one
     forward + backward + TALR/momentum update from IDENTICAL state.  (A free-running
     comparison is meaningless: the float64 oracle alone turns a 1e-5 relative weight
     perturbation into a 7-50 % gradient change through max-pool / ReLU flips.)"""
     from oracle.ref_net import RefNet
-    net = make_net((32, 32, c0), (n_cls,))
+    net = make_net((hw, hw, c0), (n_cls,))
     eng = net.engine()
     eng.init_params(1234)
     if net._net_kind != 'sr':
@@ -94,7 +94,7 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL, n_cls=1
     worst = {'grad': 0.0, 'update': 0.0}
     flips_total = decisions_total = 0
     for t in range(steps):
-        x0, y = batch(n, c0, n_cls, seed=t)
+        x0, y = batch(n, c0, n_cls, seed=t, hw=hw)
         feed = {net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: lr, **feeds(net, t)}
         kw = {}
         if net._net_kind != 'sr':
@@ -163,7 +163,7 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL, n_cls=1
           'decisions that differ from the free float64 run: %d of %d (%.1e)'
           % (steps, worst['grad'], worst['update'], tol, flips_total, decisions_total, flips_total / max(1, decisions_total)))
     # evaluation pass: moving-average BatchNorm, hard routing, statistics
-    x0, y = batch(n, c0, n_cls, seed=99)
+    x0, y = batch(n, c0, n_cls, seed=99, hw=hw)
     feed = {net.x0: x0, net.y: y, **{k: v for k, v in feeds(net, 0).items()}}
     kw = {}
     if k_cpt_vec is not None:
