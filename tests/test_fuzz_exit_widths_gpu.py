@@ -12,7 +12,7 @@ from test_net_parity import _wide_chain, batch, perturb_routers, run_case
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = [int(s) for s in os.environ.get('MPNN_FUZZ_WIDTH_SEEDS', '0 1 2 3 4 5 6 7').split()]
+SEEDS = [int(s) for s in os.environ.get('MPNN_FUZZ_WIDTH_SEEDS', '0 1 2 3 4 5').split()]
 WIDTHS = [1, 2, 3, 7, 8, 13, 16, 17, 24, 31, 32, 33, 48, 64, 100, 127, 128, 200, 256]
 CLASSES = [2, 3, 5, 10, 11, 16, 17, 37, 100, 257, 1000]
 BATCHES = [5, 9, 16, 33, 64, 127, 128, 129, 200]          # (two-sample BatchNorm statistics amplify fp32 rounding beyond the 1e-4 gate)
