@@ -1505,9 +1505,10 @@ class Engine:
                         pa.front_parent[f], pa.front_sink[f] = rec_of[id(src[0])], src[1]
                         pa.front_idx[f], pa.front_cnt[f] = b.ev_idx.data_ptr(), b.ev_cnt.data_ptr()
                         pa.n_front = f + 1
-                dev_pa = _hip.to_device_table([pa], self.dev)
-                keep.extend([pa, dev_pa])
-                fwd.append(call(lib.mpnn_ev_prefix_walk, 'ev_prefix_walk', C.byref(pa), dev_pa.data_ptr()))
+                if pa.count > 0:                   # (a prefix of static blocks only has no exit to make routed)
+                    dev_pa = _hip.to_device_table([pa], self.dev)
+                    keep.extend([pa, dev_pa])
+                    fwd.append(call(lib.mpnn_ev_prefix_walk, 'ev_prefix_walk', C.byref(pa), dev_pa.data_ptr()))
             for d in sorted(by_depth):
                 bs = by_depth[d]
                 if walk and d < d0:
