@@ -318,3 +318,54 @@ def test_adaptive_loop_draws_in_the_reference_order():
             assert np.array_equal(rec[jj][:, 0], j) and np.array_equal(rec[jj][:, 1].astype(bool), flip) and np.array_equal(rec[jj][:, 2:], sh)
             assert np.array_equal(ks[jj], kc)
     assert np.array_equal(np.random.randint(0, 2 ** 32, 8, dtype=np.uint32), tail)
+
+
+@pytest.mark.parametrize('kind', ['cr_tree', 'sr', 'dyn', 'wide', 'conv', 'random_tree'])
+def test_checkpoint_round_trip_for_every_net_family(kind, tmp_path):
+    """write_net / read_net (the reference's record format + the momentum slots) on the other net families: a 47-block
+    critic tree, a statically-routed chain, a per-sample-k_cpt net, wide routers with 37 classes (the any-width exit
+    kernels), a single-scale Conv net, a randomly drawn tree with static links -- the restored net has the same
+    parameters, momentum and BatchNorm state and takes the same next training step, bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import arch_and_hypers as A
+    from lib.net_types import CriticNet
+    from lib.serdes import write_net, read_net
+    from test_net_parity import _wide_chain, batch, perturb_routers
+    hw, n_cls, extra = 32, 10, (lambda net: {net.τ: 0.6})
+    if kind == 'cr_tree':
+        mk = A.cr_tree(k_cpt=4e-9)
+    elif kind == 'sr':
+        mk, extra = A.sr_chain(4), (lambda net: {})
+    elif kind == 'dyn':
+        mk = A.ac_chain(dyn_k_cpt=True)
+        extra = lambda net: {net.τ: 0.6, net.k_cpt: np.random.default_rng(1).choice(A.k_cpts, 12).astype(np.float32)}
+    elif kind == 'wide':
+        mk, n_cls = _wide_chain(CriticNet, (24, 40), k_cpt=8e-9), 37
+    elif kind == 'conv':
+        from test_conv_layer import pooled_conv_net
+        mk, hw, extra = pooled_conv_net(), 16, (lambda net: {})
+    else:
+        from lib.net_types import ActorNet
+        from test_fuzz_trees_gpu import draw_tree, make_tree
+        mk = make_tree(ActorNet, draw_tree(np.random.default_rng(1300), 3), k_cpt=4e-9)
+    net = mk((hw, hw, 3), (n_cls,))
+    net.engine().init_params(21)
+    if kind not in ('sr', 'conv'):
+        perturb_routers(net)
+    x0, y = batch(12, 3, n_cls, seed=1, hw=hw)
+    feed = lambda m: {m.x0: x0, m.y: y, m.mode: 'tr', m.λ_lrn: 0.05, **extra(m)}
+    for _ in range(2):
+        net.train.run(feed(net))
+    path = str(tmp_path / 'net.npy')
+    write_net(path, net, with_optimizer=True)
+    net2 = read_net(path)
+    assert type(net2) is type(net)
+    for p, q in zip(net._all_params, net2._all_params):
+        assert (p.name, p.shape) == (q.name, q.shape) and torch.equal(p.data.cpu(), q.data.cpu()), (p.owner.name, p.name)
+        if p.trainable:
+            assert torch.equal(p.accum.cpu(), q.accum.cpu()), (p.owner.name, p.name)
+    net.train.run(feed(net)); net2.train.run(feed(net2))
+    torch.cuda.synchronize()
+    tol = 0.0 if kind != 'conv' else 2e-6         # (the Conv engine's 1x1 weight gradients meet in fp32 atomics)
+    d = float((net.engine().P - net2.engine().P).abs().max())
+    assert d <= tol * float(net.engine().P.abs().max()), d
