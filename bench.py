@@ -20,6 +20,10 @@ for p in (ROOT, os.path.join(ROOT, 'multipath-nn_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# (before anything initialises HIP: the host driver of this pool only supports dmabuf IPC -- without it RCCL between
+# processes fails with hipIpcGetMemHandle: invalid argument; the launcher below sets it for its children as well)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import numpy as np
 import torch
 

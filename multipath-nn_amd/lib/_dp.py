@@ -11,6 +11,8 @@ applies 1/world_size to the gradients and 1/(n*world_size) to the statistics.
 """
 import os
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # (dmabuf IPC: what RCCL between processes needs on this stack; before HIP starts)
+
 import torch
 import torch.distributed as dist
 
