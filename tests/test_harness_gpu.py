@@ -369,3 +369,52 @@ def test_checkpoint_round_trip_for_every_net_family(kind, tmp_path):
     tol = 0.0 if kind != 'conv' else 2e-6         # (the Conv engine's 1x1 weight gradients meet in fp32 atomics)
     d = float((net.engine().P - net2.engine().P).abs().max())
     assert d <= tol * float(net.engine().P.abs().max()), d
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_device_augmentation_on_random_shapes(seed):
+    """mpnn_augment_batch / mpnn_augment_batch_multi against the vectorised host path (itself pinned to the reference's
+    fixtures above) on random image sizes (8 ... 40 pixels, non-square too), 1 / 3 / 4 channels, 2 ... 12 classes, shift
+    ranges 0 ... 6 (beyond half of a small image), ragged batches: gathered pixels exact, mean fill to fp32 rounding."""
+    import ctypes as C
+    from lib import _hip, data as D
+    rng = np.random.default_rng(500 + seed)
+    H, W = int(rng.integers(8, 41)), int(rng.integers(8, 41))
+    if seed % 2 == 0:
+        W = H
+    c, n_cls, n_src = int(rng.choice([1, 3, 4])), int(rng.integers(2, 13)), int(rng.integers(1, 70))
+    x = rng.random((n_src, H, W, c)).astype(np.float32)
+    yy = np.eye(n_cls, dtype=np.float32)[rng.integers(0, n_cls, n_src)]
+    ds = D.Dataset(arrays=dict(x0_tr=x, y_tr=yy, x0_ts=x[:1], y_ts=yy[:1], m_sym=rng.random(n_cls) < 0.5))
+    ds.to_device('cuda:0')
+    for trial in range(3):
+        n, r = int(rng.integers(1, 150)), int(rng.integers(0, 7))
+        np.random.seed(seed * 10 + trial)
+        xh, yh = ds.augmented_training_batch(n, r)
+        np.random.seed(seed * 10 + trial)
+        xd, yd = ds.augmented_training_batch_device(n, r)
+        torch.cuda.synchronize()
+        assert np.abs(xd.cpu().numpy().astype(np.float64) - xh).max() <= 2e-7, (H, W, c, n, r)
+        assert np.array_equal(yd.cpu().numpy(), yh.astype(np.float32))
+    # the multi-consumer launch (co-training): three consumers, each its own records
+    n, r, K = 17, 3, 3
+    np.random.seed(99)
+    want = [ds.augmented_training_batch(n, r) for _ in range(K)]
+    np.random.seed(99)
+    recs = torch.zeros((K, n, 4), dtype=torch.int32)
+    for k in range(K):
+        D._draw_augmentation_fast(n, n_src, ds._sym_u8, r, out=recs[k].numpy(), all_sym=ds._all_sym)
+    recs_d = recs.cuda()
+    xo = torch.full((K, n, H, W, c), float('nan'), device='cuda'); yo = torch.full((K, n, n_cls), float('nan'), device='cuda')
+    tab = []
+    for k in range(K):
+        d = _hip.AugmentDst()
+        d.draw, d.x_out, d.y_out = recs_d[k].data_ptr(), xo[k].data_ptr(), yo[k].data_ptr()
+        tab.append(d)
+    dev_tab = _hip.to_device_table(tab, 'cuda:0')
+    _hip.check(_hip.load().mpnn_augment_batch_multi(ds._x_dev.data_ptr(), ds._y_dev.data_ptr(), dev_tab.data_ptr(), K, n, H, W, c, n_cls,
+                                                    torch.cuda.current_stream().cuda_stream), 'augment_batch_multi')
+    torch.cuda.synchronize()
+    for k in range(K):
+        assert np.abs(xo[k].cpu().numpy().astype(np.float64) - want[k][0]).max() <= 2e-7, k
+        assert np.array_equal(yo[k].cpu().numpy(), want[k][1].astype(np.float32)), k
