@@ -115,6 +115,29 @@ def test_groups_side_by_side_equal_the_solo_steps(makers, streams, sizes, share)
     _compare_with_solo_steps(co_nets, solo, run, cg.share, 16, routed=routed)
 
 
+@pytest.mark.calibrate
+def test_stream_calibration():
+    """concurrent_streams: between one and the requested number of streams whose dependent launch chains overlap (four on
+    this runtime's four hardware queues when nothing else loads the GPU -- not asserted: a timing measurement), and a plan
+    built on the measurement trains."""
+    import arch_and_hypers as A
+    from lib._co import CoGroups, concurrent_streams
+    found = concurrent_streams(torch.device('cuda:0'), 4)
+    assert 1 <= len(found) <= 4 and len({s.cuda_stream for s in found}) == len(found)
+    nets = _nets([A.ac_chain(k_cpt=k) for k in A.k_cpts[:4]])
+    cg = CoGroups.plan(nets, streams=4)
+    assert sum(c.K for c in cg.groups) == 4 and len(cg.streams) <= max(1, len(cg.groups))
+    for t in range(3):
+        feeds = []
+        for i, net in enumerate(nets):
+            x0, y = batch(16, seed=i + 10 * t)
+            feeds.append({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.02, net.τ: 0.8})
+        cg.run(feeds)
+    cg.join()
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(net.engine().P).all()) for net in nets)
+
+
 def test_groups_side_by_side_are_deterministic():
     """A race detector for the side-by-side form: groups on different streams share nothing but the read-only dataset, and
     every group's joint graph is deterministic -- so 60 free-running rounds (no barrier between steps, the groups drift
@@ -127,7 +150,7 @@ def test_groups_side_by_side_are_deterministic():
     for rep in range(2):
         nets = _nets([A.ac_chain(k_cpt=ks[i]) for i in range(4)] + [A.sr_chain(3)])
         cg = CoGroups.plan(nets, streams=4)
-        assert [c.K for c in cg.groups] == [2, 1, 1, 1] or len(cg.streams) < 4
+        assert [c.K for c in cg.groups] == [2, 1, 1, 1]
         xs = [batch(32, seed=50 + i) for i in range(len(nets))]
         for t in range(60):
             feeds = [{net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.02, **({net.τ: 1.0 - 0.01 * t} if net._net_kind != 'sr' else {})}
