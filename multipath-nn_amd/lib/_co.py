@@ -293,9 +293,15 @@ class CoGroups:
             if runs and runs[-1][0] == s:
                 runs[-1][1] += 1
             else:
-                runs.append([s, 1])
+                runs.append([s, 1, net])
         K = len(nets)
-        for _, cnt in runs:
+        for _, cnt, first in runs:
+            eng = first.engine()
+            if cnt > 1 and hasattr(eng, '_groupable') and not eng._groupable():
+                # (an architecture whose forward convs are single launches -- 64+ channels on 16x16 / 32x32 maps -- has no
+                # multi-net launch form: its nets run side by side as groups of one)
+                sizes += [1] * cnt
+                continue
             g = max(1, min(cnt, round(streams * cnt / K)))
             base, extra = divmod(cnt, g)
             sizes += [base + (1 if i < extra else 0) for i in range(g)]

@@ -351,3 +351,39 @@ def test_train_nets_shard_nets_under_torchrun(tmp_path):
     for i in (0, 1, 2):
         for f in ('%.4i.npy', '%.4i-stats.npy', '%.4i-log.txt'):
             assert os.path.exists(os.path.join(base, f % i)), f % i
+
+
+@pytest.mark.parametrize('seed', [int(s) for s in __import__('os').environ.get('MPNN_FUZZ_COTREE_SEEDS', '0 1').split()])
+def test_cotrained_random_trees_and_architectures_equal_the_solo_steps(seed):
+    """Co-training beyond the shipped shapes: three nets of one RANDOMLY drawn tree (forks, static links:
+    tests/test_fuzz_trees_gpu.py) or of one randomly drawn channel / scale table (tests/test_fuzz_arch_gpu.py), in one
+    joint graph and as groups on streams -- every net takes the step it takes alone with the group's planner setting."""
+    from lib._co import CoGroups, CoTrainer
+    from lib.net_types import ActorNet, CriticNet
+    from test_fuzz_arch_gpu import draw_arch, make_chain
+    from test_fuzz_trees_gpu import draw_tree, make_tree
+    rng = np.random.default_rng(1700 + seed)
+    kind = (ActorNet, CriticNet)[seed % 2]
+    if seed % 3 == 0:
+        arch = draw_arch(rng)
+        mk = lambda k: make_chain(kind, arch, len(arch[0]), k_cpt=k)
+    else:
+        has_switch = lambda t: (int(t[0]) + len(t[1]) >= 2) or any(has_switch(c) for c in t[1])
+        spec = draw_tree(rng, int(rng.integers(2, 5)))
+        while not has_switch(spec):
+            spec = draw_tree(rng, int(rng.integers(2, 5)))
+        mk = lambda k: make_tree(kind, spec, k_cpt=k)
+    ks = [0.0, 4e-9, 1.6e-8]
+    n = int(rng.choice([8, 24, 128]))
+    co_nets, solo = _nets([mk(k) for k in ks]), _nets([mk(k) for k in ks])
+    if co_nets[0].engine()._groupable():
+        co = CoTrainer(co_nets)
+        _compare_with_solo_steps(co_nets, solo, co.run, 3, n, steps=3)
+        co_nets, solo = _nets([mk(k) for k in ks]), _nets([mk(k) for k in ks])
+    cg = CoGroups.plan(co_nets, streams=2)          # (an architecture without multi-net launch forms: groups of one)
+    assert co_nets[0].engine()._groupable() or [c.K for c in cg.groups] == [1, 1, 1]
+
+    def run(feeds):
+        cg.run(feeds)
+        cg.join()
+    _compare_with_solo_steps(co_nets, solo, run, cg.share, n, steps=3)
