@@ -382,6 +382,9 @@ typedef struct {
      * MPNN_HYP_N schedule values hyp_src[0 .. MPNN_HYP_N) to hyp_dst -- the buffer mpnn_route and the optimizer of THIS
      * step read -- so that step j of the graph runs with the values staged in slot j, without a launch of its own. */
     const float *hyp_src;  float *hyp_dst;
+    /* The SECOND router BatchNorm's own hyper-parameters (bn_eps / bn_decay above are the first one's: the two are
+     * separate BatchNorm(d, eps) layers in the router chain, arch_and_hypers.py:47-49).  Always read: set both. */
+    float bn_eps2, bn_decay2;
 } mpnn_exit_tail_args;
 int mpnn_exit_tail_fwd(const mpnn_exit_tail_args *dev_table, int count, int n_max,
                        void *stream);
@@ -429,6 +432,7 @@ typedef struct {
     int R2;                              /* width of the second hidden layer (0: R); see mpnn_exit_tail_args */
     float *z, *h1;                       /* scratch of mpnn_exit_ev_gen: [n, n_cls] head logits, [n, R] first router map
                                           * (rows by IMAGE; the tuned mpnn_exit_ev keeps both in LDS and ignores them) */
+    float bn_eps2;                       /* epsilon of the SECOND router BatchNorm (bn_eps: the first one's); always read */
 } mpnn_exit_ev_args;
 int mpnn_exit_ev(const mpnn_exit_ev_args *dev_table, int count, int n_max, void *stream);
 int mpnn_exit_ev_check(const mpnn_exit_ev_args *host_record);

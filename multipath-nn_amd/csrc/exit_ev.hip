@@ -59,7 +59,7 @@ __global__ __launch_bounds__(EV_WAVES * 64) void exit_ev_k(const mpnn_exit_ev_ar
             const int c = tid - TR * TR - TR * TS;
             const bool ok = c < R;
             // BatchNorm with moving averages folded to scale/shift: y = k*(x - m) + beta
-            const float k1 = ok ? a.g1[c] * rsqrtf(a.v1[c] + a.bn_eps) : 0.f, k2 = ok ? a.g2[c] * rsqrtf(a.v2[c] + a.bn_eps) : 0.f;
+            const float k1 = ok ? a.g1[c] * rsqrtf(a.v1[c] + a.bn_eps) : 0.f, k2 = ok ? a.g2[c] * rsqrtf(a.v2[c] + a.bn_eps2) : 0.f;
             vec[c] = k1; vec[TR + c] = ok ? a.m1[c] : 0.f; vec[2 * TR + c] = ok ? a.be1[c] : 0.f;
             vec[3 * TR + c] = k2; vec[4 * TR + c] = ok ? a.m2[c] : 0.f; vec[5 * TR + c] = ok ? a.be2[c] : 0.f;
             vec[6 * TR + c] = ok ? a.bias2[c] : 0.f;

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(TT) void exit_tail_fwd_gen_k(const mpnn_exit_tail_a
     __shared__ float a1L[16 * GEN_R];
     const int R = a.R, R2 = a.R2 > 0 ? a.R2 : a.R, S = a.n_sinks;
     const bool batch = a.mode == MPNN_ACT_BN_BATCH;
-    const float inv_n = 1.f / (float)n, d = a.bn_decay;
+    const float inv_n = 1.f / (float)n, d = a.bn_decay, d2 = a.bn_decay2;
     // ---- first BatchNorm: sum and sum of squares in fp64 (one pass: exact enough for fp32 inputs), biased variance,
     //      moving averages ----
     if (batch) {
@@ -394,12 +394,12 @@ __global__ __launch_bounds__(TT) void exit_tail_fwd_gen_k(const mpnn_exit_tail_a
                     [&](int j, const double *t) {
                         const double mu = t[0] / n, vd = t[1] / n - mu * mu;
                         const float var = (float)(vd > 0.0 ? vd : 0.0);
-                        st.m2[j] = (float)mu; st.s2[j] = rsqrtf(var + a.bn_eps);
-                        a.m2[j] = d * a.m2[j] + (1.f - d) * (float)mu;
-                        a.v2[j] = d * a.v2[j] + (1.f - d) * var;
+                        st.m2[j] = (float)mu; st.s2[j] = rsqrtf(var + a.bn_eps2);
+                        a.m2[j] = d2 * a.m2[j] + (1.f - d2) * (float)mu;
+                        a.v2[j] = d2 * a.v2[j] + (1.f - d2) * var;
                     });
     } else {
-        for (int j = tid; j < R2; j += TT) { st.m2[j] = a.m2[j]; st.s2[j] = rsqrtf(a.v2[j] + a.bn_eps); }
+        for (int j = tid; j < R2; j += TT) { st.m2[j] = a.m2[j]; st.s2[j] = rsqrtf(a.v2[j] + a.bn_eps2); }
         __syncthreads();
     }
     (void)inv_n;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void ev_tail_gen_k(const mpnn_exit_ev_args *__
             for (int j = part; j < R2; j += HT) {
                 float h = a.bias2[j];
                 for (int c = 0; c < R; ++c) h += aL[sl * R + c] * a.w2[c * R2 + j];
-                bL[sl * R2 + j] = fmaxf(a.g2[j] * (h - a.m2[j]) * rsqrtf(a.v2[j] + a.bn_eps) + a.be2[j], 0.f);
+                bL[sl * R2 + j] = fmaxf(a.g2[j] * (h - a.m2[j]) * rsqrtf(a.v2[j] + a.bn_eps2) + a.be2[j], 0.f);
             }
             __syncthreads();
             if (part == 0 && ok) {

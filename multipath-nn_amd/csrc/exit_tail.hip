@@ -154,17 +154,17 @@ __device__ __forceinline__ void row_h2(const float (&h1)[TR], const RouterW &L, 
     }
 }
 // mean / rstd from the pivoted sums (as bn_stats) + the moving-average update
-__device__ __forceinline__ void stats_finish(const float *tot, const float *pv, int n, int R, const mpnn_exit_tail_args &a,
+__device__ __forceinline__ void stats_finish(const float *tot, const float *pv, int n, int R, const float bn_eps, const float bn_decay,
                                              float *m_avg, float *v_avg, float *mean, float *rstd) {
     const int tid = threadIdx.x;
     if (tid < TR) {
         const float inv = 1.f / (float)n, dm = tot[tid] * inv;
         const float mu = pv[tid] + dm, var = fmaxf(tot[TR + tid] * inv - dm * dm, 0.f);
         mean[tid] = mu;
-        rstd[tid] = rsqrtf(var + a.bn_eps);
+        rstd[tid] = rsqrtf(var + bn_eps);
         if (tid < R) {
-            m_avg[tid] = a.bn_decay * m_avg[tid] + (1.f - a.bn_decay) * mu;
-            v_avg[tid] = a.bn_decay * v_avg[tid] + (1.f - a.bn_decay) * var;
+            m_avg[tid] = bn_decay * m_avg[tid] + (1.f - bn_decay) * mu;
+            v_avg[tid] = bn_decay * v_avg[tid] + (1.f - bn_decay) * var;
         }
     }
     __syncthreads();
@@ -190,7 +190,7 @@ __device__ void router_fwd_big(const mpnn_exit_tail_args &a) {
             for (int c = 0; c < TR; ++c) { const float d = x[c] - pv[c]; acc[c] += d; acc[TR + c] += d * d; }
         }
         block_sums<2 * TR>(acc, part, tot);
-        stats_finish(tot, pv, n, R, a, a.m1, a.v1, bnp, bnp + TR);
+        stats_finish(tot, pv, n, R, a.bn_eps, a.bn_decay, a.m1, a.v1, bnp, bnp + TR);
     } else {
         if (tid < R) { bnp[tid] = a.m1[tid]; bnp[TR + tid] = rsqrtf(a.v1[tid] + a.bn_eps); }
         __syncthreads();
@@ -219,9 +219,9 @@ __device__ void router_fwd_big(const mpnn_exit_tail_args &a) {
     }
     if (batch) {
         block_sums<2 * TR>(acc, part, tot);
-        stats_finish(tot, pv, n, R, a, a.m2, a.v2, bnp + 2 * TR, bnp + 3 * TR);
+        stats_finish(tot, pv, n, R, a.bn_eps2, a.bn_decay2, a.m2, a.v2, bnp + 2 * TR, bnp + 3 * TR);
     } else {
-        if (tid < R) { bnp[2 * TR + tid] = a.m2[tid]; bnp[3 * TR + tid] = rsqrtf(a.v2[tid] + a.bn_eps); }
+        if (tid < R) { bnp[2 * TR + tid] = a.m2[tid]; bnp[3 * TR + tid] = rsqrtf(a.v2[tid] + a.bn_eps2); }
         __syncthreads();
     }
     for (int s = tid; s < n; s += 256) {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void exit_tail_fwd_k(const mpnn_exit_tail_args
     }
     __syncthreads();
     trace_stamp(3);
-    bn_stats(h2s, n, R, a.mode, a.bn_eps, a.bn_decay, a.m2, a.v2, m2o, v2o, scratch, bnp + 2 * TR, bnp + 3 * TR);
+    bn_stats(h2s, n, R, a.mode, a.bn_eps2, a.bn_decay2, a.m2, a.v2, m2o, v2o, scratch, bnp + 2 * TR, bnp + 3 * TR);
     trace_stamp(4);
     for (int s = tid; s < n; s += 256) {
         float a2[TR];

@@ -50,6 +50,11 @@ __device__ __forceinline__ int4 uniform4(int4 v) {   // a record is the same in 
 }
 
 // blk = workgroup index within the net's launch (RB samples each)
+// The deterministic statistics exchange: partials leave with write-through (system-scope) stores and are read back
+// uncached, so that what the last-arriving workgroup adds never depends on another XCD's L2.
+template <class T> __device__ __forceinline__ void st_part(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+template <class T> __device__ __forceinline__ T ld_part(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 template <int RB>
 __device__ __forceinline__ void route_body(const mpnn_route_args &a, const int blk, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -294,7 +299,7 @@ __device__ __forceinline__ void route_body(const mpnn_route_args &a, const int b
             const float pl = live ? ptr : 0.f;
             const float s1 = wave_sum_f(pl), s2 = wave_sum_f(pl * pl);
             if (lane_t == 0) {
-                if (det_stat) { a.stat_part[((size_t)blk * NN + j) * 2] = s1; a.stat_part[((size_t)blk * NN + j) * 2 + 1] = s2; }
+                if (det_stat) { st_part(a.stat_part + ((size_t)blk * NN + j) * 2, s1); st_part(a.stat_part + ((size_t)blk * NN + j) * 2 + 1, s2); }
                 else { atomicAdd(a.node_stat + j * 2, s1); atomicAdd(a.node_stat + j * 2 + 1, s2); }
             }
         }
@@ -347,13 +352,18 @@ __device__ __forceinline__ void route_body(const mpnn_route_args &a, const int b
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < RT_WAVES; ++w) t += lsum[w * 4 + threadIdx.x];
-            if (det_stat) ((double *)(a.stat_part + (size_t)nblk * NN * 2))[blk * 4 + threadIdx.x] = t;     // (summed below, in order)
+            if (det_stat) st_part((double *)(a.stat_part + (size_t)nblk * NN * 2) + blk * 4 + threadIdx.x, t);     // (summed below, in order)
             else atomicAdd(a.loss + threadIdx.x, t);
         }
     }
     if (det_stat) {
         // the partial sums of all workgroups, added in workgroup order by whichever finishes last
         int *last_s = (int *)lds + 128;                   // (dynamic LDS, behind the loss sums: the launch may use all 160 KB)
+        // RELEASE by every writer: the partials were written by lane 0 of SEVERAL waves with write-through stores
+        // (st_part); each wave waits for the acknowledgement of its own before the barrier in front of the ticket.  The
+        // barrier alone is a workgroup-scope release (lgkmcnt only) and thread 0's fence below only covers wave 0's
+        // stores -- another wave's partial could reach memory after the ticket (csrc/lin.hip uses the same exchange).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
             __threadfence();
@@ -364,13 +374,13 @@ __device__ __forceinline__ void route_body(const mpnn_route_args &a, const int b
             __threadfence();
             for (int i = threadIdx.x; i < 2 * NN; i += RT_THREADS) {
                 float t = 0.f;
-                for (int b = 0; b < nblk; ++b) t += __builtin_nontemporal_load(a.stat_part + (size_t)b * NN * 2 + i);
+                for (int b = 0; b < nblk; ++b) t += ld_part(a.stat_part + (size_t)b * NN * 2 + i);
                 a.node_stat[i] += t;
             }
             if (a.loss && threadIdx.x < 4) {
                 const double *lp = (const double *)(a.stat_part + (size_t)nblk * NN * 2);
                 double t = 0.0;
-                for (int b = 0; b < nblk; ++b) t += __builtin_nontemporal_load(lp + b * 4 + threadIdx.x);
+                for (int b = 0; b < nblk; ++b) t += ld_part(lp + b * 4 + threadIdx.x);
                 a.loss[threadIdx.x] += t;
             }
             if (threadIdx.x == 0) *a.stat_ticket = 0;

@@ -138,6 +138,8 @@ class CoTrainer:
                 keep += [mem, dev]
                 merged.append(launch_of(lib.mpnn_msconv_bwd_level_rep, what, flops, tag, mem, cnt, K, dev.data_ptr()))
             elif what == 'backward_finish':
+                if len({float(e.bn_decay) for e in self.engs}) > 1:
+                    raise NotImplementedError('co-training: the nets of a group must share the conv BatchNorms\' decay')
                 arr = (_hip.FinishNet * K)(*[p['finish_net'] for p in progs])
                 dev = table(list(arr))
                 keep.append(arr)

@@ -97,7 +97,7 @@ class ExitTailArgs(C.Structure):
                 ('h2', P), ('r', P), ('r_stride', C.c_int), ('bn_save', P),
                 ('bn_eps', C.c_float), ('bn_decay', C.c_float), ('mode', C.c_int), ('n', C.c_int),
                 ('clear_f', P), ('n_clear_f', C.c_int), ('clear_d', P), ('n_clear_d', C.c_int), ('R2', C.c_int),
-                ('hyp_src', P), ('hyp_dst', P)]
+                ('hyp_src', P), ('hyp_dst', P), ('bn_eps2', C.c_float), ('bn_decay2', C.c_float)]
 
 
 class ExitTailBwdArgs(C.Structure):
@@ -115,7 +115,7 @@ class ExitEvArgs(C.Structure):
                 ('g2', P), ('be2', P), ('m2', P), ('v2', P), ('w3', P), ('bias3', P),
                 ('bn_eps', C.c_float), ('r', P), ('r_stride', C.c_int),
                 ('idx', P), ('cnt', P), ('n', C.c_int),
-                ('child_idx', P * 4), ('child_cnt', P * 4), ('R2', C.c_int), ('z', P), ('h1', P)]
+                ('child_idx', P * 4), ('child_cnt', P * 4), ('R2', C.c_int), ('z', P), ('h1', P), ('bn_eps2', C.c_float)]
 
 
 class ConvNhwcFwdArgs(C.Structure):

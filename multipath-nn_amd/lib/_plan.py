@@ -441,7 +441,15 @@ class Engine:
             p.grad = self.G[p.offset:p.offset + p.size]
         self.n_bn = len(tab) // 8
         self.bn_table = torch.tensor(tab, dtype=torch.int32, device=dev)
-        self.bn_decay = float(self.blocks[0].bns[0].hypers.d) if self.blocks else 0.9
+        # ONE moving-average decay for the conv BatchNorms of a net (a kernel argument of the finishing launch).  Trees
+        # built through the layer classes always satisfy this: MultiscaleBatchNorm gives every scale a default
+        # BatchNorm() whatever it was handed (reference layer_types.py:246).  A tree whose comps were edited by hand
+        # is refused instead of trained with block 0's number.
+        decays = sorted({float(bn.hypers.d) for b in self.blocks for bn in b.bns})
+        if len(decays) > 1:
+            raise NotImplementedError('conv BatchNorms with different moving-average decays %r are outside the MI355X '
+                                      'hot path (one decay per net)' % (decays,))
+        self.bn_decay = decays[0] if decays else 0.9
         # routing tables
         nodes, ops = [], []
         for nd in self.nodes:                                   # (DFS preorder: a parent comes before its children)
@@ -970,6 +978,7 @@ class Engine:
                 tf.r, tf.r_stride = self.r[sw * n * MS:].data_ptr(), MS
                 tf.bn_save = b.bn_save.data_ptr()
                 tf.bn_eps, tf.bn_decay = float(bn1.hypers.ϵ), float(bn1.hypers.d)
+                tf.bn_eps2, tf.bn_decay2 = float(bn2.hypers.ϵ), float(bn2.hypers.d)
                 tb.dr = self.dr[sw * n * MS:].data_ptr()
                 tb.dh1 = b.dh1.data_ptr()
                 if mode == 'tr' and getattr(b, 'dh2', None) is not None:
@@ -1442,7 +1451,7 @@ class Engine:
                 e.w2, e.bias2 = D(l2.params.w), D(l2.params.b)
                 e.g2, e.be2, e.m2, e.v2 = D(bn2.params.γ), D(bn2.params.β), D(bn2.params.m_avg), D(bn2.params.v_avg)
                 e.w3, e.bias3 = D(l3.params.w), D(l3.params.b)
-                e.bn_eps = float(bn1.hypers.ϵ)
+                e.bn_eps, e.bn_eps2 = float(bn1.hypers.ϵ), float(bn2.hypers.ϵ)
                 e.r, e.r_stride = self.r[sw * n * MS:].data_ptr(), MS
                 if routed and id(b) not in in_prefix:       # (a prefix exit runs on every sample: the walk writes the lists)
                     for i, sb in enumerate(b.sink_blocks):

@@ -334,13 +334,17 @@ class BatchNorm(Layer):
 
 
 class MultiscaleBatchNorm(Layer):
-    """One independent BatchNorm per scale.  Reference: layer_types.py:241-249."""
+    """One independent BatchNorm per scale.  Reference: layer_types.py:241-249.
+
+    The reference accepts `d` / `ϵ` here and DISCARDS them: every scale gets a
+    `BatchNorm()` with the default hypers (layer_types.py:246).  Same here, so
+    a spec that passes either gives the reference's numbers, not the numbers
+    its author may have meant."""
     default_hypers = Ns(d=0.9, ϵ=1e-6)
 
     def link(self, x, y, mode):
         super().link(x, y, mode)
-        ϕ = self.hypers
-        self.comps = [BatchNorm(d=ϕ.d, ϵ=ϕ.ϵ) for _ in x]
+        self.comps = [BatchNorm() for _ in x]
         for ℓ, x_i in zip(self.comps, x):
             ℓ.link(x_i, y, mode)
         self.x = [ℓ.x for ℓ in self.comps]

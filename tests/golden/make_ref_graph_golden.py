@@ -46,6 +46,12 @@ CASES = {
     'ac_notalr_artr2': dict(ctor='ac_chain', hypers=dict(k_cpt=4e-9, talr=False, α_rtr=2.0), tau=1.0, n=3, seed=10),
     'cr_artr3': dict(ctor='cr_chain', hypers=dict(k_cpt=8e-9, α_rtr=3.0), tau=0.5, n=3, seed=11),
     'cr_notalr_artr': dict(ctor='cr_chain', hypers=dict(k_cpt=2e-9, talr=False, α_rtr=0.5, k_cre=0.01), tau=0.2, n=3, seed=12),
+    # LAYER-level keyword arguments (round 6; `layer_kwargs_chain` below): MultiscaleBatchNorm(d=0.5, ϵ=1e-3) on block 1
+    # -- which the reference accepts and DISCARDS (layer_types.py:246; rounds 1-5 forwarded them: 75 of 108 tensors of
+    # this very net differed from the reference's code) --, the two router BatchNorms with hypers of their own (and
+    # different from each other), CrossEntropyError(ϵ), per-layer k_l2 and a LinTrans(res=True) exit
+    'ac_layer_kwargs': dict(ctor='layer_kwargs_chain', net='ActorNet', hypers=dict(k_cpt=1.6e-8), tau=0.7, n=4, seed=13),
+    'cr_layer_kwargs': dict(ctor='layer_kwargs_chain', net='CriticNet', hypers=dict(k_cpt=8e-9), tau=0.5, n=4, seed=14),
 }
 # seeds of the first ten cases: their index in the sorted key list of the round they were generated in
 _LEGACY = ['ac', 'ac_dyn', 'ac_notalr_nokdec', 'ac_tree3', 'cr', 'cr_opt_cls', 'cr_tree3', 'sr3', 'sr8', 'sr8_mnist']
@@ -65,9 +71,42 @@ def small_tree(A, NT, case):
     return make_net
 
 
+def layer_kwargs_chain(A, NT, case):
+    """A 3-block chain built through the LAYER CLASSES of the side that runs (the module A imported them from), with
+    keyword arguments the shipped spec never passes."""
+    L = sys.modules[A.Chain.__module__]
+
+    def router(bn1, bn2, k):
+        return L.Chain(name='Router', comps=[
+            L.Select(i=-1), L.LinTrans(n_chan=A.router_n_chan, k_l2=k, σ_w=1),
+            L.BatchNorm(**bn1), L.Rect(), L.LinTrans(n_chan=A.router_n_chan, k_l2=3 * k, σ_w=1),
+            L.BatchNorm(**bn2), L.Rect(), L.LinTrans(n_chan=2, k_l2=A.k_l2, σ_w=0)])
+
+    def reg(nc, **kw):
+        return L.Chain(name='LogReg', comps=[L.Select(i=-1), L.LinTrans(n_chan=nc, k_l2=A.k_l2, σ_w=1, **kw.get('lin', {})),
+                                             L.Softmax(), L.CrossEntropyError(**kw.get('ce', {}))])
+
+    def rcm(i, sinks, msbn, rt, k_l2=A.k_l2):
+        return L.Chain(name='ReConvMax', sinks=sinks, router=rt, comps=[
+            L.MultiscaleConvMax(n_chan=A.arch[i], supp=A.conv_supp, k_l2=k_l2, σ_w=1),
+            L.MultiscaleBatchNorm(**msbn), L.MultiscaleRect()])
+
+    def make_net(x0_shape, y_shape):
+        nc = y_shape[0]
+        b2 = rcm(2, (reg(nc, ce=dict(ϵ=1e-3)),), {}, None)
+        b1 = rcm(1, (reg(nc, lin=dict(res=True)), b2), dict(d=0.5, ϵ=1e-3), router(dict(d=0.8, ϵ=1e-3), dict(d=0.6, ϵ=1e-4), 2e-4),
+                 k_l2=5e-4)
+        b0 = rcm(0, (reg(nc), b1), {}, router({}, dict(ϵ=1e-2), A.k_l2))
+        root = L.Chain(name='ToPyramid', sinks=(b0,), router=None, comps=[L.ToPyramid(n_scales=len(A.arch[0]))])
+        return getattr(NT, case['net'])(x0_shape=x0_shape, y_shape=y_shape, root=root, **case['hypers'])
+    return make_net
+
+
 def make_case(A, NT, case):
     if case['ctor'] == 'small_tree':
         return small_tree(A, NT, case)
+    if case['ctor'] == 'layer_kwargs_chain':
+        return layer_kwargs_chain(A, NT, case)
     return getattr(A, case['ctor'])(*case.get('args', ()), **case['hypers'])
 K_CPTS = [0.0, 1e-9, 2e-9, 4e-9, 8e-9, 1.6e-8, 3.2e-8, 6.4e-8]
 LR = 0.05

@@ -69,7 +69,10 @@ class T:
             dims[0] = None
         return _Shape(dims)
 
-    # arithmetic
+    # arithmetic (ndarray + T must reach T.__radd__ as it reaches a TensorFlow tensor's: `np.eye(..) + w_scale * tf.random_normal(..)`,
+    # layer_types.py:49 with res=True)
+    __array_ufunc__ = None
+
     def _bin(self, other, op, rev=False):
         other = as_T(other)
         a, b = (other, self) if rev else (self, other)

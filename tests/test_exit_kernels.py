@@ -221,6 +221,7 @@ def test_exit_tail_fwd_bwd(n, S, R):
     tf.w3, tf.bias3 = d['w3'].data_ptr(), d['bias3'].data_ptr()
     tf.h2, tf.r, tf.r_stride, tf.bn_save = h2.data_ptr(), r.data_ptr(), MS, save.data_ptr()
     tf.bn_eps, tf.bn_decay, tf.mode, tf.n = bn_eps, decay, _hip.ACT_BN_BATCH, n
+    tf.bn_eps2, tf.bn_decay2 = bn_eps, decay
     tab = _hip.to_device_table([tf], DEV)
     _hip.check(lib.mpnn_exit_tail_fwd(tab.data_ptr(), 1, n, stream()), 'exit_tail_fwd')
     torch.cuda.synchronize()
@@ -295,7 +296,7 @@ def test_exit_ev_against_oracle_with_lists(n, S, C_, dyn):
     e.g1, e.be1, e.m1, e.v1 = d['g1'].data_ptr(), d['b1'].data_ptr(), md[0].data_ptr(), md[1].data_ptr()
     e.w2, e.bias2 = d['w2'].data_ptr(), d['bias2'].data_ptr()
     e.g2, e.be2, e.m2, e.v2 = d['g2'].data_ptr(), d['b2'].data_ptr(), md[2].data_ptr(), md[3].data_ptr()
-    e.w3, e.bias3, e.bn_eps = d['w3'].data_ptr(), d['bias3'].data_ptr(), 1e-6
+    e.w3, e.bias3, e.bn_eps, e.bn_eps2 = d['w3'].data_ptr(), d['bias3'].data_ptr(), 1e-6, 1e-6
     e.r, e.r_stride = r.data_ptr(), MS
     e.idx, e.cnt = idxd.data_ptr(), cntd.data_ptr()
     for i in range(1, S):                              # sink 0: the exit's own leaf (no list)
