@@ -153,7 +153,8 @@ def run_case(make_net, n, feeds, steps=3, k_cpt_vec=None, c0=3, tol=TOL, n_cls=1
             g = p.grad.cpu().numpy()
             if p.l2:
                 pbar = 1.0 if net._net_kind == 'sr' else float(eng.nodes[p.node].layer.p_tr.mean())
-                g = g + 2 * p.l2 * pbar * v0
+                # (LinTrans(res=True): the penalty pulls towards w_eq, layer_types.py:52)
+                g = g + 2 * p.l2 * pbar * (v0 - (np.asarray(p.eq, np.float64).reshape(-1) if p.eq is not None else 0))
             scale = np.abs(g_ref).max()
             # 1e-6 floor: conv biases ahead of BatchNorm have an exactly-zero true gradient
             judge('grad', p, np.abs(g - g_ref).max(), scale, 1e-6)
