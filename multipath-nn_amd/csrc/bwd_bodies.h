@@ -240,6 +240,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
         lds_barrier();
         if (t == sq0) trace_stamp(2);
         if (t + NS * sqd < sqn) request(sel, t + NS * sqd);          // flies under NS tiles of MFMAs
+        mfma_prio_on();
         if constexpr (SMALLC) {
             float gq[4], xq[4][2];
 #pragma unroll
@@ -312,6 +313,7 @@ __device__ __forceinline__ void wgrad_body(const WgP &p, f32x4 *tile, float *gt,
                         acc[ti][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j][ti], bq[j][nt], acc[ti][nt], 0, 0, 0);
         }
         }
+        mfma_prio_off();
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, NS - 1>;

@@ -251,6 +251,24 @@ __device__ __forceinline__ void lds_barrier() {
 // accumulator register written by the last MFMA was observed to be read STALE on gfx950
 // (fwd_group_k: rows 4g+3 of a tile missed the final MFMA, run-to-run nondeterministic).
 // One s_nop 15 (16 wait states) after every unit's MFMA block, against >1000 cycles of MFMAs per unit.
+// Wave priority around a unit's MFMA block (build-time experiment, -DMPNN_MFMA_PRIO=<1..3>): the waves of different
+// workgroups that share a SIMD run the same program and fall into step -- all in their MFMA block, then all in their
+// staging code, the matrix pipe idle meanwhile (profiles/r06_sq_saturated.txt).  With the MFMA block at a raised
+// priority the wave that reaches it first keeps the pipe until its unit is done and its partners' vector work fills
+// the issue slots between its MFMAs.
+#ifndef MPNN_MFMA_PRIO
+#define MPNN_MFMA_PRIO 0
+#endif
+__device__ __forceinline__ void mfma_prio_on() {
+#if MPNN_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(MPNN_MFMA_PRIO);
+#endif
+}
+__device__ __forceinline__ void mfma_prio_off() {
+#if MPNN_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
 __device__ __forceinline__ void mfma_drain() {
     __builtin_amdgcn_sched_barrier(0);
 #ifndef MPNN_DRAIN_NOPS

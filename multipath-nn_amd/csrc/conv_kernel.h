@@ -673,6 +673,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             }
         }
         // ----------------------------- MFMAs of unit u -----------------------------
+        mfma_prio_on();
         if (!MPNN_DBG(p, 1)) {
             const f32x4 *wl = b_once ? wtile[0] : wtile[u & 1];
             const int wcol = wn * NT * 16 + li;
@@ -724,6 +725,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             }
         }
         mfma_drain();
+        mfma_prio_off();
         if (u == 0) trace_stamp(8);
         // ----------------------------- stage unit u+1 ------------------------------
         // BEFORE the epilogue: its wait then covers exactly the loads of unit u+2 issued above

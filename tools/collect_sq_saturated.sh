@@ -13,4 +13,4 @@ timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
 timeout 400 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc2 -o p2 -- $B > $O/pmc2.log 2>&1
 cd $R
 python3 tools/summarize_sq_saturated.py $O > $O/summary.txt 2>&1
-head -70 $O/summary.txt; tail -3 $O/pmc1.log $O/pmc2.log
+head -70 $O/summary.txt; tail -n 3 $O/pmc1.log; tail -n 3 $O/pmc2.log

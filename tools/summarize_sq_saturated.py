@@ -26,7 +26,7 @@ for f in glob.glob(root + '/trace/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = short(r['Kernel_Name'])
         if keep(n):
-            dur[(n, r['Grid_Size'], r['Workgroup_Size'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3)
+            dur[(n, r['Grid_Size_X'], r['Workgroup_Size_X'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3)
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ('pmc1', 'pmc2'):
     for f in glob.glob(root + '/' + sub + '/**/*counter_collection.csv', recursive=True):
@@ -35,7 +35,7 @@ for sub in ('pmc1', 'pmc2'):
             if keep(n):
                 cnt[(n, r['Grid_Size'], r['Workgroup_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
 
-hdr = '%-46s %8s %5s %8s %7s %6s | %5s %5s %5s | %5s %5s %5s %5s %5s | %6s %6s' % (
+hdr = '%-52s %8s %5s %8s %7s %6s | %5s %5s %5s | %5s %5s %5s %5s %5s | %6s %6s' % (
     'kernel', 'grid', 'n', 'us', 'TF', 'pipe', 'wait', 'stall', 'activ', 'valu', 'salu', 'lds', 'vmrd', 'vmwr', 'ldscf', 'ldswt')
 print(hdr)
 print('(wait / stall / activ: SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY of SQ_WAVE_CYCLES, %; valu .. vmwr: instructions per MFMA;')
@@ -49,8 +49,8 @@ for key in sorted(dur, key=lambda k: -sum(dur[k])):
     wc = max(1.0, c.get('SQ_WAVE_CYCLES', 0.0))
     tf = c.get('SQ_INSTS_MFMA', 0.0) * FLOP_PER_MFMA / (us * 1e-6) / 1e12
     pct = lambda a, b: 100.0 * c.get(a, 0.0) / max(1.0, c.get(b, 0.0))
-    print('%-46s %8s %5d %8.1f %7.1f %6.2f | %5.1f %5.1f %5.1f | %5.2f %5.2f %5.2f %5.2f %5.2f | %6.1f %6.1f' % (
-        key[0][:46], key[1], len(d), us, tf, tf / 157.3,
+    print('%-52s %8s %5d %8.1f %7.1f %6.2f | %5.1f %5.1f %5.1f | %5.2f %5.2f %5.2f %5.2f %5.2f | %6.1f %6.1f' % (
+        key[0][:52], key[1], len(d), us, tf, tf / 157.3,
         pct('SQ_WAIT_ANY', 'SQ_WAVE_CYCLES'), pct('SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES'), pct('SQ_ACTIVE_INST_ANY', 'SQ_WAVE_CYCLES'),
         c.get('SQ_INSTS_VALU', 0) / m, c.get('SQ_INSTS_SALU', 0) / m, c.get('SQ_INSTS_LDS', 0) / m,
         c.get('SQ_INSTS_VMEM_RD', 0) / m, c.get('SQ_INSTS_VMEM_WR', 0) / m,

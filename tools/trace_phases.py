@@ -17,7 +17,8 @@ from lib import _hip
 want = sys.argv[1] if len(sys.argv) > 1 else ''
 net = A.ac_chain(k_cpt=0.0, seed=1234)((32, 32, 3), (10,))
 eng = net.engine()
-n = 128
+n = int(os.environ.get('BATCH', '128'))
+eng._ensure_capacity(n)
 eng.x0[:n].uniform_(); eng.y[:n].zero_(); eng.y[:n, 0] = 1
 feed = {net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr', net.λ_lrn: 0.1, net.τ: 1.0}
 for _ in range(3): net.train.run(feed)
@@ -70,5 +71,9 @@ for op in ops:
             col = rel2[:, k][r[:, 8 + k] != 0]
             if len(col):
                 print('     %-8s min %6.2f  med %6.2f  max %6.2f us' % (nm, col.min(), np.median(col), col.max()))
+        ok = (units > 1) & (r[:, 3] != 0) & (r[:, 4] != 0)
+        if ok.any():
+            pu = (r[ok, 4] - r[ok, 3]) / 100.0 / (units[ok] - 1)
+            print('     steady state: %.3f us per unit (median; min %.3f max %.3f)' % (np.median(pu), pu.min(), pu.max()))
         d = (r[:, 5] - r[:, 0]) / 100.0
         print('     in-wg time (start->exit): min %.2f med %.2f max %.2f us' % (d.min(), np.median(d), d.max()))
