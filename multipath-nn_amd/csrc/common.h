@@ -53,6 +53,10 @@ static int resident_slots(const void *kernel, int dyn_lds, int threads = 256, in
             if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
         }
         if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;      // (the caller wants fewer, larger shares)
+        {   // experiment: MPNN_SLOTS_PER_CU=<n> overrides the answer (does the chip really host n workgroups of this kernel?)
+            static const int force = [] { const char *e = getenv("MPNN_SLOTS_PER_CU"); return e ? atoi(e) : 0; }();
+            if (force > 0) per_cu = force;
+        }
         if (n_cached < 64) cache[n_cached++] = Entry{kernel, dyn_lds, per_cu, cus, max_per_cu};
     }
     const int free_cus = cus - mpnn_reserved_cus_g;

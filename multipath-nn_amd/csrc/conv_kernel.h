@@ -212,6 +212,11 @@ template <int GK, bool SHIFTED> struct TileGeo {
     static constexpr int N = XItems<GK>::N;
     int pix[N];                       // (n*H + y)*W + x of the halo pixel (0 when out of range)
     int pixs[SHIFTED ? N : 1];        // the same in the un-subsampled pyramid input (ToPyramid's pick)
+    // BYTE offset of the item's float4 in operand A / operand V (pixel * channels + this thread's channel quad; 0 when
+    // out of range): a unit's load address is then scalar base (+ chunk) + one of these -- no vector arithmetic per
+    // unit.  (fp32 MFMAs and vector instructions share the SIMD's ALUs on gfx950: their times ADD, profiles/
+    // r06_mfma_loop_probe.txt, and address arithmetic was most of the 4-6 vector instructions per MFMA.)
+    unsigned offa[N], offv[N];
     unsigned inb;                     // bit k: pixel inside the image and the batch
 };
 // Image of slot `img` of a tile: a mask select over the (uniform) table im[] -- a `?:` chain on a
@@ -226,7 +231,7 @@ __device__ __forceinline__ int pick_img(const int *im, int img) {
 // im != nullptr (routed evaluation): im[j] = image behind slot n0 + j of the tile.
 template <int GK, bool SHIFTED>
 __device__ __forceinline__ void tile_geo(TileGeo<GK, SHIFTED> &tg, const ItemK<GK> &ik, const ConvP &p, int n0, int y0, int x0,
-                                         const int *im = nullptr) {
+                                         const int *im = nullptr, const int aC = 0, const int vC = 0) {
     tg.inb = 0;
 #pragma unroll
     for (int k = 0; k < ItemK<GK>::N; ++k) {
@@ -236,6 +241,8 @@ __device__ __forceinline__ void tile_geo(TileGeo<GK, SHIFTED> &tg, const ItemK<G
                         (XItems<GK>::INTERIOR || ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W));
         const int n = im ? pick_img<Geom<GK>::IMG>(im, ik.geo[k] >> 16) : slot;
         tg.pix[k] = ok ? (n * p.H + y) * p.W + x : 0;
+        tg.offa[k] = ok ? (unsigned)(tg.pix[k] * aC + ik.q * 4) * 4u : 0u;
+        tg.offv[k] = ok ? (unsigned)(tg.pix[k] * vC + ik.q * 4) * 4u : 0u;
         if (SHIFTED) {
             const int sh = p.a.shift;
             tg.pixs[k] = ok ? (n * (p.H << sh) + (y << sh)) * (p.W << sh) + (x << sh) : 0;
@@ -252,7 +259,7 @@ __device__ __forceinline__ void tile_geo(TileGeo<GK, SHIFTED> &tg, const ItemK<G
 //   KIND 2: dgrad: dz and, when BatchNorm-backward is applied on load, s
 template <int GK, int KIND, int XW, bool SHIFTED>
 __device__ __forceinline__ void ld_items(f32x4 (*xr)[XW], const ConvP &p, const TileGeo<GK, SHIFTED> &tg, const ItemK<GK> &ik,
-                                         int part, int c0, int np, const float *src, int C) {
+                                         int part, int c0, int np, const float *src, int C, const bool odd_c) {
     static_assert(KIND != 2 || XW >= 2, "dgrad staging keeps two raw registers per item");
     const int c = c0 + ik.q * 4;
     const bool qin = ik.q < np;
@@ -269,16 +276,17 @@ __device__ __forceinline__ void ld_items(f32x4 (*xr)[XW], const ConvP &p, const 
         }
         return;
     }
-    const float *src2 = p.ga_s;
+    // UNSIGNED 32-bit byte offset from a uniform base: the load takes the scalar-base + 32-bit-offset form (a signed
+    // element offset costs a sign extension and a 64-bit shift-add per load; the host keeps every activation tensor
+    // below 4 GB).  The chunk's channel offset goes into the SCALAR base, the per-thread part was computed with the tile.
+    const char *sb = (const char *)src + (size_t)c0 * 4, *sb2 = (const char *)p.ga_s + (size_t)c0 * 4;
+    (void)c;
 #pragma unroll
     for (int k = 0; k < ItemK<GK>::N; ++k) {
-        const bool live = qin && ((tg.inb >> k) & 1);
-        // UNSIGNED 32-bit byte offset from a uniform base: the load takes the scalar-base + 32-bit-offset form
-        // (a signed element offset costs a sign extension and a 64-bit shift-add per load; the host keeps every
-        // activation tensor below 4 GB)
-        const unsigned off = live ? (unsigned)(tg.pix[k] * C + c) * 4u : 0u;
-        xr[k][0] = *(const f32x4 *)((const char *)src + off);
-        if (KIND == 2 && p.ga_on) xr[k][1 % XW] = *(const f32x4 *)((const char *)src2 + off);      // (uniform)
+        unsigned off = (KIND != 2 && part) ? tg.offv[k] : tg.offa[k];
+        if (odd_c) off = qin ? off : 0u;           // (uniform: a channel count that is not a multiple of 16 somewhere)
+        xr[k][0] = *(const f32x4 *)(sb + off);
+        if (KIND == 2 && p.ga_on) xr[k][1 % XW] = *(const f32x4 *)(sb2 + off);      // (uniform)
     }
 }
 // transform + LDS store of one chunk; `inb` is the tile's in-bounds mask the chunk was loaded with
@@ -313,11 +321,9 @@ __device__ __forceinline__ void st_items(f32x4 *tile, const f32x4 (*xr)[XW], con
         } else if (MODE == 0) {
             if (p.a.mode != MPNN_ACT_IDENTITY) {       // uniform
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float t = fmaxf((v[j] - cc[j][0]) * cc[j][1] + cc[j][2], 0.f);
-                    v[j] = (c + j < p.a.C) ? t : 0.f;
-                }
-            } else if (p.a.C & 3) {                    // uniform
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf((v[j] - cc[j][0]) * cc[j][1] + cc[j][2], 0.f);
+            }
+            if (p.a.C & 3) {                           // uniform (a live quad of a count % 4 == 0 has all four channels)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = (c + j < p.a.C) ? v[j] : 0.f;
             }
@@ -421,12 +427,17 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         const int c4 = i % CT, tg = i / CT, gg = tg & 3, tap = tg >> 2;
         return tap * 16 * p.Cout * nch + (gg * p.Cout + co0 + c4) * 4;
     };
+    // ... as BYTE offsets, once per kernel, for both operands' chunk counts (a unit adds its chunk to the scalar base)
+    unsigned wofA[BN], wofV[BN];
     // The unit sequence is generated incrementally (no divisions): chunk, then operand part, then tile.
     struct UI { int t, part, ch, np, n0, y0, x0; unsigned inb; int im[IDX ? G::IMG : 1]; };
     TileGeo<GK, SMALL_A> tgeo;                       // geometry of the tile the generator stands on
     UI gen = {};
-    const int aC = p.a.C, vC = p.Cv;
+    const int aC = p.a.C, vC = HAS_V ? p.Cv : 0;
     const float *const aX = p.a.x, *const vX = p.v, *const wAp = p.wa, *const wVp = p.wv;
+    const bool odd_c = ((aC | vC) & 15) != 0;        // (uniform) some chunk has fewer than four channel quads
+#pragma unroll
+    for (int k = 0; k < BN; ++k) { wofA[k] = (unsigned)w_off(k, nchA) * 4u; wofV[k] = (unsigned)w_off(k, nchV) * 4u; }
     auto set_np = [&](UI &r) {
         const int C = HAS_V ? sel_i(r.part, aC, vC) : aC;
         r.np = (C - r.ch * 16 + 3) >> 2;           // channel quads left from this chunk on (may exceed 4)
@@ -437,9 +448,9 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         if constexpr (IDX) {                         // (uniform loads; slots past the count read slot 0 and are masked)
 #pragma unroll
             for (int j = 0; j < G::IMG; ++j) r.im[j] = p.idx[r.n0 + j < p.n ? r.n0 + j : 0];
-            tile_geo<GK, SMALL_A>(tgeo, ik, p, r.n0, r.y0, r.x0, r.im);
+            tile_geo<GK, SMALL_A>(tgeo, ik, p, r.n0, r.y0, r.x0, r.im, aC, vC);
         } else
-        tile_geo<GK, SMALL_A>(tgeo, ik, p, r.n0, r.y0, r.x0);
+        tile_geo<GK, SMALL_A>(tgeo, ik, p, r.n0, r.y0, r.x0, nullptr, aC, vC);
         r.inb = tgeo.inb;
         set_np(r);
     };
@@ -459,18 +470,18 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         // (operand selects on LOCALS: a select between two fields of the by-value kernel argument
         // was compiled to a scratch-memory table indexed by `part`)
         const float *src = HAS_V ? sel_p(q.part, aX, vX) : aX, *wp = HAS_V ? sel_p(q.part, wAp, wVp) : wAp;
-        const int C = HAS_V ? sel_i(q.part, aC, vC) : aC, nch = HAS_V ? sel_i(q.part, nchA, nchV) : nchA;
+        const int C = HAS_V ? sel_i(q.part, aC, vC) : aC;
 #pragma unroll
         for (int sc = 0; sc < SC; ++sc) {
             const int cs = KSPLIT ? kg : sc;           // chunk of the unit this thread group handles
-            ld_items<GK, LK, XW, SMALL_A>(xq + sc * XN, p, tgeo, ik, q.part, (q.ch + cs) * 16, q.np - 4 * cs, src, C);
+            ld_items<GK, LK, XW, SMALL_A>(xq + sc * XN, p, tgeo, ik, q.part, (q.ch + cs) * 16, q.np - 4 * cs, src, C, odd_c);
         }
 #pragma unroll
         for (int sc = 0; sc < SC; ++sc) {
             const int cs = KSPLIT ? kg : sc;
-            const int uo = (q.ch + cs) * 16 * p.Cout;
+            const char *wb = (const char *)wp + (size_t)((q.ch + cs) * 16 * p.Cout) * 4;       // (uniform: the unit's chunk)
 #pragma unroll
-            for (int k = 0; k < BN; ++k) bq[sc * BN + k] = *(const f32x4 *)((const char *)wp + (unsigned)(w_off(k, nch) + uo) * 4u);
+            for (int k = 0; k < BN; ++k) bq[sc * BN + k] = *(const f32x4 *)(wb + ((HAS_V && q.part) ? wofV[k] : wofA[k]));
         }
     };
     auto unit_store = [&](const UI &q, f32x4 (*xq)[XW], f32x4 *bq, int buf, bool with_b) {
