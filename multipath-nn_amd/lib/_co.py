@@ -64,6 +64,7 @@ class CoTrainer:
         self.use_graph = e0.use_graph
         self._progs, self._graphs, self._keep, self._gens = {}, {}, [], None
         self.prologue = None             # callable(stream): ONE launch that assembles every net's batch (Dataset.bind_cotrainer)
+        self.prologue_slot = None        # callable(stream, j): the same for step j of a K-step joint graph
 
     # ------------------------------------------------------------------ the merged program
     def _program(self, n):
@@ -118,6 +119,8 @@ class CoTrainer:
                 recs = [r for o in ops for r in o.host]
                 dev = table(recs)
                 merged.append(launch_of(o0.fn, what, flops, tag, dev.data_ptr(), len(recs), *o0.args[2:]))
+                merged[-1].fn, merged[-1].host = o0.fn, recs             # (run_steps builds per-step copies of this table)
+                merged[-1].first = [sum(len(q.host) for q in ops[:r]) for r in range(K)]      # net r's first record
             elif what == 'route':
                 arr = (_hip.RouteArgs * K)(*[o.host for o in ops])
                 dev = table(list(arr))
@@ -226,10 +229,130 @@ class CoTrainer:
             e.last_n, e.last_mode, e._last_fold = n, 'tr', prog['fold']
             e._bind_views(n)
 
-    def set_prologue(self, fn):
-        """fn(stream): the first launch of every joint step (replaces the nets' own prologues in the joint graph)."""
-        self.prologue = fn
+    def set_prologue(self, fn, fn_slot=None):
+        """fn(stream): the first launch of every joint step (replaces the nets' own prologues in the joint graph);
+        fn_slot(stream, j): the same for step j of a K-step joint graph (run_steps), reading record slot j."""
+        self.prologue, self.prologue_slot = fn, fn_slot
         self._graphs.clear()
+
+    STEPS_MAX = 8                       # most joint steps in one hipGraph (as Engine.STEPS_MAX: the record slots of lib/data.py)
+
+    def run_steps(self, feeds_k):
+        """S joint training steps as ONE hipGraph replay: feeds_k[j][i] is net i's feed at step j (same results, bit for
+        bit, as S calls of run()).  What changes from step to step is data: the S x K rows of schedule values travel in
+        one upload into a device ring and are copied into every net's `hyp` row by the head workgroup of the net's first
+        record of the step's own mpnn_exit_tail_fwd launch (mpnn_exit_tail_args.hyp_src / hyp_dst, as Engine.run_steps);
+        with the input pipeline bound (Dataset.bind_cotrainer) launch 0 of step j gathers every net's batch from record
+        slot j (Dataset.stage_cotrainer_draws_k).  Falls back to S calls of run() where the form does not apply (eager
+        launches, per-sample k_cpt, feeds that are neither bound nor the engines' resident buffers)."""
+        from lib._plan import BoundInput
+        S, K = len(feeds_k), self.K
+        if any(len(f) != K for f in feeds_k):
+            raise ValueError('one feed per co-trained net and step')
+
+        def one_by_one():
+            slots = getattr(self, 'prologue_slot', None) is not None and \
+                all(isinstance(f[net.x0], BoundInput) for fs in feeds_k for net, f in zip(self.nets, fs))
+            keep_p, keep_g = self.prologue, self.use_graph
+            try:
+                for j, fs in enumerate(feeds_k):
+                    if slots and j > 0:             # (slot 0 is what the one-step graph reads)
+                        self.prologue, self.use_graph = (lambda st, j=j: self.prologue_slot(st, j)), False
+                    self.run(fs)
+            finally:
+                self.prologue, self.use_graph = keep_p, keep_g
+        ok = 1 < S <= self.STEPS_MAX and self.use_graph
+        ok = ok and not any(bool(getattr(net.hypers, 'dyn_k_cpt', False)) for net in self.nets)
+        if ok:
+            for fs in feeds_k:
+                for net, e, f in zip(self.nets, self.engs, fs):
+                    x, y = f[net.x0], f[net.y]
+                    bound = isinstance(x, BoundInput) and isinstance(y, BoundInput) and x.eng is e and y.eng is e and \
+                        getattr(self, 'prologue_slot', None) is not None
+                    same = isinstance(x, torch.Tensor) and isinstance(y, torch.Tensor) and x.data_ptr() == e.x0.data_ptr() and \
+                        y.data_ptr() == e.y.data_ptr() and self.prologue is None and e.prologue is None
+                    ok = ok and (bound or same) and f.get(net.mode, net.mode.default) == 'tr'
+            ns = {int(f[net.x0].shape[0]) for fs in feeds_k for net, f in zip(self.nets, fs)}
+            ok = ok and len(ns) == 1
+        if not ok:
+            return one_by_one()
+        n = ns.pop()
+        key = ('K', n, S)
+        g = self._graphs.get(key)
+        if g is None:
+            one_by_one()                                        # (first call: loads the code objects, settles the capacities)
+            self._graphs[key] = 'warm'
+            return
+        prog = self._program(n)
+        if not prog['fold']:
+            return one_by_one()
+        # the S x K rows of schedule values: one asynchronous upload through a ring of pinned buffers
+        if not hasattr(self, '_hypk'):
+            self._hypk = torch.zeros(self.STEPS_MAX, K, _hip.HYP_N, device=self.dev)
+            self._hypk_ring = [(torch.zeros(self.STEPS_MAX, K, _hip.HYP_N).pin_memory(), None) for _ in range(8)]
+            self._hypk_slot, self._hypk_sent = -1, None
+        hs = torch.stack([torch.stack([e._hyp_values(f, n).clone() for e, f in zip(self.engs, fs)]) for fs in feeds_k])
+        if self._hypk_sent is None or self._hypk_sent.shape != hs.shape or not torch.equal(hs, self._hypk_sent):
+            r = self._hypk_slot = (self._hypk_slot + 1) % len(self._hypk_ring)
+            buf, ev = self._hypk_ring[r]
+            if ev is not None:
+                ev.synchronize()
+            buf[:S].copy_(hs)
+            self._hypk[:S].copy_(buf[:S], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._hypk_ring[r] = (buf, ev)
+            self._hypk_sent = hs
+        self._hyp_sent = None                                   # (the graph rewrites every net's hyp row on the device)
+        for e in self.engs:
+            e._hyp_sent = None
+            e._hyp_epoch = getattr(e, '_hyp_epoch', 0) + 1
+            if not e._packs_fresh:
+                e._pack()
+                e._packs_fresh = True
+        if g == 'warm':
+            torch.cuda.synchronize()
+            for e in self.engs:                                 # (captured without clearing launches)
+                if not e._acc_clean:
+                    e._begin(True)
+                    e._acc_clean = True
+            tails = [op for op in prog['ops'] if op.what == 'exit_tail_fwd']
+            assert len(tails) == 1 and getattr(tails[0], 'host', None)
+            tail = tails[0]
+            first = getattr(tail, 'first', [0])
+            tabs = []
+            for j in range(S):
+                recs = []
+                for i, rec in enumerate(tail.host):
+                    c = type(rec)()
+                    C.memmove(C.byref(c), C.byref(rec), C.sizeof(rec))
+                    if i in first:
+                        k = first.index(i)
+                        c.hyp_src, c.hyp_dst = self._hypk[j, k].data_ptr(), self.engs[k].hyp.data_ptr()
+                    recs.append(c)
+                tabs.append(_hip.to_device_table(recs, self.dev))
+            self._keep += tabs
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                st = torch.cuda.current_stream().cuda_stream
+                for j in range(S):
+                    if getattr(self, 'prologue_slot', None) is not None:
+                        self.prologue_slot(st, j)
+                    for op in prog['ops']:
+                        if op is tail:
+                            _hip.check(op.fn(tabs[j].data_ptr(), *op.args[1:], st), 'exit_tail_fwd')
+                        else:
+                            op(st)
+            self._graphs[key] = g
+        for e in self.engs:
+            if not e._acc_clean:                                # something outside run() left the accumulators dirty
+                e._begin(True)
+            e._acc_clean = False
+        g.replay()
+        for e in self.engs:
+            e._acc_clean = True
+            e.last_n, e.last_mode, e._last_fold = n, 'tr', True
+            e._bind_views(n)
 
     def invalidate(self):
         """Drop the merged programs and graphs (an engine reallocated its buffers: a larger batch came by)."""
@@ -352,9 +475,19 @@ def concurrent_streams(dev, want, candidates=12, us=60.0):
     import os
     import time
     lib = _hip.load()
-    cands = [torch.cuda.Stream(device=dev) for _ in range(max(candidates, want))]
+    # ONE calibration per process and device: the streams found (and the candidates) are kept, so that every plan of a run
+    # sees the same answer -- a second measurement on a loaded host could classify differently, change the split of the
+    # groups and with it the summation order of the trained nets -- and no call leaks a dozen streams.
+    cache = _STREAM_CACHE.setdefault(str(dev), {})
+    if 'cands' not in cache:
+        cache['cands'] = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
+    while len(cache['cands']) < want:
+        cache['cands'].append(torch.cuda.Stream(device=dev))
+    cands = cache['cands']
     if want <= 1 or os.environ.get('MPNN_CO_CALIBRATE', '1') == '0':
         return cands[:want]
+    if 'chosen' in cache and (len(cache['chosen']) >= want or cache.get('exhausted')):
+        return cache['chosen'][:want]
     for c in cands:
         _hip.check(lib.mpnn_debug_noop(c.cuda_stream), 'noop')        # (the first launch on a stream binds its queue)
     torch.cuda.synchronize(dev)
@@ -379,7 +512,11 @@ def concurrent_streams(dev, want, candidates=12, us=60.0):
             break
         if all(together(c, s) for s in chosen):
             chosen.append(c)
+    cache['chosen'], cache['exhausted'] = chosen, len(chosen) < want
     return chosen
+
+
+_STREAM_CACHE = {}
 
 
 def _arch_signature(net):

@@ -180,20 +180,30 @@ class Dataset:
         self._bufs = {}
         return self
 
-    def _draw_buffers(self, n, key=None):
-        """The static device record buffer + its ring of pinned upload buffers for one consumer (key None: the dataset's
+    def _draw_buffers(self, n, eng=None):
+        """The static device record buffer + its ring of pinned upload buffers for one consumer (eng None: the dataset's
         own; an engine bound with bind_engine has its own set, so that several engines -- the nets of a co-trained
-        group -- each read the batch staged for THEM)."""
+        group -- each read the batch staged for THEM).  An engine's set is stored ON the engine (per dataset), so it
+        lives exactly as long as its consumer: a table keyed by id(eng) outlived collected engines and could hand a NEW
+        engine (CPython reuses ids) the buffers of a dead one."""
         import torch
         from . import _hip
         if getattr(self, '_x_dev', None) is None:
             raise _hip.HipError('Dataset.to_device() first: the augmentation kernel gathers from device memory')
-        bufs = self.__dict__.setdefault('_bufs', {})
-        b = bufs.get(key)
+        if eng is None:
+            if self.__dict__.get('_bound_engines'):
+                raise ValueError('an engine is bound to this dataset (bind_engine): stage its batches with '
+                                 'stage_training_draws(n, eng=eng) -- the dataset\'s own record buffer is not what its step reads')
+            holder = self.__dict__.setdefault('_bufs', {})
+            key = None
+        else:
+            holder = eng.__dict__.setdefault('_draw_bufs', {})
+            key = id(self)
+        b = holder.get(key)
         if b is None or b['ring'][0][0].shape[0] < n:
             # dev: SLOTS record buffers -- slot j feeds step j of a K-step graph (Engine.run_steps), slot 0 the one-step graph
-            b = bufs[key] = dict(ring=[(torch.zeros((n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING * self.SLOTS)],
-                                 slot=-1, dev=torch.zeros((self.SLOTS, n, 4), dtype=torch.int32, device=self._dev))
+            b = holder[key] = dict(ring=[(torch.zeros((n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING * self.SLOTS)],
+                                   slot=-1, dev=torch.zeros((self.SLOTS, n, 4), dtype=torch.int32, device=self._dev))
         return b
 
     def stage_training_draws(self, n=128, r_shift=4, eng=None, slot=0):
@@ -203,7 +213,7 @@ class Dataset:
         after the event behind its last copy has completed (under hipGraph replay the host runs several steps ahead of the
         stream)."""
         import torch
-        b = self._draw_buffers(n, None if eng is None else id(eng))
+        b = self._draw_buffers(n, eng)
         k = b['slot'] = (b['slot'] + 1) % len(b['ring'])
         buf, ev = b['ring'][k]
         if ev is not None:
@@ -220,7 +230,7 @@ class Dataset:
         the one numpy stream) with ONE upload: a small copy on the compute stream in front of a replay costs ~8 us.
         between(j) runs right after step j's draws (the caller's own per-iteration draws keep their place in the stream)."""
         import torch
-        b = self._draw_buffers(n, None if eng is None else id(eng))
+        b = self._draw_buffers(n, eng)
         if K > self.SLOTS:
             raise ValueError('at most %d record slots' % self.SLOTS)
         if 'ringk' not in b:
@@ -277,7 +287,8 @@ class Dataset:
         # the engine's own draw buffer and upload ring, allocated WITHOUT drawing: a draw here would consume a batch of the
         # numpy stream and offset every later batch against the reference's call sequence (scripts/lib/data.py:24-34).
         # Stage every step's records with stage_training_draws(n, eng=eng).
-        draws = self._draw_buffers(n, id(eng))['dev']
+        draws = self._draw_buffers(n, eng)['dev']
+        self.__dict__['_bound_engines'] = self.__dict__.get('_bound_engines', 0) + 1
         # the engine's buffers are resolved when the launch is issued (eagerly or into a capture; the engine drops its
         # graphs whenever it reallocates them), never held as views: see _plan.BoundInput
         eng.set_prologue(lambda stream: self._augment_launch(n, eng.x0[:n], eng.y[:n], stream, draws[0]),
@@ -294,24 +305,29 @@ class Dataset:
         bound = [self.bind_engine(e, n) for e in co.engs]
         K = len(co.engs)
         h, w, c = self.x0_tr.shape[1:]
-        g = dict(n=n, dev=torch.zeros((K, n, 4), dtype=torch.int32, device=self._dev), slot=-1,
-                 ring=[(torch.zeros((K, n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING)])
-        self.__dict__.setdefault('_groups', {})[id(co)] = g
+        # dev: SLOTS record buffers [K, n, 4] -- slot j feeds step j of a K-step joint graph (CoTrainer.run_steps), slot 0
+        # the one-step graph.  The group's buffers live on the co-trainer (as an engine's on the engine).
+        g = dict(n=n, dev=torch.zeros((self.SLOTS, K, n, 4), dtype=torch.int32, device=self._dev), slot=-1,
+                 ring=[(torch.zeros((self.SLOTS, K, n, 4), dtype=torch.int32).pin_memory(), None) for _ in range(self.RING)])
+        co.__dict__.setdefault('_draw_group', {})[id(self)] = g
         state = {}
 
-        def launch(stream):
+        def launch_slot(stream, j):
             key = tuple(e._gen for e in co.engs)              # (the engines' input buffers may have been reallocated)
             if state.get('key') != key:
-                recs = []
-                for k, e in enumerate(co.engs):
-                    d = _hip.AugmentDst()
-                    d.draw, d.x_out, d.y_out = g['dev'][k].data_ptr(), e.x0.data_ptr(), e.y.data_ptr()
-                    recs.append(d)
-                state['key'], state['tab'] = key, _hip.to_device_table(recs, self._dev)
-            _hip.check(_hip.load().mpnn_augment_batch_multi(self._x_dev.data_ptr(), self._y_dev.data_ptr(), state['tab'].data_ptr(),
+                tabs = []
+                for jj in range(self.SLOTS):
+                    recs = []
+                    for k, e in enumerate(co.engs):
+                        d = _hip.AugmentDst()
+                        d.draw, d.x_out, d.y_out = g['dev'][jj, k].data_ptr(), e.x0.data_ptr(), e.y.data_ptr()
+                        recs.append(d)
+                    tabs.append(_hip.to_device_table(recs, self._dev))
+                state['key'], state['tabs'] = key, tabs
+            _hip.check(_hip.load().mpnn_augment_batch_multi(self._x_dev.data_ptr(), self._y_dev.data_ptr(), state['tabs'][j].data_ptr(),
                                                              K, n, h, w, c, self.y_tr.shape[1], stream),
                        'augment_batch_multi')
-        co.set_prologue(launch)
+        co.set_prologue(lambda stream: launch_slot(stream, 0), launch_slot)
         return bound
 
     def serial_positions(self, positions, iters, n=128, r_shift=4, seed=0):
@@ -333,19 +349,28 @@ class Dataset:
         """One step's augmentation records of EVERY net of a bound group: the reference's draws, net after net, from the one
         numpy stream -- or, with streams (one DrawStream per net), every net from its own; one asynchronous upload for the
         whole group."""
+        self.stage_cotrainer_draws_k(co, 1, r_shift, streams)
+
+    def stage_cotrainer_draws_k(self, co, S, r_shift=4, streams=None):
+        """stage_cotrainer_draws for the S steps of one K-step joint graph replay (record slots 0 .. S-1) with ONE upload.
+        Draw order: step after step, within a step net after net (the order of S single-step calls); with streams every
+        net draws its S batches from its own DrawStream -- net r's j-th batch is the j-th batch it sees in the serial loop."""
         import torch
-        g = self._groups[id(co)]
+        g = co.__dict__['_draw_group'][id(self)]
+        if S > self.SLOTS:
+            raise ValueError('at most %d record slots' % self.SLOTS)
         k = g['slot'] = (g['slot'] + 1) % len(g['ring'])
         buf, ev = g['ring'][k]
         if ev is not None:
             ev.synchronize()
         out = buf.numpy()
-        for r in range(out.shape[0]):
-            if streams is not None:                # (net r's own stream: DrawStream, e.g. its position in the serial loop)
-                streams[r].draw(g['n'], len(self.x0_tr), self._sym_u8, r_shift, out=out[r])
-            else:
-                _draw_augmentation_fast(g['n'], len(self.x0_tr), self._sym_u8, r_shift, out=out[r], all_sym=self._all_sym)
-        g['dev'].copy_(buf, non_blocking=True)
+        for j in range(S):
+            for r in range(out.shape[1]):
+                if streams is not None:            # (net r's own stream: DrawStream, e.g. its position in the serial loop)
+                    streams[r].draw(g['n'], len(self.x0_tr), self._sym_u8, r_shift, out=out[j, r])
+                else:
+                    _draw_augmentation_fast(g['n'], len(self.x0_tr), self._sym_u8, r_shift, out=out[j, r], all_sym=self._all_sym)
+        g['dev'][:S].copy_(buf[:S], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         g['ring'][k] = (buf, ev)

@@ -387,3 +387,75 @@ def test_cotrained_random_trees_and_architectures_equal_the_solo_steps(seed):
         cg.run(feeds)
         cg.join()
     _compare_with_solo_steps(co_nets, solo, run, cg.share, n, steps=3)
+
+
+@pytest.mark.parametrize('kind,K,S', [('ac', 3, 4), ('cr', 2, 3), ('ac', 1, 2)])
+def test_k_step_joint_replay_equals_k_joint_steps(kind, K, S):
+    """CoTrainer.run_steps: S joint steps captured as ONE hipGraph (per-step schedule values from a device ring, copied into
+    every net's hyp row by the step's own mpnn_exit_tail_fwd) == S calls of run(), BIT FOR BIT -- parameters, momentum,
+    BatchNorm state of every net -- on the engines' resident input buffers (different learning rates / temperatures per
+    step and per net, so a wrong or stale row would show)."""
+    import arch_and_hypers as A
+    from lib._co import CoTrainer
+    ks = A.k_cpts
+    mk = {'ac': lambda i: A.ac_chain(k_cpt=ks[i % 8]), 'cr': lambda i: A.cr_chain(k_cpt=ks[i % 8])}[kind]
+    a_nets, b_nets = _nets([mk(i) for i in range(K)]), _nets([mk(i) for i in range(K)])
+    n = 32
+    for nets in (a_nets, b_nets):
+        for i, net in enumerate(nets):
+            e = net.engine()
+            e._ensure_capacity(n)
+            x0, y = batch(n, seed=40 + i)
+            e.x0[:n].copy_(torch.from_numpy(x0)); e.y[:n].copy_(torch.from_numpy(y))
+    co_a, co_b = CoTrainer(a_nets), CoTrainer(b_nets)
+
+    def feeds(nets, t):
+        return [{net.x0: net.engine().x0[:n], net.y: net.engine().y[:n], net.mode: 'tr', net.λ_lrn: 0.05 / (1 + t) * (1 + 0.1 * i),
+                 net.τ: 0.5 + 0.07 * t + 0.1 * i} for i, net in enumerate(nets)]
+    for rnd in range(4):                                      # warm-up, capture + replay, replays
+        co_a.run_steps([feeds(a_nets, rnd * S + j) for j in range(S)])
+        for j in range(S):
+            co_b.run(feeds(b_nets, rnd * S + j))
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(a_nets, b_nets)):
+            ea, eb = a.engine(), b.engine()
+            assert torch.equal(ea.P, eb.P) and torch.equal(ea.A, eb.A) and torch.equal(ea.S, eb.S), (rnd, i)
+            for la, lb in zip(a.layers, b.layers):
+                assert torch.equal(la.p_tr, lb.p_tr) and torch.equal(la.p_ev, lb.p_ev), (rnd, i, la.name)
+    assert any(k[0] == 'K' and not isinstance(v, str) for k, v in co_a._graphs.items() if isinstance(k, tuple)), 'no K-step graph was captured'
+
+
+def test_k_step_joint_replay_through_the_input_pipeline():
+    """... and with the input pipeline bound (Dataset.bind_cotrainer): launch 0 of step j of the joint graph gathers every
+    net's batch from record slot j; stage_cotrainer_draws_k draws the S x K batches (every net from its own DrawStream: the
+    batches of the serial loop) and uploads them at once.  Same parameters, bit for bit, as single joint steps fed from the
+    same streams."""
+    import arch_and_hypers as A
+    from lib._co import CoTrainer
+    from lib.data import Dataset
+    K, S, n, T = 3, 4, 32, 12
+    runs = []
+    for form in ('k', 'single'):
+        ds = Dataset.synthetic(n_tr=300, n_ts=140, seed=1)
+        ds.to_device('cuda:0')
+        nets = _nets([A.ac_chain(k_cpt=k) for k in (0.0, 1e-9, 4e-9)])
+        co = CoTrainer(nets)
+        bound = ds.bind_cotrainer(co, n)
+        streams = ds.serial_positions(list(range(K)), T, n, seed=11)
+        feeds = lambda t: [{net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.05 / (1 + t), net.τ: 1.0 - 0.02 * t}
+                           for net, (x0, y) in zip(nets, bound)]
+        t = 0
+        while t < T:
+            if form == 'k':
+                ds.stage_cotrainer_draws_k(co, S, streams=streams)
+                co.run_steps([feeds(t + j) for j in range(S)])
+                t += S
+            else:
+                ds.stage_cotrainer_draws(co, streams=streams)
+                co.run(feeds(t))
+                t += 1
+        torch.cuda.synchronize()
+        runs.append([(net.engine().P.clone(), net.engine().S.clone(), net.engine().x0[:n].clone()) for net in nets])
+    for i, (a, b) in enumerate(zip(*runs)):
+        assert torch.equal(a[2], b[2]), ('the last batch of net %d differs' % i)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), i
