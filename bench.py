@@ -160,10 +160,19 @@ def measure_dp_structure(net, eng, feed, single_ms):
         for _ in range(5):
             net.train.run(feed)
         torch.cuda.synchronize()
-        ms = time_replays(lambda: net.train.run(feed), 200)
+        ms1 = time_replays(lambda: net.train.run(feed), 200)
         key = [k for k in eng._graphs if k[0] == 'tr' and k[2]][0]
         whole = eng._graphs[key][1] == 'whole'
+        # the form the multi-GPU run takes: K steps -- K all-reduces -- per hipGraph replay, as the single-process headline
+        K = 4
+        for _ in range(3):
+            net.train.run_steps([feed] * K)
+        torch.cuda.synchronize()
+        kk = [k for k in eng._graphs if k[0] == 'trK' and k[-1]]
+        k_captured = bool(kk) and not isinstance(eng._graphs[kk[0]], str)
+        ms = time_replays(lambda: net.train.run_steps([feed] * K), 50, chunk=5) / K if k_captured else ms1
         return {'ms_per_step': ms, 'ms_per_step_single_graph': single_ms, 'ratio': ms / single_ms,
+                'steps_per_graph': K if k_captured else 1, 'ms_per_step_one_step_graphs': ms1, 'ratio_one_step_graphs': ms1 / single_ms,
                 'buckets': list(eng.dp_buckets), 'collectives_per_step': len(eng.dp_buckets), 'rccl_ranks': dist.get_world_size(),
                 'reserved_cus': eng.dp_reserve_cus, 'per_bucket_update': bool(eng._bucket_opt_on()),
                 'form': 'ONE hipGraph per step: bucket sections + RCCL all-reduces (captured on the process group\'s stream) + optimizer'
@@ -350,9 +359,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # K training steps per hipGraph replay (single process; under data parallelism one graph per step): the ~8.6 us the
-    # GPU idles between two replays of a one-step graph are paid once per K steps.  `steps` counts training steps.
-    spg = max(1, min(args.steps_per_graph, eng.STEPS_MAX)) if (world == 1 and eng.use_graph and not args.streams) else 1
+    # K training steps per hipGraph replay -- single process AND data parallel (where the step's all-reduce is captured: K
+    # steps hold K all-reduces; Engine.run_steps falls back to one step per replay where collectives do not capture): the
+    # ~8.6 us the GPU idles between two replays of a one-step graph are paid once per K steps.  `steps` counts training steps.
+    spg = max(1, min(args.steps_per_graph, eng.STEPS_MAX)) if (eng.use_graph and not args.streams) else 1
 
     def run_steps(k):
         done = 0

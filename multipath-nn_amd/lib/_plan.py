@@ -1875,13 +1875,22 @@ class Engine:
         (dyn_k_cpt nets) ride in a device ring like the schedule values; the launches that read them get per-step records."""
         net, K = self.net, len(feeds)
         dyn = bool(getattr(net.hypers, 'dyn_k_cpt', False))
-        ok = 1 < K <= self.STEPS_MAX and self.use_graph and self.allreduce is None and not self.multi_stream
+        # data parallel: only the form in which the whole step -- its collectives included -- is ONE captured graph
+        # (lib/_dp.py: RCCL, self-tested); K steps then hold K all-reduces.  The section-graph form issues its collectives
+        # from the host between replays and stays one step at a time.
+        dp = self.allreduce is not None
+        ok = 1 < K <= self.STEPS_MAX and self.use_graph and not self.multi_stream and \
+            (not dp or (self.dp_one_graph and self.allreduce_capturable and not self._bucket_opt_on() and getattr(self, '_k_dp_ok', True)))
         if ok:
             xs = [f[net.x0] for f in feeds]
-            bound = all(isinstance(x, BoundInput) for x in xs)
+            ys = [f[net.y] for f in feeds]
+            # every feed names THIS engine's inputs, x0 and y alike, and one batch size (a mixed list would be captured and
+            # replayed with step 0's shapes)
+            bound = all(isinstance(x, BoundInput) and isinstance(y, BoundInput) and x.eng is self and y.eng is self
+                        for x, y in zip(xs, ys)) and len({x.n for x in xs} | {y.n for y in ys}) == 1
             same = all(isinstance(x, torch.Tensor) and x.data_ptr() == xs[0].data_ptr() and x.shape == xs[0].shape for x in xs) and \
                 isinstance(xs[0], torch.Tensor) and xs[0].data_ptr() == self.x0.data_ptr() and \
-                all(isinstance(f[net.y], torch.Tensor) and f[net.y].data_ptr() == self.y.data_ptr() for f in feeds)
+                all(isinstance(y, torch.Tensor) and y.data_ptr() == self.y.data_ptr() and y.shape[0] == xs[0].shape[0] for y in ys)
             ok = (bound and self.prologue_slot is not None) or (same and self.prologue is None)
             ok = ok and all(f.get(net.mode, net.mode.default) == 'tr' for f in feeds)
         def one_by_one():
@@ -1898,14 +1907,16 @@ class Engine:
         if not ok:
             return one_by_one()
         n = int(xs[0].shape[0])
-        key = ('trK', n, K, self.bwd_levels, self.fold_clear)
+        # (every planner setting that selects the program is part of the key: a graph captured from another program must
+        # not be replayed after a switch)
+        key = ('trK', n, K, self.bwd_levels, self.fold_clear, self.fuse_opt, self.co_share, dp)
         g = self._graphs.get(key)
         if g is None:
             one_by_one()                                        # (first call: the single-step path loads the code objects)
             self._graphs[key] = 'warm'
             return
         prog = self.program('tr', n)
-        if not (prog.get('fold') and prog.get('fused_opt')):
+        if not (prog.get('fold') and (prog.get('fused_opt') or dp)):
             return one_by_one()
         if len(self._event_keep) > 4096:
             torch.cuda.synchronize()
@@ -2007,21 +2018,59 @@ class Engine:
                             c.k_cpt_vec = kp
                             ktabs[(j, id(op))] = c
                 self._keep += list(ktabs.values())
+            def step_op(j, op):
+                """Launch `op` as step j of the graph runs it: its own records where they differ from step to step."""
+                if op.what == 'exit_tail_fwd':
+                    fn = lambda st: _hip.check(op.fn(tabs[j].data_ptr(), *op.args[1:], st), 'exit_tail_fwd')
+                elif (j, id(op)) in ktabs and op.what == 'route':
+                    fn = lambda st: _hip.check(op.fn(C.byref(ktabs[(j, id(op))]), st), 'route')
+                elif (j, id(op)) in ktabs:
+                    fn = lambda st: _hip.check(op.fn(ktabs[(j, id(op))].data_ptr(), *op.args[1:], st), op.what)
+                else:
+                    return op
+                for a in ('what', 'tag', 'flops', 'reserve'):
+                    if hasattr(op, a):
+                        setattr(fn, a, getattr(op, a))
+                return fn
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
-                st = torch.cuda.current_stream().cuda_stream
-                for j in range(K):
-                    if self.prologue_slot is not None:
-                        self.prologue_slot(st, j)
-                    for op in ops:
-                        if op.what == 'exit_tail_fwd':
-                            _hip.check(op.fn(tabs[j].data_ptr(), *op.args[1:], st), 'exit_tail_fwd')
-                        elif (j, id(op)) in ktabs and op.what == 'route':
-                            _hip.check(op.fn(C.byref(ktabs[(j, id(op))]), st), 'route')
-                        elif (j, id(op)) in ktabs:
-                            _hip.check(op.fn(ktabs[(j, id(op))].data_ptr(), *op.args[1:], st), op.what)
-                        else:
-                            op(st)
+            if not dp:
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                    st = torch.cuda.current_stream().cuda_stream
+                    for j in range(K):
+                        if self.prologue_slot is not None:
+                            self.prologue_slot(st, j)
+                        for op in ops:
+                            step_op(j, op)(st)
+            else:
+                # K data-parallel steps, each with its gradient all-reduce(s) on the process group's stream and the optimizer
+                # behind them, captured as ONE graph: the one-step form (_run_graphed: `_step_eager` under capture) K times
+                # with step j's records.  Every rank must end up with the same form: the ranks agree on the outcome.
+                err = None
+                if self.dp_quiesce is not None:
+                    self.dp_quiesce()
+                keep_p = self.prologue
+                try:
+                    with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                        for j in range(K):
+                            if self.prologue_slot is not None:
+                                self.prologue = lambda st, j=j: self.prologue_slot(st, j)
+                            prog_j = dict(prog, fwd=[step_op(j, op) for op in prog['fwd']], bwd=[step_op(j, op) for op in prog['bwd']])
+                            self._step_eager(prog_j, True, n)
+                except Exception as e:
+                    err = e
+                finally:
+                    self.prologue = keep_p
+                torch.cuda.synchronize()
+                agreed = self.dp_agree(err is None) if self.dp_agree is not None else err is None
+                if not agreed:
+                    import warnings
+                    warnings.warn('capturing %d data-parallel steps as one hipGraph failed on some rank (here: %r): one step per '
+                                  'replay from now on' % (K, err))
+                    self._k_dp_ok = False
+                    self._graphs.pop(key, None)
+                    self._acc_clean = False
+                    return one_by_one()
+                self._acc_clean = True
             self._graphs[key] = g
         if not self._acc_clean:                                 # something outside run() left the accumulators dirty
             self._begin(True)

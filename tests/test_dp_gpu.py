@@ -237,6 +237,92 @@ def test_rccl_section_graphs_on_one_gpu(tmp_path):
     assert np.abs(out['P'] - ref).max() <= 3e-4 * np.abs(ref).max()
 
 
+def _rccl_one_rank_k(_idx, port, out):
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    net = _net()
+    from lib import _dp
+    assert _dp.init('nccl', force=True) == (0, 1)
+    _dp.attach(net, force=True)
+    eng = net.engine()
+    x0, y = _batch(0)
+    eng._ensure_capacity(N)
+    eng.x0[:N].copy_(torch.from_numpy(x0)); eng.y[:N].copy_(torch.from_numpy(y))
+    feed = lambda t: {net.x0: eng.x0[:N], net.y: eng.y[:N], net.mode: 'tr', net.λ_lrn: 0.05 / (1 + t), net.τ: 1.0 - 0.05 * t}
+    for rnd in range(3):                     # step by step (warm-up), capture + replay, replay
+        net.train.run_steps([feed(4 * rnd + j) for j in range(4)])
+    torch.cuda.synchronize()
+    keys = [k for k in eng._graphs if k[0] == 'trK']
+    res = {'captured': bool(keys) and not isinstance(eng._graphs[keys[0]], str), 'dp_key': bool(keys) and bool(keys[0][-1]),
+           'buckets': list(eng.dp_buckets)}
+    np.save(os.path.join(out, 'P.npy'), eng.P.cpu().numpy())
+    import json
+    json.dump(res, open(os.path.join(out, 'res.json'), 'w'))
+    dist.destroy_process_group()
+
+
+def test_k_step_graph_under_data_parallelism_rccl_one_rank(tmp_path):
+    """Engine.run_steps with an all-reduce attached: K steps -- with their K x 3 captured RCCL all-reduces on the process
+    group's stream and the optimizer behind each step's last one -- are ONE hipGraph (the step form of the single-process
+    headline; round 5 ran one graph per step under data parallelism).  One rank: the sum is the identity, so twelve steps
+    must equal twelve single-process steps with the same per-step schedule values."""
+    import json
+    mp.spawn(_rccl_one_rank_k, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    res = json.load(open(str(tmp_path / 'res.json')))
+    assert res['captured'] and res['dp_key'] and res['buckets'] == ['exit', 'mid', 'end']
+    net = _net()
+    eng = net.engine()
+    x0, y = _batch(0)
+    for t in range(12):
+        net.train.run({net.x0: x0, net.y: y, net.mode: 'tr', net.λ_lrn: 0.05 / (1 + t), net.τ: 1.0 - 0.05 * t})
+    torch.cuda.synchronize()
+    ref = eng.P.cpu().numpy()
+    got = np.load(str(tmp_path / 'P.npy'))
+    assert np.abs(got - ref).max() <= 3e-4 * np.abs(ref).max()
+
+
+def _worker_k(rank, world, port, out):
+    """As _worker, but the last two of the three steps through run_steps: over gloo the collectives do not capture, so the
+    K-step call must fall back to one step per replay -- and still be the same three steps."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    net = _net()
+    from lib import _dp
+    _dp.init('gloo')
+    torch.cuda.set_device(0)
+    _dp.attach(net)
+    eng = net.engine()
+    inner = eng.allreduce
+
+    def via_host(flat):
+        try:
+            return inner(flat)
+        except RuntimeError:
+            h = flat.cpu(); dist.all_reduce(h); flat.copy_(h); return flat
+    eng.allreduce = via_host
+    x0, y = _batch(rank)
+    eng._ensure_capacity(N)
+    eng.x0[:N].copy_(torch.from_numpy(x0)); eng.y[:N].copy_(torch.from_numpy(y))
+    feed = {net.x0: eng.x0[:N], net.y: eng.y[:N], net.mode: 'tr', net.λ_lrn: 0.05, net.τ: 1.0}
+    net.train.run(feed)
+    net.train.run_steps([feed, feed])
+    torch.cuda.synchronize()
+    assert not any(k[0] == 'trK' and not isinstance(v, str) for k, v in eng._graphs.items())     # (nothing to capture over gloo)
+    np.save(os.path.join(out, 'P%d.npy' % rank), eng.P.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_run_steps_falls_back_over_gloo(tmp_path):
+    mp.spawn(_worker_k, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(str(tmp_path / 'P0.npy')), np.load(str(tmp_path / 'P1.npy'))
+    assert np.array_equal(p0, p1), 'replicas diverged'
+    ref_dir = tmp_path / 'ref'
+    ref_dir.mkdir()
+    mp.spawn(_worker, args=(2, _free_port(), str(ref_dir)), nprocs=2, join=True)
+    want = np.load(str(ref_dir / 'P0.npy'))
+    assert np.abs(p0 - want).max() <= 3e-5 * np.abs(want).max()
+
+
 def test_default_is_one_bucket():
     """The shipped form: the whole of G (TALR statistics at its head) in ONE all-reduce after the backward pass."""
     for p in (ROOT, os.path.join(ROOT, 'multipath-nn_amd')):
