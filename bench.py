@@ -362,7 +362,8 @@ def main():
     # K training steps per hipGraph replay -- single process AND data parallel (where the step's all-reduce is captured: K
     # steps hold K all-reduces; Engine.run_steps falls back to one step per replay where collectives do not capture): the
     # ~8.6 us the GPU idles between two replays of a one-step graph are paid once per K steps.  `steps` counts training steps.
-    spg = max(1, min(args.steps_per_graph, eng.STEPS_MAX)) if (eng.use_graph and not args.streams) else 1
+    k_ok = world == 1 or (eng.allreduce is not None and eng.dp_one_graph and eng.allreduce_capturable and not eng._bucket_opt_on())
+    spg = max(1, min(args.steps_per_graph, eng.STEPS_MAX)) if (eng.use_graph and not args.streams and k_ok) else 1
 
     def run_steps(k):
         done = 0
