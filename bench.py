@@ -262,6 +262,45 @@ def time_experiment(dev, n, single_ms, reps=100):
         co.run(feeds)
     torch.cuda.synchronize()
     ms_one = time_replays(lambda: co.run(feeds), reps)
+    # the saturated operating point of the conv bodies: every launch of the joint step (8 nets x 128 images per launch) in
+    # situ, eager launches with a HIP-event pair around each -- per family and per launch against the fp32 MFMA peak
+    roof = None
+    try:
+        prog = co._program(n)
+        st = torch.cuda.current_stream()
+        tot = [0.0] * len(prog['ops'])
+        R = 5
+        for rp in range(R + 1):
+            for e in co.engs:
+                e._begin(True)
+            evs = []
+            for op in prog['ops']:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st); op(st.cuda_stream); e1.record(st)
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            if rp:
+                for j, (e0, e1) in enumerate(evs):
+                    tot[j] += e0.elapsed_time(e1) / R
+        for e in co.engs:
+            e.mark_dirty()
+        fams = {}
+        for op, t in zip(prog['ops'], tot):
+            if op.flops:
+                f = fams.setdefault(op.what, dict(launches=0, flops=0.0, ms=0.0, members=[]))
+                f['launches'] += 1; f['flops'] += op.flops; f['ms'] += t
+                tf = op.flops / (t * 1e-3) / 1e12
+                f['members'].append({'launch': op.tag, 'us': t * 1e3, 'tflops': tf, 'frac': tf / PEAK_F32_MFMA})
+        roof = {}
+        for what, f in fams.items():
+            tf = f['flops'] / (f['ms'] * 1e-3) / 1e12
+            roof[what] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s', 'frac': tf / PEAK_F32_MFMA,
+                          'launches_per_joint_step': f['launches'], 'us_per_joint_step': f['ms'] * 1e3,
+                          'members': sorted(f['members'], key=lambda m: m['frac'])}
+        roof['what'] = ('one group of 8 (one joint step = one launch per layer for all 8 nets, 1 024 images per launch), eager launches, '
+                        'HIP events around every launch: the event pairs add the host\'s launch latency to each')
+    except Exception as e:
+        roof = {'error': repr(e)}
     del co
     # the same 8 nets as 4 groups of 2, each group's joint hipGraph on a stream of its own (lib/_co.py: CoGroups;
     # `train-nets --co-train 8` runs this form): a second hardware queue fills the ramps and drains of the first
@@ -289,7 +328,8 @@ def time_experiment(dev, n, single_ms, reps=100):
             'step_frac_of_mfma_roofline': K * n / (ms * 1e-3) * F_TRAIN / 1e12 / PEAK_F32_MFMA,
             'groups': [c.K for c in cg.groups], 'streams': len(cg.streams), 'share': cg.share,
             'one_group': {'what': 'all 8 nets in ONE joint hipGraph on one stream', 'images_per_s': K * n / (ms_one * 1e-3),
-                          'ms_per_joint_step': ms_one, 'speedup_vs_serial': K * single_ms / ms_one}}
+                          'ms_per_joint_step': ms_one, 'speedup_vs_serial': K * single_ms / ms_one},
+            'roofline': roof}
 
 
 def main():
@@ -590,7 +630,14 @@ def main():
                          'frac': ach / PEAK_F32_MFMA, 'traffic': traffic, 'traffic_source': traffic_src,
                          'traffic_stale': traffic_stale,
                          'kernel': symbol, 'launches_per_step': cnt,
-                         'kernel_ms': t_ms / cnt, 'kernel_flops': fl / cnt},
+                         'kernel_ms': t_ms / cnt, 'kernel_flops': fl / cnt,
+                         # every launch of the family (one per step each), furthest from the roofline first: its own in-situ
+                         # HIP-event pair (whole steps run eagerly; the pair adds the host's launch latency, so the members'
+                         # times sum to more than launches_per_step x kernel_ms)
+                         'members': sorted([{'launch': tag_, 'launches_per_step': 1, 'us': t_ * 1e3,
+                                             'tflops': fl_ / (t_ * 1e-3) / 1e12, 'frac': fl_ / (t_ * 1e-3) / 1e12 / PEAK_F32_MFMA}
+                                            for what_, tag_, fl_, t_ in ops if what_ == dom_name and fl_ > 0 and t_ > 0],
+                                           key=lambda m: m['frac'])},
             'step_frac_of_mfma_roofline': value / world * F_TRAIN / 1e12 / PEAK_F32_MFMA,
             'conv_kernels': {'tflops': conv_fl / (conv_ms * 1e-3) / 1e12, 'sum_ms': conv_ms,
                              'all_launches_sum_ms': total_ms, 'n_launches': len(ops)},
