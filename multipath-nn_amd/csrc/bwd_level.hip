@@ -63,12 +63,15 @@ extern "C" int mpnn_msconv_bwd_level_slots(const int *H, const int *W, const int
 }
 
 // records + first-workgroup table + kernel variant of a level; total = workgroups of the launch
-static bool g_level_smallc = false;      // (set by level_build: some member's operand A is a 1- / 3-channel image)
-static int level_build(const mpnn_bwd_member *mem, int count, BwdRec *recs, BwdLevelQ &lq, int &gkmask, int &otmask, int &total) {
+// smallc (out): some member's operand A is a 1- / 3-channel image -- the kernel variant with the SMALLC weight-gradient body.
+// (An out-parameter, not file-scope state: two engines building programs from different host threads would overwrite each
+// other's answer between level_build and the launch.)
+static int level_build(const mpnn_bwd_member *mem, int count, BwdRec *recs, BwdLevelQ &lq, int &gkmask, int &otmask, int &total,
+                       bool &smallc) {
     if (!mem || count < 1 || count > MPNN_BWD_LEVEL_MAX) return MPNN_E_ARG;
     gkmask = otmask = total = 0;
     lq.n = count;
-    g_level_smallc = false;
+    smallc = false;
     BwdRec scratch;
     for (int k = 0; k < count; ++k) {
         const mpnn_bwd_member &m = mem[k];
@@ -98,7 +101,7 @@ static int level_build(const mpnn_bwd_member *mem, int count, BwdRec *recs, BwdL
         total += q.gyh * q.gxh + q.gyv * q.gxv + gyw * q.gxw;
         gkmask |= 1 << r.gk;
         otmask |= r.wide ? 2 : 1;
-        if (!r.wide && w->a.C <= 3) g_level_smallc = true;
+        if (!r.wide && w->a.C <= 3) smallc = true;
     }
     return 0;
 }
@@ -107,22 +110,25 @@ extern "C" int mpnn_msconv_bwd_level_prepare(const mpnn_bwd_member *members, int
     if (!host_records) return MPNN_E_ARG;
     BwdLevelQ lq = {};
     int gkmask, otmask, total;
-    return level_build(members, count, (BwdRec *)host_records, lq, gkmask, otmask, total);
+    bool smallc;
+    return level_build(members, count, (BwdRec *)host_records, lq, gkmask, otmask, total, smallc);
 }
 
 // The same level for `reps` nets of one architecture in ONE launch (co-training, lib/_co.py): members / records hold
 // reps * count entries, net r's at [r * count, (r + 1) * count) -- identical shapes and workgroup budgets, the buffers of
 // net r.  The caller's budget is per net (mpnn_msconv_bwd_level_slots / reps).
-static int level_build_rep(const mpnn_bwd_member *mem, int count, int reps, BwdRec *recs, BwdLevelQ &lq, int &gkmask, int &otmask, int &total) {
+static int level_build_rep(const mpnn_bwd_member *mem, int count, int reps, BwdRec *recs, BwdLevelQ &lq, int &gkmask, int &otmask, int &total,
+                           bool &smallc) {
     if (reps < 1) return MPNN_E_ARG;
-    int rc = level_build(mem, count, recs, lq, gkmask, otmask, total);
+    int rc = level_build(mem, count, recs, lq, gkmask, otmask, total, smallc);
     if (rc) return rc;
     for (int r = 1; r < reps; ++r) {
         BwdLevelQ l2 = {};
         BwdRec tmp[MPNN_BWD_LEVEL_MAX];
         int g2, o2, t2;
-        if ((rc = level_build(mem + r * count, count, recs ? recs + r * count : tmp, l2, g2, o2, t2))) return rc;
-        if (g2 != gkmask || o2 != otmask || t2 != total) return MPNN_E_ARG;
+        bool s2;
+        if ((rc = level_build(mem + r * count, count, recs ? recs + r * count : tmp, l2, g2, o2, t2, s2))) return rc;
+        if (g2 != gkmask || o2 != otmask || t2 != total || s2 != smallc) return MPNN_E_ARG;      // (identical shapes: see above)
         for (int k = 0; k < count; ++k) if (l2.w0[k] != lq.w0[k]) return MPNN_E_ARG;
     }
     lq.reps = reps;  lq.wpr = total;
@@ -136,16 +142,18 @@ extern "C" int mpnn_msconv_bwd_level_prepare_rep(const mpnn_bwd_member *members,
     if (!host_records) return MPNN_E_ARG;
     BwdLevelQ lq = {};
     int gkmask, otmask, total;
-    return level_build_rep(members, count, reps, (BwdRec *)host_records, lq, gkmask, otmask, total);
+    bool smallc;
+    return level_build_rep(members, count, reps, (BwdRec *)host_records, lq, gkmask, otmask, total, smallc);
 }
 
 extern "C" int mpnn_msconv_bwd_level_rep(const mpnn_bwd_member *members, int count, int reps, const void *dev_records, void *stream) {
     if (!dev_records) return MPNN_E_ARG;
     BwdLevelQ lq = {};
     int gkmask, otmask, total;
-    const int rc = level_build_rep(members, count, reps, nullptr, lq, gkmask, otmask, total);
+    bool smallc;
+    const int rc = level_build_rep(members, count, reps, nullptr, lq, gkmask, otmask, total, smallc);
     if (rc) return rc;
-    LevelKern kern = level_kernel(gkmask, otmask, g_level_smallc);
+    LevelKern kern = level_kernel(gkmask, otmask, smallc);
     if (!kern) return MPNN_E_SHAPE;
     hipLaunchKernelGGL(kern, dim3(total * reps), dim3(256), 0, (hipStream_t)stream, (const BwdRec *)dev_records, lq);
     MPNN_LAUNCH_CHECK();
@@ -157,9 +165,10 @@ extern "C" int mpnn_msconv_bwd_level(const mpnn_bwd_member *members, int count, 
     BwdRec recs[MPNN_BWD_LEVEL_MAX];
     BwdLevelQ lq = {};
     int gkmask, otmask, total;
-    const int rc = level_build(members, count, recs, lq, gkmask, otmask, total);
+    bool smallc;
+    const int rc = level_build(members, count, recs, lq, gkmask, otmask, total, smallc);
     if (rc) return rc;
-    LevelKern kern = level_kernel(gkmask, otmask, g_level_smallc);
+    LevelKern kern = level_kernel(gkmask, otmask, smallc);
     if (!kern) return MPNN_E_SHAPE;
     hipLaunchKernelGGL(kern, dim3(total), dim3(256), 0, (hipStream_t)stream, (const BwdRec *)dev_records, lq);
     MPNN_LAUNCH_CHECK();

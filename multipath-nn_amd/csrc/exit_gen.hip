@@ -22,6 +22,7 @@
 //     output) and every pass uses all 256 threads: column sums as (column, row group) partials that meet in LDS, the two
 //     small products (a1' dh2, dh2 w2') from row chunks staged in LDS; the head (softmax, cross-entropy, arg-max) runs
 //     in workgroups of its own, four threads per sample.
+#include <atomic>
 #include "common.h"
 
 #define GEN_C 256            // channels of the exit's input map (coefficient table)
@@ -685,12 +686,15 @@ __global__ __launch_bounds__(256) void ev_tail_gen_k(const mpnn_exit_ev_args *__
 // Widest head / router the records of the process need (column tiles of the forward map's grid): the records live in
 // device memory, so the launcher cannot read them -- mpnn_exit_gen_check, which the caller runs on every exit before
 // uploading its record, keeps the maxima.  (Workgroups beyond a record's own tiles return at once.)
-static int g_gen_tiles = 2;
+// (a process-wide MAXIMUM that only grows, kept with an atomic max: engines that validate their exits from different host
+// threads cannot lose each other's larger value; a launch with more column tiles than a record needs costs workgroups that
+// return at once, never correctness)
+static std::atomic<int> g_gen_tiles{2};
 
 extern "C" int mpnn_lin_fwd_gen(const mpnn_lin_fwd_args *dev_table, int count, int n_max, void *stream) {
     if (count <= 0 || n_max <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    hipLaunchKernelGGL(lin_fwd_gen_k, dim3((n_max + 15) / 16, g_gen_tiles, count), dim3(256), 0, (hipStream_t)stream, dev_table);
+    hipLaunchKernelGGL(lin_fwd_gen_k, dim3((n_max + 15) / 16, g_gen_tiles.load(), count), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     return 0;
 }
@@ -724,7 +728,7 @@ extern "C" int mpnn_exit_tail_bwd_gen(const mpnn_exit_tail_bwd_args *dev_table, 
 extern "C" int mpnn_exit_ev_gen(const mpnn_exit_ev_args *dev_table, int count, int n_max, void *stream) {
     if (count <= 0 || n_max <= 0) return 0;
     if (!dev_table) return MPNN_E_ARG;
-    hipLaunchKernelGGL(ev_lin_gen_k, dim3((n_max + 15) / 16, g_gen_tiles, count), dim3(256), 0, (hipStream_t)stream, dev_table);
+    hipLaunchKernelGGL(ev_lin_gen_k, dim3((n_max + 15) / 16, g_gen_tiles.load(), count), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(ev_tail_gen_k, dim3((n_max + EV_SPW - 1) / EV_SPW, count), dim3(256), 0, (hipStream_t)stream, dev_table);
     MPNN_LAUNCH_CHECK();
@@ -737,6 +741,6 @@ extern "C" int mpnn_exit_gen_check(int C, int K, int n_cls, int R, int R2, int n
     if (n_cls < 0 || n_cls > 1024 || R < 0 || R > GEN_R || R2 < 0 || R2 > GEN_R) return MPNN_E_SHAPE;
     if (R && (n_sinks < 2 || n_sinks > MPNN_MAX_SINKS)) return MPNN_E_SHAPE;
     const int tiles = (n_cls + 15) / 16 + (R + 15) / 16;
-    if (tiles > g_gen_tiles) g_gen_tiles = tiles;
+    for (int cur = g_gen_tiles.load(); tiles > cur && !g_gen_tiles.compare_exchange_weak(cur, tiles);) {}
     return 0;
 }
