@@ -46,7 +46,7 @@ def csrc_sha16():
     import hashlib
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, 'multipath-nn_amd', 'csrc', '*.h*'))) + \
-        [os.path.join(ROOT, 'multipath-nn_amd', 'lib', '_plan.py')]
+        [os.path.join(ROOT, 'multipath-nn_amd', 'lib', '_plan.py')] + sorted(glob.glob(os.path.join(ROOT, 'multipath-nn_amd', 'lib', '_eng_*.py')))
     for f in files:
         h.update(open(f, 'rb').read())
     return h.hexdigest()[:16]
@@ -161,20 +161,18 @@ def measure_dp_structure(net, eng, feed, single_ms):
             net.train.run(feed)
         torch.cuda.synchronize()
         ms1 = time_replays(lambda: net.train.run(feed), 200)
-        key = [k for k in eng._graphs if k[0] == 'tr' and k[2]][0]
-        whole = eng._graphs[key][1] == 'whole'
+        whole = eng.step_graph_form() == 'whole'
         # the form the multi-GPU run takes: K steps -- K all-reduces -- per hipGraph replay, as the single-process headline
         K = 4
         for _ in range(3):
             net.train.run_steps([feed] * K)
         torch.cuda.synchronize()
-        kk = [k for k in eng._graphs if k[0] == 'trK' and k[-1]]
-        k_captured = bool(kk) and not isinstance(eng._graphs[kk[0]], str)
+        k_captured = eng.k_step_graph_captured(dp=True)
         ms = time_replays(lambda: net.train.run_steps([feed] * K), 50, chunk=5) / K if k_captured else ms1
         return {'ms_per_step': ms, 'ms_per_step_single_graph': single_ms, 'ratio': ms / single_ms,
                 'steps_per_graph': K if k_captured else 1, 'ms_per_step_one_step_graphs': ms1, 'ratio_one_step_graphs': ms1 / single_ms,
                 'buckets': list(eng.dp_buckets), 'collectives_per_step': len(eng.dp_buckets), 'rccl_ranks': dist.get_world_size(),
-                'reserved_cus': eng.dp_reserve_cus, 'per_bucket_update': bool(eng._bucket_opt_on()),
+                'reserved_cus': eng.dp_reserve_cus, 'per_bucket_update': eng.per_bucket_update,
                 'form': 'ONE hipGraph per step: bucket sections + RCCL all-reduces (captured on the process group\'s stream) + optimizer'
                         if whole else 'one hipGraph per bucket section, all-reduces issued from the host, optimizer graph',
                 'what': 'forced 1-rank RCCL group, 200 steps, beside the single-process one-graph step'}
@@ -221,7 +219,7 @@ def time_configs(dev, n, reps=200):
             net.to(dev)
             eng = net.engine()
             g = torch.Generator().manual_seed(7)
-            eng._ensure_capacity(n, train=True)
+            eng.ensure_capacity(n, train=True)
             eng.x0[:n].copy_(torch.rand((n, 32, 32, c0), generator=g).to(dev))
             eng.y[:n].copy_(torch.nn.functional.one_hot(torch.randint(0, 10, (n,), generator=g), 10).float().to(dev))
             feed = {net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr', net.λ_lrn: A.λ_lrn(0)}
@@ -251,7 +249,7 @@ def time_experiment(dev, n, single_ms, reps=100):
         net = A.ac_chain(k_cpt=k, seed=1234 + i)((32, 32, 3), (10,))
         net.to(dev)
         eng = net.engine()
-        eng._ensure_capacity(n, train=True)
+        eng.ensure_capacity(n, train=True)
         eng.x0[:n].copy_(torch.rand((n, 32, 32, 3), generator=g).to(dev))
         eng.y[:n].copy_(torch.nn.functional.one_hot(torch.randint(0, 10, (n,), generator=g), 10).float().to(dev))
         nets.append(net)
@@ -272,7 +270,7 @@ def time_experiment(dev, n, single_ms, reps=100):
         R = 5
         for rp in range(R + 1):
             for e in co.engs:
-                e._begin(True)
+                e.begin_step(False)
             evs = []
             for op in prog['ops']:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -385,8 +383,8 @@ def main():
     _dp.attach(net)
     n = args.batch
     if rank == 0:                              # buffers for the evaluation measurement too: allocated before anything is timed
-        eng._ensure_capacity(max(n, args.eval_batch), train=False)
-        eng._ensure_capacity(n, train=True)
+        eng.ensure_capacity(max(n, args.eval_batch), train=False)
+        eng.ensure_capacity(n, train=True)
     x0, y = synthetic(n, rank, dev)
     eng.x0[:n].copy_(x0)
     eng.y[:n].copy_(y)
@@ -402,7 +400,7 @@ def main():
     # K training steps per hipGraph replay -- single process AND data parallel (where the step's all-reduce is captured: K
     # steps hold K all-reduces; Engine.run_steps falls back to one step per replay where collectives do not capture): the
     # ~8.6 us the GPU idles between two replays of a one-step graph are paid once per K steps.  `steps` counts training steps.
-    k_ok = world == 1 or (eng.allreduce is not None and eng.dp_one_graph and eng.allreduce_capturable and not eng._bucket_opt_on())
+    k_ok = world == 1 or (eng.allreduce is not None and eng.dp_one_graph and eng.allreduce_capturable and not eng.per_bucket_update)
     spg = max(1, min(args.steps_per_graph, eng.STEPS_MAX)) if (eng.use_graph and not args.streams and k_ok) else 1
 
     def run_steps(k):
@@ -472,10 +470,9 @@ def main():
     # reported, not required to agree.
     dp_check = None
     if world > 1:
-        key = [k for k in eng._graphs if k[0] == 'tr' and k[2]] if eng.use_graph else []
-        form = 'eager'
-        if key and isinstance(eng._graphs[key[0]], tuple):
-            form = 'whole' if eng._graphs[key[0]][1] == 'whole' else 'sections'
+        form = (eng.step_graph_form() if eng.use_graph else None) or 'eager'
+        if eng.k_step_graph_captured(dp=True):
+            form = 'whole, %d steps per graph' % spg
         dP, dA, dS = _dp.max_divergence(eng.P), _dp.max_divergence(eng.A), _dp.max_divergence(eng.S)
         dp_check = {'replicas_identical': dP == 0.0 and dA == 0.0, 'max_abs_param_divergence': dP,
                     'max_abs_momentum_divergence': dA, 'bn_moving_average_divergence': dS,

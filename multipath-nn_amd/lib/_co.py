@@ -56,9 +56,8 @@ class CoTrainer:
         for k, e in enumerate(self.engs):
             self.hyp_all[k].copy_(e.hyp)
             e.hyp = self.hyp_all[k]
-            e._hyp_sent = None
-            e._progs.clear()
-            e._graphs.clear()
+            e.hyp_rewritten()
+            e.drop_programs()
         self._hyp_ring = [(torch.zeros(self.K, _hip.HYP_N).pin_memory(), None) for _ in range(8)]
         self._hyp_slot, self._hyp_sent, self._hyp_epochs = -1, None, None
         self.use_graph = e0.use_graph
@@ -68,7 +67,7 @@ class CoTrainer:
 
     # ------------------------------------------------------------------ the merged program
     def _program(self, n):
-        gens = tuple(e._gen for e in self.engs)
+        gens = tuple(e.generation for e in self.engs)
         if self._progs and self._gens != gens:             # an engine reallocated its buffers (a larger batch came by)
             self.invalidate()
         if n in self._progs:
@@ -81,7 +80,7 @@ class CoTrainer:
                 progs.append(e.program('tr', n))
             finally:
                 e.co_share = 1
-        self._gens = tuple(e._gen for e in self.engs)
+        self._gens = tuple(e.generation for e in self.engs)
         skip = ('fork', 'join')
         lists = [[op for op in list(p['fwd']) + list(p['bwd']) if op.what not in skip] for p in progs]
         sig = [[(op.what, op.tag) for op in ops] for ops in lists]
@@ -162,13 +161,11 @@ class CoTrainer:
         for e in self.engs:
             if self.prologue is None and e.prologue is not None:
                 e.prologue(st)
-            if not (prog['fold'] and e._acc_clean):
-                e._begin(True)
-            e._acc_clean = False
+            e.begin_step(prog['fold'])
         for op in prog['ops']:
             op(st)
         for e in self.engs:
-            e._acc_clean = prog['fold']
+            e.end_step(prog['n'], prog['fold'])
 
     def run(self, feeds):
         """One training step of every net: feeds[i] is net i's feed (as for ``net.train.run``)."""
@@ -177,15 +174,13 @@ class CoTrainer:
         ns = set()
         hs = torch.empty(self.K, _hip.HYP_N)
         for k, (e, net, feed) in enumerate(zip(self.engs, self.nets, feeds)):
-            n, mode = e._stage(feed, upload_hyp=False)
-            hs[k].copy_(e._hyp_stage)
+            n, mode, row = e.stage_feed(feed)
+            hs[k].copy_(row)
             if mode != 'tr':
                 raise ValueError("co-training needs net.mode: 'tr' in every feed")
             ns.add(n)
-            if not e._packs_fresh:
-                e._pack()
-                e._packs_fresh = True
-        epochs = tuple(getattr(e, '_hyp_epoch', 0) for e in self.engs)      # (a net that stepped alone rewrote its row)
+            e.fresh_packs()
+        epochs = tuple(e.hyp_epoch for e in self.engs)      # (a net that stepped alone rewrote its row)
         if self._hyp_sent is None or epochs != self._hyp_epochs or not torch.equal(hs, self._hyp_sent):
             self._hyp_epochs = epochs
             r = self._hyp_slot = (self._hyp_slot + 1) % len(self._hyp_ring)
@@ -211,23 +206,20 @@ class CoTrainer:
             if g == 'warm':
                 torch.cuda.synchronize()
                 for e in self.engs:                        # (captured without clearing launches)
-                    if prog['fold'] and not e._acc_clean:
-                        e._begin(True)
-                        e._acc_clean = True
+                    if prog['fold']:
+                        e.clear_for_capture()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     self._eager(prog)
                 self._graphs[n] = g
             for e in self.engs:
-                if prog['fold'] and not e._acc_clean:      # something outside run() left the accumulators dirty
-                    e._begin(True)
-                e._acc_clean = False
+                if prog['fold']:
+                    e.begin_step(True)                     # (a clearing launch only if something outside run() left them dirty)
+                else:
+                    e.mark_dirty()                         # (the graph holds the program's own clearing launch)
             g.replay()
-            for e in self.engs:
-                e._acc_clean = prog['fold']
         for e in self.engs:
-            e.last_n, e.last_mode, e._last_fold = n, 'tr', prog['fold']
-            e._bind_views(n)
+            e.end_step(n, prog['fold'])
 
     def set_prologue(self, fn, fn_slot=None):
         """fn(stream): the first launch of every joint step (replaces the nets' own prologues in the joint graph);
@@ -291,7 +283,7 @@ class CoTrainer:
             self._hypk = torch.zeros(self.STEPS_MAX, K, _hip.HYP_N, device=self.dev)
             self._hypk_ring = [(torch.zeros(self.STEPS_MAX, K, _hip.HYP_N).pin_memory(), None) for _ in range(8)]
             self._hypk_slot, self._hypk_sent = -1, None
-        hs = torch.stack([torch.stack([e._hyp_values(f, n).clone() for e, f in zip(self.engs, fs)]) for fs in feeds_k])
+        hs = torch.stack([torch.stack([e.schedule_values(f, n) for e, f in zip(self.engs, fs)]) for fs in feeds_k])
         if self._hypk_sent is None or self._hypk_sent.shape != hs.shape or not torch.equal(hs, self._hypk_sent):
             r = self._hypk_slot = (self._hypk_slot + 1) % len(self._hypk_ring)
             buf, ev = self._hypk_ring[r]
@@ -305,17 +297,12 @@ class CoTrainer:
             self._hypk_sent = hs
         self._hyp_sent = None                                   # (the graph rewrites every net's hyp row on the device)
         for e in self.engs:
-            e._hyp_sent = None
-            e._hyp_epoch = getattr(e, '_hyp_epoch', 0) + 1
-            if not e._packs_fresh:
-                e._pack()
-                e._packs_fresh = True
+            e.hyp_rewritten()
+            e.fresh_packs()
         if g == 'warm':
             torch.cuda.synchronize()
             for e in self.engs:                                 # (captured without clearing launches)
-                if not e._acc_clean:
-                    e._begin(True)
-                    e._acc_clean = True
+                e.clear_for_capture()
             tails = [op for op in prog['ops'] if op.what == 'exit_tail_fwd']
             assert len(tails) == 1 and getattr(tails[0], 'host', None)
             tail = tails[0]
@@ -345,14 +332,10 @@ class CoTrainer:
                             op(st)
             self._graphs[key] = g
         for e in self.engs:
-            if not e._acc_clean:                                # something outside run() left the accumulators dirty
-                e._begin(True)
-            e._acc_clean = False
+            e.begin_step(True)                                  # (a clearing launch only if something outside left them dirty)
         g.replay()
         for e in self.engs:
-            e._acc_clean = True
-            e.last_n, e.last_mode, e._last_fold = n, 'tr', True
-            e._bind_views(n)
+            e.end_step(n, True)
 
     def invalidate(self):
         """Drop the merged programs and graphs (an engine reallocated its buffers: a larger batch came by)."""
@@ -422,7 +405,7 @@ class CoGroups:
         K = len(nets)
         for _, cnt, first in runs:
             eng = first.engine()
-            if cnt > 1 and hasattr(eng, '_groupable') and not eng._groupable():
+            if cnt > 1 and hasattr(eng, 'groupable') and not eng.groupable():
                 # (an architecture whose forward convs are single launches -- 64+ channels on 16x16 / 32x32 maps -- has no
                 # multi-net launch form: its nets run side by side as groups of one)
                 sizes += [1] * cnt

@@ -205,7 +205,7 @@ def attach(net, force=False):
             _selftest = captured_collectives_work()
         eng.allreduce_capturable = _selftest
         eng.dp_selftest = bool(_selftest)
-    eng._graphs.clear()                        # graphs captured so far folded the optimizer into the step
+    eng.drop_graphs()                        # graphs captured so far folded the optimizer into the step
     for buf in (eng.P, eng.S, eng.A):          # identical replicas to start from
         if buf.is_cuda and dist.get_backend() == 'gloo':
             h = buf.cpu(); dist.broadcast(h, src=0); buf.copy_(h)
@@ -222,5 +222,5 @@ def detach(net):
         eng.world, eng.allreduce = 1, None
         return net
     eng.world, eng.allreduce, eng.allreduce_capturable, eng.dp_agree, eng.dp_quiesce = 1, None, False, None, None
-    eng._graphs.clear()
+    eng.drop_graphs()
     return net

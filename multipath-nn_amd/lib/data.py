@@ -283,7 +283,7 @@ class Dataset:
         from ._plan import BoundInput
         if getattr(self, '_x_dev', None) is None:
             self.to_device(str(eng.dev))
-        eng._ensure_capacity(n)
+        eng.ensure_capacity(n)
         # the engine's own draw buffer and upload ring, allocated WITHOUT drawing: a draw here would consume a batch of the
         # numpy stream and offset every later batch against the reference's call sequence (scripts/lib/data.py:24-34).
         # Stage every step's records with stage_training_draws(n, eng=eng).
@@ -313,7 +313,7 @@ class Dataset:
         state = {}
 
         def launch_slot(stream, j):
-            key = tuple(e._gen for e in co.engs)              # (the engines' input buffers may have been reallocated)
+            key = tuple(e.generation for e in co.engs)              # (the engines' input buffers may have been reallocated)
             if state.get('key') != key:
                 tabs = []
                 for jj in range(self.SLOTS):
