@@ -59,7 +59,11 @@ extern "C" int mpnn_msconv_bwd_level_slots(const int *H, const int *W, const int
         gkmask |= 1 << gk;
         otmask |= (Cout[k] % 64) == 0 ? 2 : 1;
     }
-    return resident_slots((const void *)level_kernel(gkmask, otmask), 0, 256, (otmask & 2) ? 2 : 0);
+    // (levels with a 64-channel weight-gradient group: at most THREE workgroups per CU.  Rounds 2-5 capped them at two --
+    // fewer, larger shares --; with three the co-trained joint step of 8 nets takes 1 983 instead of 2 002 us and the single
+    // net's step is unchanged (485.1 / 485.5 us): profiles/r06_level_cap.txt.  MPNN_LEVEL_WIDE_CAP overrides, 0 = whatever fits)
+    static const int wide_cap = [] { const char *e = getenv("MPNN_LEVEL_WIDE_CAP"); return e ? atoi(e) : 3; }();
+    return resident_slots((const void *)level_kernel(gkmask, otmask), 0, 256, (otmask & 2) ? wide_cap : 0);
 }
 
 // records + first-workgroup table + kernel variant of a level; total = workgroups of the launch
