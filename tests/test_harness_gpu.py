@@ -282,6 +282,10 @@ def test_bound_input_pipeline_feeds_every_step_in_every_graph_form(form):
             yb = torch.zeros(n * 8, ds.y_shape[0], device='cuda'); yb[:, 0] = 1
             net.eval({net.x0: xb, net.y: yb})
     assert all(np.abs(a - b).max() > 0 for a, b in zip(seen, seen[1:]))
+    # the old call form -- staging into the dataset's own buffer while an engine is bound -- would feed the step from records
+    # nobody wrote (every sample source image 0, unflipped, unshifted): it raises instead
+    with pytest.raises(ValueError):
+        ds.stage_training_draws(n)
     if form == 'sections':
         assert len(calls) >= 6 and eng._graphs and all(v[1] != 'whole' for v in eng._graphs.values() if isinstance(v, tuple))
 
@@ -418,3 +422,15 @@ def test_device_augmentation_on_random_shapes(seed):
     for k in range(K):
         assert np.abs(xo[k].cpu().numpy().astype(np.float64) - want[k][0]).max() <= 2e-7, k
         assert np.array_equal(yo[k].cpu().numpy(), want[k][1].astype(np.float32)), k
+
+
+def test_engine_refuses_conv_batchnorms_with_different_decays():
+    """The conv BatchNorms' moving-average decay is ONE kernel argument per net.  Trees built through the layer classes always
+    satisfy that (MultiscaleBatchNorm hands every scale a default BatchNorm, as the reference does); a tree whose components
+    were edited by hand is refused instead of trained with block 0's number (round 5: silently)."""
+    import arch_and_hypers as A
+    net = A.ac_chain(k_cpt=1e-9, seed=3)((32, 32, 3), (10,))
+    blk = [ℓ for ℓ in net.layers if ℓ.name == 'ReConvMax'][1]
+    blk.comps[1].comps[0].hypers.d = 0.5
+    with pytest.raises(NotImplementedError):
+        net.engine()

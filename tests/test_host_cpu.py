@@ -100,6 +100,11 @@ def test_operator_surface_and_unicode_keywords():
     assert r0.comps[1].params.w.shape == (257, 16)                         # flatten(4x4x16) + k_cpt column
     with pytest.raises(NotImplementedError):
         L.MultiscaleLLN().link([L.Sym((4, 4, 3))], None, 'tr')
+    # MultiscaleBatchNorm accepts d / ϵ and DISCARDS them: every scale gets a BatchNorm() with the default hypers, as in the
+    # reference (layer_types.py:246).  Rounds 1-5 forwarded them.
+    ms = L.MultiscaleBatchNorm(d=0.5, ϵ=1e-3)
+    ms.link([L.Sym((8, 8, 16)), L.Sym((4, 4, 16))], None, 'tr')
+    assert [(c.hypers.d, _attr(c.hypers, 'ϵ')) for c in ms.comps] == [(0.9, 1e-6)] * 2 and ms.hypers.d == 0.5
 
 
 @pytest.mark.skipif(not os.path.exists('/root/reference/scripts/arch_and_hypers.py'), reason='reference not mounted')
