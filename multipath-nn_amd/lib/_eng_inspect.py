@@ -120,6 +120,48 @@ class Inspection:
                 ℓ.router.x = self.r[sw * n * MS:(sw + 1) * n * MS].view(n, MS)[:, :len(ℓ.sinks)]
 
 
+    def state_sums(self):
+        """The statistics of state(), each SUMMED over the samples of the last run (float64 device tensors, same keys): what
+        the dataset-wide averages of lib/desc.py need.  A dozen batched device operations (row gathers of the flat result
+        buffers, two small matrix products for the per-class statistics) instead of six per leaf -- a statistics pass spent
+        as long in ~150 tiny launches per batch as in the evaluation itself (profiles/r06_experiment_wall.txt)."""
+        net, n = self.net, self.last_n
+        nn, nl, MS, dev = len(self.nodes), len(self.leaves), self.max_sinks, self.dev
+        c = getattr(self, '_sums_cache', None)
+        if c is None:
+            c = self._sums_cache = dict(
+                leaf_rows=torch.tensor([nd.idx for nd in self.leaves], device=dev),
+                leaf_ids=torch.tensor([nd.leaf_id for nd in self.leaves], device=dev),
+                ops=torch.tensor(self.node_ops_host, dtype=torch.float64, device=dev),
+                sw_ids=torch.tensor([nd.switch_id for nd in self.switches], device=dev, dtype=torch.long),
+                sw_mask=torch.tensor([[1.0 / len(nd.layer.sinks) if k < len(nd.layer.sinks) else 0.0 for k in range(MS)]
+                                      for nd in self.switches], dtype=torch.float64, device=dev))
+        pev = self.p_ev[:nn * n].view(nn, n).double()
+        pl = pev[c['leaf_rows']]                                   # [leaves, n], in self.leaves order
+        dcor = self.d_cor[:nl * n].view(nl, n)[c['leaf_ids']].double()
+        cerr = self.c_err[:nl * n].view(nl, n)[c['leaf_ids']].double()
+        y = self.y[:n].double()
+        cor = pl * dcor
+        inc = pl - cor                                             # (δ_cor is 0 or 1: p_ev (1 - δ) exactly)
+        cor_cls, inc_cls = cor @ y, inc @ y
+        p_cor, p_inc, c_sum = cor.sum(1), inc.sum(1), cerr.sum(1)
+        out = {(net, 'acc'): p_cor.sum(), (net, 'moc'): (pev.sum(1) * c['ops']).sum()}
+        ptr = self.p_tr[:nn * n].view(nn, n)[c['leaf_rows']].double().sum(1) if net._net_kind != 'sr' else None
+        for k, nd in enumerate(self.leaves):
+            ℓ = nd.layer
+            out[(ℓ, 'p_cor')], out[(ℓ, 'p_inc')] = p_cor[k], p_inc[k]
+            out[(ℓ, 'p_cor_by_cls')], out[(ℓ, 'p_inc_by_cls')] = cor_cls[k], inc_cls[k]
+            if ptr is not None:
+                out[(ℓ, 'p_tr')] = ptr[k]
+            out[(ℓ, 'c_err')] = c_sum[k]
+        if self.switches:
+            nsw = len(self.switches)                                                      # (switch ids: 0 .. nsw - 1)
+            r = self.r[:nsw * n * MS].view(nsw, n, MS)[c['sw_ids']].abs().double()        # [switches, n, MS]
+            x = (r * c['sw_mask'][:, None, :]).sum((1, 2))                                  # sum over samples of mean |r| over the sinks
+            for k, nd in enumerate(self.switches):
+                out[(nd.layer, 'x_rte')] = x[k]
+        return out
+
     def state(self):
         """Per-sample statistics of the last run (scripts/train-nets:117-130)."""
         net, n = self.net, self.last_n

@@ -25,8 +25,11 @@ def mean_net_state(net, data, hypers, routed=False):
     sums, count = None, 0
     for x0, y in data:
         net.eval({net.x0: x0, net.y: y, **hypers}, routed=routed)
-        state = net.state()
-        part = {k: v.sum(0).double() for k, v in state.items()}
+        sums_of = getattr(net.engine(), 'state_sums', None)
+        if sums_of is not None:                 # (the multiscale engine: the sums in a dozen batched device operations)
+            part = sums_of()
+        else:
+            part = {k: v.sum(0).double() for k, v in net.state().items()}
         sums = part if sums is None else {k: sums[k] + part[k] for k in part}
         count += len(x0)
     if sums is None:

@@ -434,3 +434,31 @@ def test_engine_refuses_conv_batchnorms_with_different_decays():
     blk.comps[1].comps[0].hypers.d = 0.5
     with pytest.raises(NotImplementedError):
         net.engine()
+
+
+@pytest.mark.parametrize('kind', ['ac', 'cr', 'sr', 'tree'])
+def test_state_sums_equal_the_sums_of_state(kind):
+    """Engine.state_sums (what the statistics pass accumulates: a dozen batched device operations) == the per-sample
+    statistics of Engine.state summed over the batch, key for key -- dense and routed evaluation, chains, a tree with 3-way
+    switches (x_rte averages over the node's own number of sinks)."""
+    import arch_and_hypers as A
+    mk = {'ac': A.ac_chain(k_cpt=1e-9, seed=3), 'cr': A.cr_chain(k_cpt=1e-9, seed=3), 'sr': A.sr_chain(5), 'tree': A.ac_tree(k_cpt=1e-9, seed=3)}[kind]
+    net = mk((32, 32, 3), (10,))
+    eng = net.engine()
+    rng = np.random.default_rng(0)
+    if kind != 'sr':
+        for ℓ in net.layers:
+            if ℓ.router is not None:
+                w = ℓ.router.comps[-1].params.w
+                w.assign(rng.standard_normal(w.shape) * 0.5)
+    n = 300 if kind != 'tree' else 40
+    x0 = rng.random((n, 32, 32, 3)).astype(np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, n)]
+    for routed in ([False, True] if kind != 'sr' else [False]):
+        net.eval({net.x0: x0, net.y: y}, routed=routed)
+        want = {k: v.double().sum(0) for k, v in eng.state().items()}
+        got = eng.state_sums()
+        assert set(got) == set(want)
+        for k in want:
+            assert got[k].shape == want[k].shape, k[1]
+            assert torch.allclose(got[k], want[k], rtol=1e-6, atol=1e-6), (kind, routed, k[1])
