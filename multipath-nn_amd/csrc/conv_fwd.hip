@@ -216,10 +216,11 @@ static int fwd_group_launch(const mpnn_conv_fwd_args *args, const mpnn_conv_fwd_
     for (int k = 0; k < count; ++k) any_small = any_small || q.small[k];
     // 32-channel output tiles: every member an 8x8 / 4x4 conv with Cout % 32 == 0, evaluation mode, capacity >= MPNN_FWD_WIDE
     static const int wide_env = [] { const char *e = getenv("MPNN_FWD_WIDE"); return e ? atoi(e) : 1024; }();     // 0 = off
+    static const int wide_train = [] { const char *e = getenv("MPNN_FWD_WIDE_TRAIN"); return e ? atoi(e) : 0; }();     // experiment: also in multi-member training levels
     bool wide = wide_env > 0;
     for (int k = 0; k < count; ++k)
         wide = wide && (q.gk[k] == 1 || q.gk[k] == 2) && !q.small[k] && (hp[k].Cout % 32) == 0 && (long)hp[k].n * share >= wide_env &&
-               (hp[k].a.mode != MPNN_ACT_BN_BATCH || (share > 1 && count == 1));
+               (hp[k].a.mode != MPNN_ACT_BN_BATCH || (share > 1 && (count == 1 || wide_train)));
     // (training launches of a co-trained group: a deep 4x4 / 8x8 conv alone in its level, measured at 8 nets x 128 images:
     // h4 64+64->64 38.0 -> 33.7 us, 64->128 37.7 -> 35.2, 128->128 63.5 -> 58.1; in the two-member levels the 8x8 member
     // got slower -- 92 -> 108 us -- and they keep the 16-channel tile)

@@ -348,6 +348,14 @@ template <int WNT> struct CT_OK { static constexpr bool v = WNT == 1; };      //
 #ifndef MPNN_WT_SINGLE
 #define MPNN_WT_SINGLE 0
 #endif
+// ... the same for the 32-channel output tiles only -- ON (round 6): their two weight buffers were 36 KB of the 58 KB that kept
+// them at two workgroups per CU; with one buffer (40 KB: three per CU) and units of 72 MFMAs per wave the second barrier is
+// cheap: dense evaluation at 4 096 images 2.127 -> 2.063 ms, routed 1.530 -> 1.480 ms, 8 192: 3.990 -> 3.882 / 2.653 -> 2.581 ms
+// (tools/wide_single_probe.sh; -DMPNN_WT_SINGLE_WIDE=0 for the A/B build).  Same arithmetic, bit-identical results.
+#ifndef MPNN_WT_SINGLE_WIDE
+#define MPNN_WT_SINGLE_WIDE 1
+#endif
+template <int CT> struct WtSingle { static constexpr bool v = MPNN_WT_SINGLE || (MPNN_WT_SINGLE_WIDE && CT == 32); };
 // LDS bytes of one workgroup (all variants of a launch share one arena).
 template <int GK, int WM, int CT, int NCH = 1>
 struct ConvSmem {
@@ -355,7 +363,7 @@ struct ConvSmem {
     // beside the pooling area where a map is pooled -- 8x8 --, on top of it on the 4x4 maps, which are never pooled and
     // whose four-way split sits 192 bytes under the 160 KB of a CU)
     static constexpr int KRED0 = (NCH == 4 && GK != 2) ? 64 * CT * 4 : 0;          // byte offset of the partial sums in POOL
-    static constexpr int TILE = NCH * 2 * 4 * Geom<GK>::P * 16, WT = NCH * (MPNN_WT_SINGLE ? 1 : 2) * 36 * CT * 16, CA = 128 * 5 * 4, CE = CT * 5 * 4,
+    static constexpr int TILE = NCH * 2 * 4 * Geom<GK>::P * 16, WT = NCH * (WtSingle<CT>::v ? 1 : 2) * 36 * CT * 16, CA = 128 * 5 * 4, CE = CT * 5 * 4,
                          RED = WM * CT * 2 * 8, POOL = NCH == 4 ? KRED0 + 3 * 4096 : 64 * CT * 4;
     static constexpr int BYTES = TILE + WT + CA + ((CE + 15) & ~15) + RED + POOL;
 };
@@ -507,7 +515,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
             if (!done) st_items<GK, 0, XW>(td, xs, p, cA, q.inb, ik, c0, np);
         }
         if (with_b) {
-            f32x4 *dst = wtile[(b_once || MPNN_WT_SINGLE) ? 0 : buf];
+            f32x4 *dst = wtile[(b_once || WtSingle<CT>::v) ? 0 : buf];
 #pragma unroll
             for (int sc = 0; sc < SC; ++sc)
 #pragma unroll
@@ -692,7 +700,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         // ----------------------------- MFMAs of unit u -----------------------------
         mfma_prio_on();
         if (!MPNN_DBG(p, 1)) {
-            const f32x4 *wl = (b_once || MPNN_WT_SINGLE) ? wtile[0] : wtile[u & 1];
+            const f32x4 *wl = (b_once || WtSingle<CT>::v) ? wtile[0] : wtile[u & 1];
             const int wcol = wn * NT * 16 + li;
             if (SMALL_A && part == 0) {
                 const float *tf = (const float *)cur;
@@ -743,7 +751,7 @@ __device__ __forceinline__ void conv_body(const ConvP &p, const int bx, const in
         }
         mfma_drain();
         mfma_prio_off();
-        if (MPNN_WT_SINGLE && !b_once) lds_barrier();      // (single weight buffer: every wave is done with this unit's weights)
+        if (WtSingle<CT>::v && !b_once) lds_barrier();      // (single weight buffer: every wave is done with this unit's weights)
         if (u == 0) trace_stamp(8);
         // ----------------------------- stage unit u+1 ------------------------------
         // BEFORE the epilogue: its wait then covers exactly the loads of unit u+2 issued above
