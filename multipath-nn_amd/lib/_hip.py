@@ -245,6 +245,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise HipError('%s not found -- build it with `make -C multipath-nn_amd/csrc` '
                            '(or __graft_entry__.build()); there is no CPU fallback' % LIB_PATH)
+        # ONE HIP runtime per process: PyTorch bundles its own libamdhip64 and the library's device pointers are torch
+        # allocations.  With torch loaded first the library's dependency resolves to that copy (same SONAME); loaded the
+        # other way round the process holds two runtimes and the first launch fails with hipErrorNoDevice.
+        try:
+            import torch                        # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, sig in _SIGS.items():
             fn = getattr(lib, name)
