@@ -417,11 +417,18 @@ def main():
         for _ in range(3):                     # (warm-up, capture, first replay of the K-step graph)
             net.train.run_steps([feed] * spg)
     run_steps(max(args.warmup, 3))
+    # (the host runs about one replay ahead of the GPU -- hipGraphLaunch returns when the previous replay has freed its queue
+    # slots --, so a host pause of a few milliseconds inside the 10-100 ms timed region stalls the GPU: one run in ten read 10 %
+    # low with an unchanged steady state.  The one pause this process can rule out is its own garbage collector.)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
