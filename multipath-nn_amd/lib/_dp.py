@@ -133,8 +133,9 @@ def agree(ok):
 
 
 def captured_collectives_work():
-    """Self-test, run once per process group with MORE than one rank before any training step is captured: an
-    all-reduce recorded into a hipGraph and replayed twice must give the sum over the ranks, on every rank.  The
+    """Self-test, run once per process group with MORE than one rank before any training step is captured: two dependent
+    all-reduces recorded into ONE hipGraph (as K training steps per graph hold K of them) and replayed twice must give the sums
+    over the ranks, on every rank.  The
     one-graph form of the data-parallel step (lib/_plan.py) is only used when this passed everywhere; otherwise all
     ranks use one graph per bucket section with the collectives issued from the host."""
     import warnings
@@ -150,11 +151,12 @@ def captured_collectives_work():
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
             buf.copy_(src)
-            h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
-            with torch.cuda.stream(side):                         # (the shape of the real step: a consumer on a third stream)
-                h.wait()
-                buf.mul_(2.0)
-            torch.cuda.current_stream().wait_stream(side)
+            for _ in range(2):                                    # (TWO dependent collectives in one graph: the K-step form)
+                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+                with torch.cuda.stream(side):                     # (the shape of the real step: a consumer on a third stream)
+                    h.wait()
+                    buf.mul_(2.0)
+                torch.cuda.current_stream().wait_stream(side)
     except Exception as e:                                          # noqa: BLE001 -- any failure means "do not capture"
         warnings.warn('capturing an RCCL collective failed (%r): the data-parallel step uses section graphs' % (e,))
         g = None
@@ -170,7 +172,7 @@ def captured_collectives_work():
         for _ in range(2):
             g.replay()
         torch.cuda.synchronize()
-        ok = bool(torch.all(buf == float(world * (world + 1))).item())
+        ok = bool(torch.all(buf == float(2 * world * world * (world + 1))).item())      # sum(rank + 1) x 2, summed again, x 2
     except Exception as e:                                          # noqa: BLE001
         warnings.warn('replaying a captured RCCL collective failed (%r): the data-parallel step uses section graphs' % (e,))
         ok = False
