@@ -20,6 +20,7 @@ eng = net.engine()
 n = int(os.environ.get('BATCH', '128'))
 eng._ensure_capacity(n)
 eng.x0[:n].uniform_(); eng.y[:n].zero_(); eng.y[:n, 0] = 1
+eng.co_share = int(os.environ.get('CO_SHARE', '1'))      # (the planner setting of a co-trained group: grids for slots / share, level launches)
 feed = {net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr', net.λ_lrn: 0.1, net.τ: 1.0}
 for _ in range(3): net.train.run(feed)
 torch.cuda.synchronize()
