@@ -76,6 +76,9 @@ def set_exit_fractions(net, feed, n, fractions):
         alive[order[:max(want, 0)]] = False
 
 
+CLOCK_WARMUP = 96        # untimed training steps in front of the warm-up steps: the GPU's clocks after the idle time of graph capture (main())
+
+
 def cpu_baseline(batch, seconds=24.0):
     """The oracle (oracle/ref_net.py, torch-CPU fp32, all host cores) on the same step."""
     import arch_and_hypers as A
@@ -416,13 +419,22 @@ def main():
     if spg > 1:
         for _ in range(3):                     # (warm-up, capture, first replay of the K-step graph)
             net.train.run_steps([feed] * spg)
-    run_steps(max(args.warmup, 3))
-    # (the host runs about one replay ahead of the GPU -- hipGraphLaunch returns when the previous replay has freed its queue
-    # slots --, so a host pause of a few milliseconds inside the 10-100 ms timed region stalls the GPU: one run in ten read 10 %
-    # low with an unchanged steady state.  The one pause this process can rule out is its own garbage collector.)
+    # The GPU must be BUSY right up to the timed region: its power management drops the clocks within milliseconds of idle and
+    # takes milliseconds of work to bring them back -- the first 20-step (10 ms) region after 5 ms of idle reads + 1.5 %, after
+    # 20-100 ms + 3 %, after 1 s + 5 %, after 5 s + 10 % (tools/clock_ramp_probe.py, profiles/r06_clock_ramp.txt); a 200-step
+    # region dilutes that tenfold.  So everything the host has to do -- Python's garbage collection, which round 6 first put
+    # BETWEEN the warm-up and the region: tens of milliseconds of idle -- happens before the warm-up steps, and nothing but
+    # the barrier separates them from the timed steps.  (The host enqueues a whole 200-step region in ~6 ms, 0.03 ms per
+    # step: it is not the host that the region waits for.)
+    # Capturing the graphs above left the GPU idle for ~100 ms, and the driver's W = 5 warm-up steps are 2.4 ms of work: not
+    # enough to bring the clocks back (20-step regions then read 0.496-0.502 ms per step against a steady state of 0.486).
+    # CLOCK_WARMUP further untimed steps (~50 ms of the same work, reported as config.clock_warmup_steps) run in front of
+    # the W warm-up steps; the timed region is still exactly `steps` full training steps.
     import gc
     gc.collect()
     gc.disable()
+    run_steps(CLOCK_WARMUP)
+    run_steps(max(args.warmup, 3))
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
@@ -629,7 +641,8 @@ def main():
                        'global_batch': n * world, 'per_gpu_batch': n, 'parallelism': 'dp%d' % world, 'rccl_ranks': (dist.get_world_size() if world > 1 else 1),
                        'allreduce': ar,
                        **(dp_check or {}),
-                       'hip_graph': bool(eng.use_graph), 'steps_per_graph': spg, 'streams': eng.n_streams if eng.multi_stream else 1},
+                       'hip_graph': bool(eng.use_graph), 'steps_per_graph': spg, 'streams': eng.n_streams if eng.multi_stream else 1,
+                       'clock_warmup_steps': CLOCK_WARMUP},
             'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
                          'frac': ach / PEAK_F32_MFMA, 'traffic': traffic, 'traffic_source': traffic_src,
                          'traffic_stale': traffic_stale,
