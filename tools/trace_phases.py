@@ -24,10 +24,31 @@ eng.co_share = int(os.environ.get('CO_SHARE', '1'))      # (the planner setting 
 feed = {net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr', net.λ_lrn: 0.1, net.τ: 1.0}
 for _ in range(3): net.train.run(feed)
 torch.cuda.synchronize()
-prog = eng.program('tr', n)
-ops = [o for o in list(prog['fwd']) + list(prog['bwd']) if o.what not in ('fork', 'join')]
 st = torch.cuda.current_stream()
-eng._zero(True); eng._pack()
+CO_K = int(os.environ.get('CO_K', '0'))
+if CO_K > 1:
+    # the MERGED launches of CO_K co-trained nets (lib/_co.py: one launch per layer for all of them): what the workgroups of
+    # a saturated launch do, all nets' workgroups contending.  Rows are grouped by (member, body) over all nets.
+    from lib._co import CoTrainer
+    nets, feeds = [net], [feed]
+    for i in range(1, CO_K):
+        nt = A.ac_chain(k_cpt=A.k_cpts[i % 8], seed=1234 + i)((32, 32, 3), (10,))
+        e = nt.engine()
+        e.x0[:n].uniform_(); e.y[:n].zero_(); e.y[:n, i % 10] = 1
+        nets.append(nt)
+        feeds.append({nt.x0: e.x0[:n], nt.y: e.y[:n], nt.mode: 'tr', nt.λ_lrn: 0.1, nt.τ: 1.0})
+    eng.co_share = 1
+    co = CoTrainer(nets)
+    for _ in range(3): co.run(feeds)
+    torch.cuda.synchronize()
+    co.use_graph = False
+    for e in co.engs: e.mark_dirty()
+    for e in co.engs: e._begin(True)
+    ops = list(co._program(n)['ops'])
+else:
+    prog = eng.program('tr', n)
+    ops = [o for o in list(prog['fwd']) + list(prog['bwd']) if o.what not in ('fork', 'join')]
+    eng._zero(True); eng._pack()
 for op in ops: op(st.cuda_stream)
 torch.cuda.synchronize()
 NWG = 1 << 16
@@ -46,6 +67,10 @@ for op in ops:
     e0.record(st); op(st.cuda_stream); e1.record(st); e1.synchronize()
     _hip.check(eng.lib.mpnn_debug_set_trace(None), 'set_trace')
     t = buf.cpu().numpy().reshape(NWG, SL)
+    if os.environ.get('TRACE_DUMP'):              # raw rows (index = blockIdx.x) of every traced launch, for offline analysis
+        os.makedirs(os.environ['TRACE_DUMP'], exist_ok=True)
+        nz = np.nonzero(t[:, 0])[0]
+        np.save(os.path.join(os.environ['TRACE_DUMP'], '%02d_%s.npy' % (ops.index(op), op.what)), np.concatenate([nz[:, None], t[nz]], axis=1))
     rows = t[t[:, 0] != 0]
     if not len(rows):
         continue
