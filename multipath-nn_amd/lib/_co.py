@@ -270,12 +270,14 @@ class CoTrainer:
             return one_by_one()
         n = ns.pop()
         key = ('K', n, S)
+        # (the merged program FIRST: it drops every joint graph when an engine has reallocated its buffers since -- a larger
+        # evaluation batch came by -- and a graph looked up before that would be replayed over the old buffers)
+        prog = self._program(n)
         g = self._graphs.get(key)
         if g is None:
             one_by_one()                                        # (first call: loads the code objects, settles the capacities)
             self._graphs[key] = 'warm'
             return
-        prog = self._program(n)
         if not prog['fold']:
             return one_by_one()
         # the S x K rows of schedule values: one asynchronous upload through a ring of pinned buffers

@@ -425,6 +425,49 @@ def test_k_step_joint_replay_equals_k_joint_steps(kind, K, S):
     assert any(k[0] == 'K' and not isinstance(v, str) for k, v in co_a._graphs.items() if isinstance(k, tuple)), 'no K-step graph was captured'
 
 
+def test_k_step_joint_graph_is_dropped_when_an_engine_reallocates():
+    """An evaluation at a larger batch between two K-step joint replays reallocates an engine's buffers: the merged program
+    and every joint graph are rebuilt (CoTrainer._program compares the engines' generations BEFORE run_steps looks its
+    graph up) -- the next replay must not run the old graph over the old buffers.  Same results as single joint steps."""
+    import arch_and_hypers as A
+    from lib._co import CoTrainer
+    K, S, n = 2, 3, 16
+    mk = lambda i: A.ac_chain(k_cpt=A.k_cpts[i % 8])
+    a_nets, b_nets = _nets([mk(i) for i in range(K)]), _nets([mk(i) for i in range(K)])
+
+    def fill(nets):
+        for i, net in enumerate(nets):
+            e = net.engine()
+            e.ensure_capacity(n)
+            x0, y = batch(n, seed=60 + i)
+            e.x0[:n].copy_(torch.from_numpy(x0)); e.y[:n].copy_(torch.from_numpy(y))
+    fill(a_nets); fill(b_nets)
+    co_a, co_b = CoTrainer(a_nets), CoTrainer(b_nets)
+
+    def feeds(nets, t):
+        return [{net.x0: net.engine().x0[:n], net.y: net.engine().y[:n], net.mode: 'tr', net.λ_lrn: 0.05 / (1 + t),
+                 net.τ: 0.6 + 0.05 * t + 0.1 * i} for i, net in enumerate(nets)]
+
+    def rounds(r0, r1):
+        for rnd in range(r0, r1):
+            co_a.run_steps([feeds(a_nets, rnd * S + j) for j in range(S)])
+            for j in range(S):
+                co_b.run(feeds(b_nets, rnd * S + j))
+            torch.cuda.synchronize()
+            for i, (a, b) in enumerate(zip(a_nets, b_nets)):
+                ea, eb = a.engine(), b.engine()
+                assert torch.equal(ea.P, eb.P) and torch.equal(ea.A, eb.A) and torch.equal(ea.S, eb.S), (rnd, i)
+    rounds(0, 3)                                              # warm-up, capture + replay, a replay
+    gens = [net.engine().generation for net in a_nets]
+    for nets in (a_nets, b_nets):                             # a larger evaluation batch: net 0's buffers move
+        net = nets[0]
+        x0, y = batch(300, seed=7)
+        net.eval({net.x0: x0, net.y: y, net.τ: 0.5})
+    assert a_nets[0].engine().generation != gens[0], 'the evaluation did not reallocate'
+    fill(a_nets); fill(b_nets)                                # (the resident input buffers are new ones)
+    rounds(3, 6)
+
+
 def test_k_step_joint_replay_through_the_input_pipeline():
     """... and with the input pipeline bound (Dataset.bind_cotrainer): launch 0 of step j of the joint graph gathers every
     net's batch from record slot j; stage_cotrainer_draws_k draws the S x K batches (every net from its own DrawStream: the
