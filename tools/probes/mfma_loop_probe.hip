@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void probe(float *out, unsigned long long *tic
     f32x4 br[3] = {f32x4{1.f, 2.f, 3.f, 4.f}, f32x4{5.f, 6.f, 7.f, 8.f}, f32x4{9.f, 1.f, 2.f, 3.f}};
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     f32x4 ra = {0.1f * lane, 0.2f, 0.3f, 0.4f}, rb = {0.5f, 0.25f * lane, 0.125f, 1.f};
-    constexpr bool LDS = V >= 2, BAR = V >= 3, STAGE = V >= 4, INTER = V == 5 || V == 6 || V == 8, TWO = V == 1 || V == 6, GL = V >= 7;
+    constexpr bool LDS = V >= 2, BAR = V >= 3, STAGE = V >= 4, INTER = V == 5 || V == 6 || V == 8, TWO = V == 1 || V == 6, GL = V == 7 || V == 8 || V == 10;
+    constexpr bool FIRST = V == 9 || V == 10;      // the next unit's staging BEFORE this unit's MFMAs: the LDS writes complete under them
     const f32x4 *gsrc = src + (size_t)blockIdx.x * 512 + tid;
     f32x4 nx[2] = {xr[0], xr[1]};
 
@@ -76,6 +77,10 @@ __global__ __launch_bounds__(256) void probe(float *out, unsigned long long *tic
     for (int u = 0; u < units; ++u) {
         const f32x4 *cur = tile[u & 1], *wl = wt[u & 1];
         if (GL) { nx[0] = gsrc[(u & 7) * 65536]; nx[1] = gsrc[(u & 7) * 65536 + 256]; }
+        if (STAGE && FIRST) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) stage_slice(k, (u + 1) & 1);
+        }
         if (!LDS) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256) void probe(float *out, unsigned long long *tic
             }
         }
         asm volatile("s_nop 15");
-        if (STAGE && !INTER) {
+        if (STAGE && !INTER && !FIRST) {
 #pragma unroll
             for (int k = 0; k < 5; ++k) stage_slice(k, (u + 1) & 1);
         }
@@ -168,7 +173,8 @@ int main(int argc, char **argv) {
         run<0>(units, wpc, out, ticks, src); run<1>(units, wpc, out, ticks, src); run<2>(units, wpc, out, ticks, src);
         run<3>(units, wpc, out, ticks, src); run<4>(units, wpc, out, ticks, src); run<5>(units, wpc, out, ticks, src);
         run<6>(units, wpc, out, ticks, src); run<7>(units, wpc, out, ticks, src); run<8>(units, wpc, out, ticks, src);
-        for (int xv : {40, 80, 120, 160, 240}) { run<4>(units, wpc, out, ticks, src, xv); run<7>(units, wpc, out, ticks, src, xv); }
+        run<9>(units, wpc, out, ticks, src); run<10>(units, wpc, out, ticks, src);
+        for (int xv : {40, 80, 120, 160, 240}) { run<4>(units, wpc, out, ticks, src, xv); run<7>(units, wpc, out, ticks, src, xv); run<10>(units, wpc, out, ticks, src, xv); }
     }
     return 0;
 }
