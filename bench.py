@@ -321,13 +321,53 @@ def time_experiment(dev, n, single_ms, reps=100):
         torch.cuda.synchronize()
         per.append(e0.elapsed_time(e1) / max(1, reps // 5))
     ms = float(np.median(per))
-    return {'nets': K, 'what': 'cifar10-ac experiment: ac_chain(k_cpt=k) for the 8 k_cpts, batch %d each, co-trained: %d groups of %d '
+    # ... and TWO experiments of one architecture together (`train-nets cifar10-ac --with cifar10-cr`: the eight ac_chain and
+    # the eight cr_chain nets, 16 per joint step): twice the tile-rows per launch for the same 768 resident workgroups --
+    # smaller, more equal shares ("where the idle quarter sits")
+    g_sizes, g_streams, g_share = [c.K for c in cg.groups], len(cg.streams), cg.share
+    two = None
+    try:
+        nets2, feeds2 = list(nets), list(feeds)
+        for i, k in enumerate(A.k_cpts):
+            net = A.cr_chain(k_cpt=k, seed=4321 + i)((32, 32, 3), (10,))
+            net.to(dev)
+            eng = net.engine()
+            eng.ensure_capacity(n, train=True)
+            eng.x0[:n].copy_(torch.rand((n, 32, 32, 3), generator=g).to(dev))
+            eng.y[:n].copy_(torch.nn.functional.one_hot(torch.randint(0, 10, (n,), generator=g), 10).float().to(dev))
+            nets2.append(net)
+            feeds2.append({net.x0: eng.x0[:n], net.y: eng.y[:n], net.mode: 'tr', net.λ_lrn: A.λ_lrn(0), net.τ: A.τ_cr(0)})
+        del cg
+        cg2 = CoGroups.plan(nets2, streams=4)
+        for _ in range(5):
+            cg2.run(feeds2)
+        cg2.join()
+        torch.cuda.synchronize()
+        per2 = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main_st)
+            for _ in range(max(1, reps // 10)):
+                cg2.run(feeds2)
+            cg2.join()
+            e1.record(main_st)
+            torch.cuda.synchronize()
+            per2.append(e0.elapsed_time(e1) / max(1, reps // 10))
+        ms2 = float(np.median(per2))
+        two = {'what': 'cifar10-ac + cifar10-cr: 16 nets of one architecture, %s on %d streams' % ([c.K for c in cg2.groups], len(cg2.streams)),
+               'nets': len(nets2), 'images_per_s': len(nets2) * n / (ms2 * 1e-3), 'ms_per_joint_step': ms2,
+               'speedup_vs_serial': len(nets2) * single_ms / ms2,
+               'step_frac_of_mfma_roofline': len(nets2) * n / (ms2 * 1e-3) * F_TRAIN / 1e12 / PEAK_F32_MFMA}
+        del cg2
+    except Exception as e:
+        two = {'error': repr(e)}
+    return {'nets': K, 'two_experiments': two, 'what': 'cifar10-ac experiment: ac_chain(k_cpt=k) for the 8 k_cpts, batch %d each, co-trained: %d groups of %d '
                                '(one hipGraph per group: launch j = launch j of its nets) side by side on %d streams'
-                               % (n, len(cg.groups), max(c.K for c in cg.groups), len(cg.streams)),
+                               % (n, len(g_sizes), max(g_sizes), g_streams),
             'images_per_s': K * n / (ms * 1e-3), 'ms_per_joint_step': ms, 'ms_per_net_step': ms / K,
             'images_per_s_serial': n / (single_ms * 1e-3), 'speedup_vs_serial': K * single_ms / ms,
             'step_frac_of_mfma_roofline': K * n / (ms * 1e-3) * F_TRAIN / 1e12 / PEAK_F32_MFMA,
-            'groups': [c.K for c in cg.groups], 'streams': len(cg.streams), 'share': cg.share,
+            'groups': g_sizes, 'streams': g_streams, 'share': g_share,
             'one_group': {'what': 'all 8 nets in ONE joint hipGraph on one stream', 'images_per_s': K * n / (ms_one * 1e-3),
                           'ms_per_joint_step': ms_one, 'speedup_vs_serial': K * single_ms / ms_one},
             'roofline': roof}
