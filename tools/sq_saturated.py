@@ -23,7 +23,7 @@ st = torch.cuda.current_stream()
 g = torch.Generator().manual_seed(0)
 
 if 'cotrain' in what:
-    K, n = 8, 128
+    K, n = int(os.environ.get('CO_K', '8')), 128          # (CO_K=16: two experiments' worth of nets per launch)
     nets, feeds = [], []
     for i in range(K):
         net = A.ac_chain(k_cpt=A.k_cpts[i % 8], seed=1234 + i)((32, 32, 3), (10,))
